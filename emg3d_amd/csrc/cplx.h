@@ -1,0 +1,70 @@
+// Scalar types for the fp64 / complex-fp64 instantiations of every kernel.
+//
+// The reference runs its kernels either on complex128 (frequency domain) or on
+// float64 (Laplace domain) arrays (reference emg3d/fields.py:93-98). `cplx` is a
+// plain {re, im} pair laid out exactly like numpy complex128 / C99 double complex,
+// so device buffers can be filled from either without conversion.
+//
+// EMG_HD expands to __host__ __device__ under hipcc and to nothing under a plain
+// host compiler; the latter is used ONLY by the CPU emulation harness in
+// tests/emu/ (unit tests of the kernel bodies without a GPU), never by the product.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define EMG_HD __host__ __device__ __forceinline__
+#else
+#define EMG_HD inline
+#endif
+
+namespace emg {
+
+struct cplx {
+    double re, im;
+    EMG_HD cplx() {}
+    EMG_HD cplx(double r) : re(r), im(0.0) {}
+    EMG_HD cplx(double r, double i) : re(r), im(i) {}
+};
+
+EMG_HD cplx operator+(cplx a, cplx b) { return cplx(a.re + b.re, a.im + b.im); }
+EMG_HD cplx operator-(cplx a, cplx b) { return cplx(a.re - b.re, a.im - b.im); }
+EMG_HD cplx operator-(cplx a) { return cplx(-a.re, -a.im); }
+EMG_HD cplx operator*(cplx a, cplx b)
+{
+    return cplx(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+EMG_HD cplx operator*(double a, cplx b) { return cplx(a * b.re, a * b.im); }
+EMG_HD cplx operator*(cplx a, double b) { return cplx(a.re * b, a.im * b); }
+EMG_HD cplx operator+(cplx a, double b) { return cplx(a.re + b, a.im); }
+EMG_HD cplx operator+(double a, cplx b) { return cplx(a + b.re, b.im); }
+EMG_HD cplx operator-(cplx a, double b) { return cplx(a.re - b, a.im); }
+EMG_HD cplx &operator+=(cplx &a, cplx b) { a.re += b.re; a.im += b.im; return a; }
+EMG_HD cplx &operator-=(cplx &a, cplx b) { a.re -= b.re; a.im -= b.im; return a; }
+EMG_HD cplx &operator+=(cplx &a, double b) { a.re += b; return a; }
+EMG_HD cplx &operator*=(cplx &a, cplx b) { a = a * b; return a; }
+EMG_HD cplx &operator*=(cplx &a, double b) { a.re *= b; a.im *= b; return a; }
+
+// 1/z with one real division: conj(z) / |z|^2.
+EMG_HD cplx recip(cplx a)
+{
+    double d = 1.0 / (a.re * a.re + a.im * a.im);
+    return cplx(a.re * d, -a.im * d);
+}
+EMG_HD double recip(double a) { return 1.0 / a; }
+
+EMG_HD double abs2(cplx a) { return a.re * a.re + a.im * a.im; }
+EMG_HD double abs2(double a) { return a * a; }
+
+template <class T> EMG_HD T zero();
+template <> EMG_HD double zero<double>() { return 0.0; }
+template <> EMG_HD cplx zero<cplx>() { return cplx(0.0, 0.0); }
+
+// a*b+c helpers (the compiler contracts these into v_fma_f64)
+EMG_HD double fmadd(double a, double b, double c) { return a * b + c; }
+EMG_HD cplx fmadd(double a, cplx b, cplx c) { return cplx(a * b.re + c.re, a * b.im + c.im); }
+EMG_HD cplx fmadd(cplx a, cplx b, cplx c)
+{
+    return cplx(a.re * b.re - a.im * b.im + c.re, a.re * b.im + a.im * b.re + c.im);
+}
+
+}  // namespace emg

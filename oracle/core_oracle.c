@@ -1,0 +1,66 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C99) of the numba kernels of the reference's multigrid
+ * inner loop, emg3d/core.py (reference @ /root/reference). Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the emg3d_amd product path never does.
+ *
+ * Parity status: PINNED. Checked in the build container against the reference
+ * itself (imported un-jitted, tools/make_golden.py / tools/check_oracle_vs_reference.py)
+ * and against the committed golden vectors in tests/golden/ (tests/test_oracle.py).
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -std=c99, no -ffast-math).
+ */
+#include <complex.h>
+#include <stdlib.h>
+#include <stddef.h>
+
+#define PASTE_(a, b) a##b
+#define PASTE(a, b) PASTE_(a, b)
+
+/* real instantiation:  *_d */
+#define T double
+#define FN(name) PASTE(name, _d)
+#include "core_generic.h"
+#undef T
+#undef FN
+
+/* complex instantiation:  *_z */
+#define T double complex
+#define FN(name) PASTE(name, _z)
+#include "core_generic.h"
+#undef T
+#undef FN
+
+/* core.restrict_weights -- reference emg3d/core.py:2004-2076.
+ * n = len(cnodes); outputs wl, w0, wr of length n. d has n+1 entries. */
+void restrict_weights(const double *nodes, const double *cell_centers, const double *h, int nh,
+                      const double *cnodes, const double *ccell_centers, const double *ch, int n,
+                      double *wl, double *w0, double *wr)
+{
+    double *d = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    int i;
+    int nch = n - 1;           /* number of coarse cells */
+    int nnodes = nh + 1;       /* number of fine nodes   */
+
+    /* dual grid cell widths (core.py:2055-2059) */
+    d[0] = h[0] / 2;
+    d[n] = h[nh - 1] / 2;
+    for (i = 1; i < n; i++) d[i] = (h[2 * i - 2] + h[2 * i - 1]) / 2.;
+
+    /* left weight (core.py:2062-2065) */
+    for (i = 0; i < n; i++) wl[i] = 1 / d[i];
+    wl[0] *= (nodes[0] - h[0] / 2) - (cnodes[0] - ch[0] / 2);
+    for (i = 1; i < n; i++) wl[i] *= cell_centers[2 * i - 1] - ccell_centers[i - 1];
+
+    /* central weight (core.py:2068) */
+    for (i = 0; i < n; i++) w0[i] = 1.0;
+
+    /* right weight (core.py:2071-2074) */
+    for (i = 0; i < n; i++) wr[i] = 1 / d[i + 1];
+    wr[n - 1] *= (cnodes[n - 1] + ch[nch - 1] / 2) - (nodes[nnodes - 1] + h[nh - 1] / 2);
+    for (i = 0; i < n - 1; i++) wr[i] *= ccell_centers[i] - cell_centers[2 * i];
+
+    free(d);
+}

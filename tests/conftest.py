@@ -1,0 +1,31 @@
+"""pytest configuration: `gpu` marker + shared fixture loaders."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope='session')
+def golden_kernels():
+    return np.load(os.path.join(GOLDEN, 'kernels.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_solves():
+    return np.load(os.path.join(GOLDEN, 'solves.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_regression():
+    return np.load(os.path.join(GOLDEN, 'regression_small.npz'), allow_pickle=False)

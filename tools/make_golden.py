@@ -1,0 +1,297 @@
+"""Generate the golden vectors in tests/golden/ from the reference (build container only).
+
+The reference is imported un-jitted from /root/reference (stubs for numba /
+empymod / scooby in tools/oracle_stubs; they contain no reference code). The
+fixtures are DATA: inputs and the reference's outputs. Nothing of the
+reference's source travels.
+
+    python tools/make_golden.py            # all fixtures (takes a few minutes)
+
+Fixtures written (each ≤ 1.5 MB):
+    tests/golden/regression_small.npz   arrays of the reference's own golden file
+                                        tests/data/regression.npz (res / reg_2 / lap)
+    tests/golden/kernels.npz            per-function input/output vectors of emg3d.core
+                                        and of the solver.py wrappers on small grids
+    tests/golden/solves.npz             converged reference solves (tol 1e-10) incl.
+                                        per-cycle error history
+Metadata (scipy version, mu_0, seeds) is stored in every file.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(HERE, 'oracle_stubs'), '/root/reference',
+                '/root/reference/tests']
+
+import scipy  # noqa: E402
+import scipy.constants  # noqa: E402
+import emg3d  # noqa: E402  (the reference)
+from emg3d import core as rcore, solver as rsolver  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+META = {
+    'meta_scipy_version': scipy.__version__,
+    'meta_numpy_version': np.__version__,
+    'meta_mu_0': scipy.constants.mu_0,
+    'meta_epsilon_0': scipy.constants.epsilon_0,
+    'meta_reference': 'emsig/emg3d @ /root/reference (post v1.8.7), un-jitted',
+}
+
+
+def widths(ncore, npad, width, factor):
+    pad = ((np.ones(npad) * np.abs(factor)) ** (np.arange(npad) + 1)) * width
+    return np.r_[pad[::-1], np.ones(ncore) * width, pad]
+
+
+def vm_arrays(vm):
+    return {'eta_x': vm.eta_x, 'eta_y': vm.eta_y, 'eta_z': vm.eta_z, 'zeta': vm.zeta}
+
+
+# ------------------------------------------------------------------------------
+def regression_small():
+    d = emg3d.load('/root/reference/tests/data/regression.npz', verb=0)
+    out = dict(META)
+    out['meta_source_file'] = 'tests/data/regression.npz (reference test data)'
+    out['meta_file_version'] = d['_version']
+    for key in ('res', 'lap'):
+        r = d[key]
+        g = r['grid']
+        out[f'{key}_hx'], out[f'{key}_hy'], out[f'{key}_hz'] = g.h
+        out[f'{key}_origin'] = np.asarray(g.origin, dtype=float)
+        m = r['input_model']
+        out[f'{key}_res_xyz'] = np.array([m['property_x'], m['property_y'], m['property_z']], float)
+        out[f'{key}_source'] = np.asarray(r['input_source']['source'], float)
+        out[f'{key}_frequency'] = float(r['input_source']['frequency'])
+        out[f'{key}_sfield'] = np.asarray(r['sfield'].field)
+        for k in ('Fresult', 'Wresult', 'Vresult', 'bicresult'):
+            if k in r:
+                out[f'{key}_{k}'] = np.asarray(r[k].field)
+    r = d['reg_2']
+    g = r['grid']
+    out['reg2_hx'], out['reg2_hy'], out['reg2_hz'] = g.h
+    out['reg2_origin'] = np.asarray(g.origin, dtype=float)
+    out['reg2_res_x'] = np.asarray(r['model'].property_x)
+    out['reg2_res_y'] = np.asarray(r['model'].property_y)
+    out['reg2_res_z'] = np.asarray(r['model'].property_z)
+    out['reg2_frequency'] = float(r['sfield'].frequency)
+    out['reg2_sfield'] = np.asarray(r['sfield'].field)
+    out['reg2_result'] = np.asarray(r['result'].field)
+    for k, v in r['inp'].items():
+        out[f'reg2_inp_{k}'] = v
+    np.savez_compressed(os.path.join(OUT, 'regression_small.npz'), **out)
+    print('regression_small.npz written')
+
+
+# ------------------------------------------------------------------------------
+def kernel_cases():
+    """(name, shape, dtype, case) small stretched grids; 2-cell directions included."""
+    return [
+        ('c_tri', (6, 4, 8), np.complex128, 'triaxial'),
+        ('c_iso', (4, 8, 6), np.complex128, 'isotropic'),
+        ('c_vti', (8, 6, 4), np.complex128, 'VTI'),
+        ('r_tri', (6, 8, 4), np.float64, 'triaxial'),
+        ('r_iso', (4, 4, 4), np.float64, 'isotropic'),
+        ('c_x2', (2, 6, 4), np.complex128, 'triaxial'),
+        ('c_y2', (6, 2, 4), np.complex128, 'HTI'),
+        ('c_z2', (4, 6, 2), np.complex128, 'triaxial'),
+    ]
+
+
+def build_case(rng, shape, dtype, case):
+    nx, ny, nz = shape
+    hx = widths(nx - 2 * (nx // 4), nx // 4, 40., 1.3) if nx > 2 else np.array([40., 55.])
+    hy = widths(ny - 2 * (ny // 4), ny // 4, 50., 1.2) if ny > 2 else np.array([50., 45.])
+    hz = widths(nz - 2 * (nz // 4), nz // 4, 30., 1.4) if nz > 2 else np.array([30., 42.])
+    grid = emg3d.TensorMesh([hx, hy, hz], origin=(-hx.sum() / 2, -hy.sum() / 2, -hz.sum()))
+    n = grid.n_cells
+    px = 10 ** rng.uniform(-1, 2, n)
+    kw = {'property_x': px}
+    if case in ('HTI', 'triaxial'):
+        kw['property_y'] = px * rng.uniform(0.5, 2, n)
+    if case in ('VTI', 'triaxial'):
+        kw['property_z'] = px * rng.uniform(1, 3, n)
+    model = emg3d.Model(grid, mapping='Resistivity', **kw)
+    freq = 0.77 if dtype == np.complex128 else -1.9
+    sfield = emg3d.Field(grid, frequency=freq)
+    vm = emg3d.models.VolumeModel(model, sfield)
+
+    def rand_field(pec):
+        f = emg3d.Field(grid, frequency=freq)
+        v = rng.standard_normal(f.field.size)
+        if dtype == np.complex128:
+            v = v + 1j * rng.standard_normal(f.field.size)
+        f.field = v
+        if pec:
+            f.fx[:, 0, :] = f.fx[:, -1, :] = 0.
+            f.fx[:, :, 0] = f.fx[:, :, -1] = 0.
+            f.fy[0, :, :] = f.fy[-1, :, :] = 0.
+            f.fy[:, :, 0] = f.fy[:, :, -1] = 0.
+            f.fz[0, :, :] = f.fz[-1, :, :] = 0.
+            f.fz[:, 0, :] = f.fz[:, -1, :] = 0.
+        return f
+    return grid, model, vm, freq, rand_field
+
+
+def kernels():
+    rng = np.random.default_rng(20260928)
+    out = dict(META)
+    out['meta_seed'] = 20260928
+    names = []
+    for name, shape, dtype, case in kernel_cases():
+        names.append(name)
+        grid, model, vm, freq, rand_field = build_case(rng, shape, dtype, case)
+        p = name + '_'
+        out[p + 'hx'], out[p + 'hy'], out[p + 'hz'] = grid.h
+        out[p + 'origin'] = np.asarray(grid.origin, float)
+        out[p + 'case'] = case
+        out[p + 'frequency'] = freq
+        out[p + 'res_x'] = model.property_x
+        if model.property_y is not None:
+            out[p + 'res_y'] = model.property_y
+        if model.property_z is not None:
+            out[p + 'res_z'] = model.property_z
+        for k, v in vm_arrays(vm).items():
+            out[p + k] = np.asarray(v)
+        h = grid.h
+        vma = (vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+
+        # amat_x with non-zero boundary entries
+        e, s = rand_field(False), rand_field(False)
+        out[p + 'amat_e'], out[p + 'amat_r_in'] = e.field.copy(), s.field.copy()
+        r = s.copy()
+        rcore.amat_x(r.fx, r.fy, r.fz, e.fx, e.fy, e.fz, *vma, *h)
+        out[p + 'amat_r_out'] = r.field.copy()
+
+        # smoothers through the wrapper's kernels, nu = 1 and 2 (first sweep backward)
+        e, s = rand_field(True), rand_field(True)
+        out[p + 'gs_e_in'], out[p + 'gs_s'] = e.field.copy(), s.field.copy()
+        for fn in ('gauss_seidel', 'gauss_seidel_x', 'gauss_seidel_y', 'gauss_seidel_z'):
+            for nu in (1, 2):
+                f = e.copy()
+                getattr(rcore, fn)(f.fx, f.fy, f.fz, s.fx, s.fy, s.fz, *vma, *h, nu)
+                out[p + f'{fn}_nu{nu}'] = f.field.copy()
+
+        # residual norm (solver.residual)
+        out[p + 'residual_norm'] = rsolver.residual(vm, s, e, True)
+
+        # restriction (model + field) and prolongation for every sc_dir that is valid
+        res = rand_field(False)
+        out[p + 'restrict_res'] = res.field.copy()
+        for sc_dir in range(7):
+            rx, ry, rz = [1 if sc_dir in s_ else 2 for s_ in ([1, 5, 6], [2, 4, 6], [3, 4, 5])]
+            if any(r_ == 2 and (n_ % 2 != 0 or n_ < 4) for r_, n_ in zip((rx, ry, rz), shape)):
+                continue
+            cmodel, cs, ce = rsolver.restriction(vm, s, res, sc_dir)
+            q = p + f'sc{sc_dir}_'
+            out[q + 'csfield'] = cs.field.copy()
+            out[q + 'ceta_x'] = np.asarray(cmodel.eta_x)
+            out[q + 'ceta_y'] = np.asarray(cmodel.eta_y)
+            out[q + 'ceta_z'] = np.asarray(cmodel.eta_z)
+            out[q + 'czeta'] = np.asarray(cmodel.zeta)
+            wx, wy, wz = rsolver._get_restriction_weights(vm.grid, cmodel.grid, sc_dir)
+            for nm, w in zip('xyz', (wx, wy, wz)):
+                out[q + f'w{nm}'] = np.array(w)
+            # prolongation of a random coarse field onto a random fine field
+            ce.field = (rng.standard_normal(ce.field.size) +
+                        (1j * rng.standard_normal(ce.field.size) if dtype == np.complex128 else 0))
+            fine = rand_field(True)
+            out[q + 'prol_c'] = ce.field.copy()
+            out[q + 'prol_f_in'] = fine.field.copy()
+            rsolver.prolongation(fine, ce, sc_dir)
+            out[q + 'prol_f_out'] = fine.field.copy()
+    out['meta_cases'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'kernels.npz'), **out)
+    print('kernels.npz written')
+
+
+# ------------------------------------------------------------------------------
+def solves():
+    rng = np.random.default_rng(7)
+    out = dict(META)
+    names = []
+
+    def run(name, grid, model, src, freq, **kw):
+        t0 = time.time()
+        sfield = emg3d.get_source_field(grid, src, freq)
+        ef, info = rsolver.solve(model, sfield, return_info=True, sslsolver=False, verb=0, **kw)
+        vm = emg3d.models.VolumeModel(model, sfield)
+        p = name + '_'
+        names.append(name)
+        out[p + 'hx'], out[p + 'hy'], out[p + 'hz'] = grid.h
+        out[p + 'origin'] = np.asarray(grid.origin, float)
+        out[p + 'case'] = model.case
+        out[p + 'frequency'] = float(freq)
+        out[p + 'source'] = np.asarray(src, float)
+        out[p + 'res_x'] = model.property_x
+        if model.property_y is not None:
+            out[p + 'res_y'] = model.property_y
+        if model.property_z is not None:
+            out[p + 'res_z'] = model.property_z
+        for k, v in vm_arrays(vm).items():
+            out[p + k] = np.asarray(v)
+        out[p + 'sfield'] = np.asarray(sfield.field)
+        out[p + 'efield'] = np.asarray(ef.field)
+        out[p + 'it_mg'] = info['it_mg']
+        out[p + 'exit_message'] = info['exit_message']
+        out[p + 'error_at_cycle'] = info['error_at_cycle']
+        out[p + 'ref_error'] = info['ref_error']
+        for k, v in kw.items():
+            out[p + 'kw_' + k] = v
+        print(f"  {name}: {info['exit_message']} it={info['it_mg']} "
+              f"rel={info['rel_error']:.3e}  ({time.time() - t0:.1f} s)")
+
+    # (a) config-1 family: uniform fullspace, plain F-cycle (docs/dev/tests.rst:193-219), nx=16
+    h = np.ones(16) * 50.
+    grid = emg3d.TensorMesh([h, h, h], origin=(-400, -400, -400))
+    model = emg3d.Model(grid, property_x=1., mapping='Resistivity')
+    run('uni16_F', grid, model, (0, 0, 0, 0, 0), 1.0, semicoarsening=False,
+        linerelaxation=False, cycle='F', tol=1e-10)
+
+    # (b) stretched marine VTI, W-cycle + semicoarsening + line relaxation (config-2 family)
+    hx = widths(8, 4, 50, 1.3); hz = widths(8, 4, 25, 1.4)
+    grid = emg3d.TensorMesh([hx, hx, hz], origin=(-hx.sum() / 2, -hx.sum() / 2, -hz[:10].sum()))
+    zc = grid.cell_centers_z
+    rh = np.where(zc > -200, 0.3, 1.0)
+    rv = np.where(zc > -200, 0.3, 2.0)
+    px = np.tile(rh[None, None, :], (16, 16, 1)).ravel('F')
+    pz = np.tile(rv[None, None, :], (16, 16, 1)).ravel('F')
+    model = emg3d.Model(grid, property_x=px, property_z=pz, mapping='Resistivity')
+    run('marine16_W', grid, model, (0, 0, -150, 0, 0), 1.0, semicoarsening=True,
+        linerelaxation=True, cycle='W', tol=1e-10)
+
+    # (c) tri-axial random blocky model, F-cycle, sc=123 lr=456, non-cubic grid
+    hx = widths(4, 4, 30, 1.2); hy = widths(4, 2, 40, 1.3); hz = widths(8, 4, 20, 1.25)
+    grid = emg3d.TensorMesh([hx, hy, hz], origin=(-hx.sum() / 2, -hy.sum() / 2, -hz.sum() / 2))
+    lat = 10 ** rng.uniform(-0.5, 1.5, (3, 2, 4))
+    px = np.kron(lat, np.ones((4, 4, 4))).ravel('F')
+    model = emg3d.Model(grid, property_x=px, property_y=1.5 * px, property_z=2.5 * px,
+                        mapping='Resistivity')
+    run('tri12x8x16_F', grid, model, (5, -3, 2, 30, 10), 0.5, semicoarsening=123,
+        linerelaxation=456, cycle='F', tol=1e-10)
+
+    # (d) Laplace domain (real arithmetic), V-cycle, line relaxation 7
+    h = widths(4, 2, 20, 1.3)
+    grid = emg3d.TensorMesh([h, h, h], origin=(-h.sum() / 2, -h.sum() / 2, -h.sum() / 2))
+    model = emg3d.Model(grid, property_x=1.5, property_y=2.0, property_z=3.3, mapping='Resistivity')
+    run('lap8_V', grid, model, (3, 2, 1, 20, 40), -2 * np.pi, semicoarsening=False,
+        linerelaxation=7, cycle='V', tol=1e-10)
+
+    out['meta_cases'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'solves.npz'), **out)
+    print('solves.npz written')
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['regression', 'kernels', 'solves']
+    if 'regression' in which:
+        regression_small()
+    if 'kernels' in which:
+        kernels()
+    if 'solves' in which:
+        solves()
