@@ -1,0 +1,542 @@
+// HIP kernels (gfx950) + C ABI of the emg3d multigrid inner loop. See include/emg3d_amd.h
+// for the contract of every entry point and the reference lines each one replaces.
+//
+// Launch geometry: thread x runs along the contiguous (x) axis of the Fortran-ordered
+// arrays wherever the work decomposition allows it, workgroups are 256 threads (4 waves of
+// 64). All kernels are HBM-bandwidth bound fp64 stencil / small-dense-solve work: there is
+// no dense contraction and therefore no MFMA use.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/emg3d_amd.h"
+#include "launch.h"
+
+using emg::cplx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what)
+{
+    g_err = what;
+    return code;
+}
+
+int hipfail(hipError_t e, const char *where)
+{
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return (int)e;
+}
+
+#define HIP_TRY(call)                                      \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return hipfail(e_, #call);   \
+    } while (0)
+
+template <class T> emg::Level<T> to_level(const emg3d_level *lv)
+{
+    emg::Level<T> L;
+    L.nx = lv->nx; L.ny = lv->ny; L.nz = lv->nz;
+    L.ex = (T *)lv->ex; L.ey = (T *)lv->ey; L.ez = (T *)lv->ez;
+    L.sx = (const T *)lv->sx; L.sy = (const T *)lv->sy; L.sz = (const T *)lv->sz;
+    L.eta_x = (const T *)lv->eta_x; L.eta_y = (const T *)lv->eta_y; L.eta_z = (const T *)lv->eta_z;
+    L.zeta = lv->zeta;
+    L.ihx = lv->ihx; L.ihy = lv->ihy; L.ihz = lv->ihz;
+    return L;
+}
+
+using emg::cdiv;
+using emg::cnt_par;
+using emg::sc_flags;
+using emg::ScDirs;
+
+inline dim3 d3(emg::Dim3 d) { return dim3(d.x, d.y, d.z); }
+
+// ----------------------------------------------------------------------------- kernels --
+
+// Point smoother, one colour. colour = ((ix+iz)&1) | (((iy+iz)&1)<<1).
+template <class T>
+__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, int colour)
+{
+    emg::gs_point_thread<T>(L, colour, blockIdx.x * blockDim.x + threadIdx.x,
+                            blockIdx.y * blockDim.y + threadIdx.y, blockIdx.z);
+}
+
+// Line smoother along DIR, one colour; one thread per line. (p,q) are the two transverse
+// PHYSICAL node indices in memory order (p faster): DIR 0 -> (iy,iz), 1 -> (ix,iz),
+// 2 -> (ix,iy). colour = (p&1) | ((q&1)<<1).
+template <class T, int DIR>
+__global__ __launch_bounds__(64) void k_gs_line(emg::Level<T> L, int colour, int cntp, int cntq,
+                                                T *scratch)
+{
+    emg::gs_line_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
+                                scratch);
+}
+
+// Residual + per-block partial sums of |r|^2.
+template <class T>
+__global__ __launch_bounds__(256) void k_residual(emg::Level<T> L, T *rx, T *ry, T *rz, double *partial)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int iz = blockIdx.z;
+    double acc = 0.0;
+    if (ix <= L.nx && iy <= L.ny) acc = emg::residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
+    if (partial) {
+        // wave reduction (64 lanes), then across the 4 waves through LDS
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        __shared__ double wsum[4];
+        const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+        if ((tid & 63) == 0) wsum[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            partial[bid] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        }
+    }
+}
+
+// Deterministic final reduction of the partial sums (single workgroup).
+__global__ __launch_bounds__(256) void k_reduce_sum(const double *partial, int n, double *out)
+{
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0];
+}
+
+template <class T> __global__ __launch_bounds__(256) void k_restrict(emg::Restrict<T> R)
+{
+    const int cix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ciy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int ciz = blockIdx.z;
+    if (cix >= R.cnxn || ciy >= R.cnyn) return;
+    emg::restrict_node<T>(R, cix, ciy, ciz);
+}
+
+template <class T> __global__ __launch_bounds__(256) void k_prolong(emg::Prolong<T> P)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int iz = blockIdx.z;
+    if (ix > P.nx || iy > P.ny) return;
+    emg::prolong_cell<T>(P, ix, iy, iz);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_restrict_param(T *out, const T *in, int nx, int ny, int cnx,
+                                                        int cny, int fx, int fy, int fz)
+{
+    const int cix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ciy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int ciz = blockIdx.z;
+    if (cix >= cnx || ciy >= cny) return;
+    emg::restrict_param_cell<T>(out, in, nx, ny, cnx, cny, fx, fy, fz, cix, ciy, ciz);
+}
+
+// Zero the tangential components on the PEC faces (reference emg3d/solver.py:349-355).
+template <class T>
+__global__ __launch_bounds__(256) void k_pec_zero(T *ex, T *ey, T *ez, int nx, int ny, int nz)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int iz = blockIdx.z;
+    if (ix > nx || iy > ny) return;
+    const bool bx = ix == 0 || ix == nx, by = iy == 0 || iy == ny, bz = iz == 0 || iz == nz;
+    if (ix < nx && (by || bz)) ex[ix + nx * (iy + (ny + 1) * iz)] = emg::zero<T>();
+    if (iy < ny && (bx || bz)) ey[ix + (nx + 1) * (iy + ny * iz)] = emg::zero<T>();
+    if (iz < nz && (bx || by)) ez[ix + (nx + 1) * (iy + (ny + 1) * iz)] = emg::zero<T>();
+}
+
+template <class T> __global__ void k_band_solve(T *amat, T *bvec, int n)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) emg::band_solve<T>(amat, bvec, n);
+}
+
+template <class T>
+__global__ void k_blocks_to_amat(T *amat, T *bvec, const T *middle, const double *left, const T *rhs,
+                                 int im, int nc)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) emg::blocks_to_amat<T>(amat, bvec, middle, left, rhs, im, nc);
+}
+
+// --------------------------------------------------------------------------- launchers --
+
+template <class T>
+int launch_gs(const emg3d_level *lv, int lr, int nu, void *scratch, size_t scratch_bytes, hipStream_t st)
+{
+    emg::Level<T> L = to_level<T>(lv);
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    if (nx < 2 || ny < 2 || nz < 2) return fail(EMG3D_ERR_BADARG, "gauss_seidel: need >= 2 cells per direction");
+    if (lr != 0 && scratch_bytes < emg3d_gs_scratch_bytes(lr, nx, ny, nz, lv->is_complex))
+        return fail(EMG3D_ERR_SCRATCH, "gauss_seidel: scratch buffer too small");
+    int iback = 0;
+    for (int it = 0; it < nu; ++it) {
+        iback = 1 - iback;   // first sweep backward (reference emg3d/core.py:301,311)
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = iback ? 3 - cc : cc;
+            if (lr == 0) {
+                const emg::Dim3 g = emg::gs_point_grid(nx, ny, nz);
+                if (g.x > 0 && g.y > 0 && g.z > 0)
+                    hipLaunchKernelGGL(k_gs_point<T>, d3(g), d3(emg::gs_point_block()), 0, st, L, c);
+            } else {
+                const int dir = lr - 1;
+                const int cntp = cnt_par(emg::line_np(dir, nx, ny, nz), c & 1);
+                const int cntq = cnt_par(emg::line_nq(dir, nx, ny, nz), (c >> 1) & 1);
+                if (cntp <= 0 || cntq <= 0) continue;
+                const dim3 grid = d3(emg::gs_line_grid(cntp, cntq)), block = d3(emg::gs_line_block());
+                if (dir == 0) hipLaunchKernelGGL((k_gs_line<T, 0>), grid, block, 0, st, L, c, cntp, cntq, (T *)scratch);
+                else if (dir == 1) hipLaunchKernelGGL((k_gs_line<T, 1>), grid, block, 0, st, L, c, cntp, cntq, (T *)scratch);
+                else hipLaunchKernelGGL((k_gs_line<T, 2>), grid, block, 0, st, L, c, cntp, cntq, (T *)scratch);
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T>
+int launch_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double *ws, size_t ws_len,
+                    double *sumsq, hipStream_t st)
+{
+    emg::Level<T> L = to_level<T>(lv);
+    const dim3 block = d3(emg::cell_block());
+    const dim3 grid = d3(emg::cell_grid(L.nx + 1, L.ny + 1, L.nz + 1));
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    if (sumsq && (ws == nullptr || ws_len < nblk)) return fail(EMG3D_ERR_SCRATCH, "residual: workspace too small");
+    hipLaunchKernelGGL(k_residual<T>, grid, block, 0, st, L, (T *)rx, (T *)ry, (T *)rz, sumsq ? ws : nullptr);
+    if (sumsq) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, ws, (int)nblk, sumsq);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T>
+int launch_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry, const void *rz,
+                    const double *const w[9], int nx, int ny, int nz, int sc_dir, hipStream_t st)
+{
+    const ScDirs f = sc_flags(sc_dir);
+    if ((f.cx && nx % 2) || (f.cy && ny % 2) || (f.cz && nz % 2))
+        return fail(EMG3D_ERR_BADARG, "restrict: odd cell count in a coarsened direction");
+    const emg::Restrict<T> R = emg::make_restrict<T>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir);
+    hipLaunchKernelGGL(k_restrict<T>, d3(emg::cell_grid(R.cnxn, R.cnyn, R.cnzn)), d3(emg::cell_block()), 0, st, R);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T>
+int launch_prolong(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,
+                   const int32_t *ilx, const int32_t *ily, const int32_t *ilz, const double *wx,
+                   const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir, hipStream_t st)
+{
+    const emg::Prolong<T> P =
+        emg::make_prolong<T>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz, sc_dir);
+    hipLaunchKernelGGL(k_prolong<T>, d3(emg::cell_grid(nx + 1, ny + 1, nz + 1)), d3(emg::cell_block()), 0, st, P);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T>
+int launch_restrict_param(void *out, const void *in, int nx, int ny, int nz, int sc_dir, hipStream_t st)
+{
+    const ScDirs f = sc_flags(sc_dir);
+    const int fx = f.cx ? 2 : 1, fy = f.cy ? 2 : 1, fz = f.cz ? 2 : 1;
+    const int cnx = nx / fx, cny = ny / fy, cnz = nz / fz;
+    const dim3 block = d3(emg::cell_block());
+    const dim3 grid = d3(emg::cell_grid(cnx, cny, cnz));
+    hipLaunchKernelGGL(k_restrict_param<T>, grid, block, 0, st, (T *)out, (const T *)in, nx, ny, cnx, cny, fx, fy, fz);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------- host-flavour plumbing ----
+
+// RAII device buffer filled from / copied back to a host pointer.
+struct DevBuf {
+    void *d = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (d) (void)hipFree(d); }
+    hipError_t up(const void *h, size_t n)
+    {
+        bytes = n;
+        hipError_t e = hipMalloc(&d, n ? n : 1);
+        if (e != hipSuccess) return e;
+        return n ? hipMemcpy(d, h, n, hipMemcpyHostToDevice) : hipSuccess;
+    }
+    hipError_t alloc(size_t n)
+    {
+        bytes = n;
+        return hipMalloc(&d, n ? n : 1);
+    }
+    hipError_t down(void *h) const { return bytes ? hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost) : hipSuccess; }
+};
+
+struct Sizes {
+    size_t nex, ney, nez, ncc, esz;
+    Sizes(int nx, int ny, int nz, int is_complex)
+    {
+        nex = (size_t)nx * (ny + 1) * (nz + 1);
+        ney = (size_t)(nx + 1) * ny * (nz + 1);
+        nez = (size_t)(nx + 1) * (ny + 1) * nz;
+        ncc = (size_t)nx * ny * nz;
+        esz = is_complex ? 16 : 8;
+    }
+};
+
+// Upload eta_x/eta_y/eta_z preserving aliasing (one device copy per distinct host pointer).
+struct EtaUpload {
+    DevBuf b[3];
+    const void *dptr[3] = {nullptr, nullptr, nullptr};
+    hipError_t up(const void *hx, const void *hy, const void *hz, size_t bytes)
+    {
+        const void *h[3] = {hx, hy, hz};
+        for (int i = 0; i < 3; ++i) {
+            int alias = -1;
+            for (int j = 0; j < i; ++j)
+                if (h[j] == h[i]) { alias = j; break; }
+            if (alias >= 0) { dptr[i] = dptr[alias]; continue; }
+            hipError_t e = b[i].up(h[i], bytes);
+            if (e != hipSuccess) return e;
+            dptr[i] = b[i].d;
+        }
+        return hipSuccess;
+    }
+};
+
+hipError_t upload_inverse(DevBuf &b, const double *h, int n)
+{
+    double *tmp = new double[n > 0 ? n : 1];
+    for (int i = 0; i < n; ++i) tmp[i] = 1.0 / h[i];
+    hipError_t e = b.up(tmp, sizeof(double) * (size_t)n);
+    delete[] tmp;
+    return e;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI ==
+extern "C" {
+
+int emg3d_version(void) { return EMG3D_AMD_VERSION; }
+const char *emg3d_last_error(void) { return g_err.c_str(); }
+
+int emg3d_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex)
+{
+    if (lr < 1 || lr > 3) return 0;
+    return emg::gs_line_scratch_elems(lr - 1, nx, ny, nz) * (is_complex ? 16 : 8);
+}
+
+int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, void *scratch, size_t scratch_bytes,
+                           void *stream)
+{
+    if (!lv || lr < 0 || lr > 3 || nu < 0) return fail(EMG3D_ERR_BADARG, "gauss_seidel: bad argument");
+    return lv->is_complex ? launch_gs<cplx>(lv, lr, nu, scratch, scratch_bytes, (hipStream_t)stream)
+                          : launch_gs<double>(lv, lr, nu, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+size_t emg3d_residual_ws_len(int nx, int ny, int nz)
+{
+    const emg::Dim3 g = emg::cell_grid(nx + 1, ny + 1, nz + 1);
+    return (size_t)g.x * g.y * g.z;
+}
+
+int emg3d_dev_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double *ws, size_t ws_len,
+                       double *sumsq, void *stream)
+{
+    if (!lv) return fail(EMG3D_ERR_BADARG, "residual: bad argument");
+    return lv->is_complex ? launch_residual<cplx>(lv, rx, ry, rz, ws, ws_len, sumsq, (hipStream_t)stream)
+                          : launch_residual<double>(lv, rx, ry, rz, ws, ws_len, sumsq, (hipStream_t)stream);
+}
+
+int emg3d_dev_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry, const void *rz,
+                       const double *wxl, const double *wx0, const double *wxr, const double *wyl,
+                       const double *wy0, const double *wyr, const double *wzl, const double *wz0,
+                       const double *wzr, int nx, int ny, int nz, int sc_dir, int is_complex, void *stream)
+{
+    if (sc_dir < 0 || sc_dir > 6) return fail(EMG3D_ERR_BADARG, "restrict: sc_dir must be 0..6");
+    const double *const w[9] = {wxl, wx0, wxr, wyl, wy0, wyr, wzl, wz0, wzr};
+    return is_complex ? launch_restrict<cplx>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir, (hipStream_t)stream)
+                      : launch_restrict<double>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir, (hipStream_t)stream);
+}
+
+int emg3d_dev_prolong(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,
+                      const int32_t *ilx, const int32_t *ily, const int32_t *ilz, const double *wx,
+                      const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir,
+                      int is_complex, void *stream)
+{
+    if (sc_dir < 0 || sc_dir > 6) return fail(EMG3D_ERR_BADARG, "prolong: sc_dir must be 0..6");
+    return is_complex ? launch_prolong<cplx>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz,
+                                             sc_dir, (hipStream_t)stream)
+                      : launch_prolong<double>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz,
+                                               sc_dir, (hipStream_t)stream);
+}
+
+int emg3d_dev_restrict_param(void *out, const void *in, int nx, int ny, int nz, int sc_dir, int is_complex,
+                             void *stream)
+{
+    if (sc_dir < 0 || sc_dir > 6) return fail(EMG3D_ERR_BADARG, "restrict_param: sc_dir must be 0..6");
+    return is_complex ? launch_restrict_param<cplx>(out, in, nx, ny, nz, sc_dir, (hipStream_t)stream)
+                      : launch_restrict_param<double>(out, in, nx, ny, nz, sc_dir, (hipStream_t)stream);
+}
+
+int emg3d_dev_pec_zero(void *ex, void *ey, void *ez, int nx, int ny, int nz, int is_complex, void *stream)
+{
+    const dim3 block = d3(emg::cell_block());
+    const dim3 grid = d3(emg::cell_grid(nx + 1, ny + 1, nz + 1));
+    if (is_complex)
+        hipLaunchKernelGGL(k_pec_zero<cplx>, grid, block, 0, (hipStream_t)stream, (cplx *)ex, (cplx *)ey, (cplx *)ez, nx, ny, nz);
+    else
+        hipLaunchKernelGGL(k_pec_zero<double>, grid, block, 0, (hipStream_t)stream, (double *)ex, (double *)ey, (double *)ez, nx, ny, nz);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------- host flavour ----
+
+int emg3d_core_amat_x(void *rx, void *ry, void *rz, const void *ex, const void *ey, const void *ez,
+                      const void *eta_x, const void *eta_y, const void *eta_z, const double *zeta,
+                      const double *hx, const double *hy, const double *hz, int nx, int ny, int nz,
+                      int is_complex)
+{
+    if (emg3d_device_count() < 1) return fail(EMG3D_ERR_NODEVICE, "no HIP device");
+    const Sizes S(nx, ny, nz, is_complex);
+    DevBuf drx, dry, drz, dex, dey, dez, dz, dhx, dhy, dhz;
+    EtaUpload eta;
+    HIP_TRY(drx.up(rx, S.nex * S.esz)); HIP_TRY(dry.up(ry, S.ney * S.esz)); HIP_TRY(drz.up(rz, S.nez * S.esz));
+    HIP_TRY(dex.up(ex, S.nex * S.esz)); HIP_TRY(dey.up(ey, S.ney * S.esz)); HIP_TRY(dez.up(ez, S.nez * S.esz));
+    HIP_TRY(eta.up(eta_x, eta_y, eta_z, S.ncc * S.esz));
+    HIP_TRY(dz.up(zeta, S.ncc * 8));
+    HIP_TRY(upload_inverse(dhx, hx, nx)); HIP_TRY(upload_inverse(dhy, hy, ny)); HIP_TRY(upload_inverse(dhz, hz, nz));
+    emg3d_level lv;
+    lv.nx = nx; lv.ny = ny; lv.nz = nz; lv.is_complex = is_complex;
+    lv.ex = dex.d; lv.ey = dey.d; lv.ez = dez.d;
+    lv.sx = drx.d; lv.sy = dry.d; lv.sz = drz.d;   // r -= A e  ==  r = r_in - A e, in place
+    lv.eta_x = eta.dptr[0]; lv.eta_y = eta.dptr[1]; lv.eta_z = eta.dptr[2];
+    lv.zeta = (const double *)dz.d;
+    lv.ihx = (const double *)dhx.d; lv.ihy = (const double *)dhy.d; lv.ihz = (const double *)dhz.d;
+    // core.amat_x only touches the entries of cells 0..n-1; the upper-boundary branch of
+    // the kernel rewrites r = r there, i.e. leaves them as they are.
+    int rc = emg3d_dev_residual(&lv, drx.d, dry.d, drz.d, nullptr, 0, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(drx.down(rx)); HIP_TRY(dry.down(ry)); HIP_TRY(drz.down(rz));
+    return 0;
+}
+
+int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx, const void *sy,
+                            const void *sz, const void *eta_x, const void *eta_y, const void *eta_z,
+                            const double *zeta, const double *hx, const double *hy, const double *hz,
+                            int nx, int ny, int nz, int nu, int is_complex)
+{
+    if (emg3d_device_count() < 1) return fail(EMG3D_ERR_NODEVICE, "no HIP device");
+    const Sizes S(nx, ny, nz, is_complex);
+    DevBuf dsx, dsy, dsz, dex, dey, dez, dz, dhx, dhy, dhz, scr;
+    EtaUpload eta;
+    HIP_TRY(dsx.up(sx, S.nex * S.esz)); HIP_TRY(dsy.up(sy, S.ney * S.esz)); HIP_TRY(dsz.up(sz, S.nez * S.esz));
+    HIP_TRY(dex.up(ex, S.nex * S.esz)); HIP_TRY(dey.up(ey, S.ney * S.esz)); HIP_TRY(dez.up(ez, S.nez * S.esz));
+    HIP_TRY(eta.up(eta_x, eta_y, eta_z, S.ncc * S.esz));
+    HIP_TRY(dz.up(zeta, S.ncc * 8));
+    HIP_TRY(upload_inverse(dhx, hx, nx)); HIP_TRY(upload_inverse(dhy, hy, ny)); HIP_TRY(upload_inverse(dhz, hz, nz));
+    const size_t sb = emg3d_gs_scratch_bytes(lr, nx, ny, nz, is_complex);
+    HIP_TRY(scr.alloc(sb));
+    emg3d_level lv;
+    lv.nx = nx; lv.ny = ny; lv.nz = nz; lv.is_complex = is_complex;
+    lv.ex = dex.d; lv.ey = dey.d; lv.ez = dez.d;
+    lv.sx = dsx.d; lv.sy = dsy.d; lv.sz = dsz.d;
+    lv.eta_x = eta.dptr[0]; lv.eta_y = eta.dptr[1]; lv.eta_z = eta.dptr[2];
+    lv.zeta = (const double *)dz.d;
+    lv.ihx = (const double *)dhx.d; lv.ihy = (const double *)dhy.d; lv.ihz = (const double *)dhz.d;
+    int rc = emg3d_dev_gauss_seidel(&lv, lr, nu, scr.d, sb, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dex.down(ex)); HIP_TRY(dey.down(ey)); HIP_TRY(dez.down(ez));
+    return 0;
+}
+
+int emg3d_core_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry, const void *rz,
+                        const double *wxl, const double *wx0, const double *wxr, const double *wyl,
+                        const double *wy0, const double *wyr, const double *wzl, const double *wz0,
+                        const double *wzr, int nx, int ny, int nz, int sc_dir, int is_complex)
+{
+    if (emg3d_device_count() < 1) return fail(EMG3D_ERR_NODEVICE, "no HIP device");
+    if (sc_dir < 0 || sc_dir > 6) return fail(EMG3D_ERR_BADARG, "restrict: sc_dir must be 0..6");
+    const ScDirs f = sc_flags(sc_dir);
+    const int cnx = f.cx ? nx / 2 : nx, cny = f.cy ? ny / 2 : ny, cnz = f.cz ? nz / 2 : nz;
+    const Sizes S(nx, ny, nz, is_complex), C(cnx, cny, cnz, is_complex);
+    DevBuf drx, dry, drz, dcx, dcy, dcz, w[9];
+    HIP_TRY(drx.up(rx, S.nex * S.esz)); HIP_TRY(dry.up(ry, S.ney * S.esz)); HIP_TRY(drz.up(rz, S.nez * S.esz));
+    // coarse arrays are uploaded too: entries the kernel does not write keep their value
+    HIP_TRY(dcx.up(crx, C.nex * C.esz)); HIP_TRY(dcy.up(cry, C.ney * C.esz)); HIP_TRY(dcz.up(crz, C.nez * C.esz));
+    const double *hw[9] = {wxl, wx0, wxr, wyl, wy0, wyr, wzl, wz0, wzr};
+    const int wn[3] = {cnx + 1, cny + 1, cnz + 1};
+    const int coarsened[3] = {f.cx, f.cy, f.cz};
+    const double *dw[9];
+    for (int i = 0; i < 9; ++i) {
+        dw[i] = nullptr;
+        if (coarsened[i / 3]) {
+            HIP_TRY(w[i].up(hw[i], sizeof(double) * (size_t)wn[i / 3]));
+            dw[i] = (const double *)w[i].d;
+        }
+    }
+    int rc = emg3d_dev_restrict(dcx.d, dcy.d, dcz.d, drx.d, dry.d, drz.d, dw[0], dw[1], dw[2], dw[3], dw[4],
+                                dw[5], dw[6], dw[7], dw[8], nx, ny, nz, sc_dir, is_complex, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dcx.down(crx)); HIP_TRY(dcy.down(cry)); HIP_TRY(dcz.down(crz));
+    return 0;
+}
+
+int emg3d_core_blocks_to_amat(void *amat, void *bvec, const void *middle, const double *left,
+                              const void *rhs, int im, int nc, int n, int is_complex)
+{
+    if (emg3d_device_count() < 1) return fail(EMG3D_ERR_NODEVICE, "no HIP device");
+    const size_t e = is_complex ? 16 : 8;
+    DevBuf da, db, dm, dl, dr;
+    HIP_TRY(da.up(amat, 6 * (size_t)n * e)); HIP_TRY(db.up(bvec, (size_t)n * e));
+    HIP_TRY(dm.up(middle, 25 * e)); HIP_TRY(dl.up(left, 25 * 8)); HIP_TRY(dr.up(rhs, 5 * e));
+    if (is_complex)
+        hipLaunchKernelGGL(k_blocks_to_amat<cplx>, dim3(1), dim3(1), 0, 0, (cplx *)da.d, (cplx *)db.d,
+                           (const cplx *)dm.d, (const double *)dl.d, (const cplx *)dr.d, im, nc);
+    else
+        hipLaunchKernelGGL(k_blocks_to_amat<double>, dim3(1), dim3(1), 0, 0, (double *)da.d, (double *)db.d,
+                           (const double *)dm.d, (const double *)dl.d, (const double *)dr.d, im, nc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(da.down(amat)); HIP_TRY(db.down(bvec));
+    return 0;
+}
+
+int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex)
+{
+    if (emg3d_device_count() < 1) return fail(EMG3D_ERR_NODEVICE, "no HIP device");
+    const size_t e = is_complex ? 16 : 8;
+    DevBuf da, db;
+    HIP_TRY(da.up(amat, 6 * (size_t)n * e)); HIP_TRY(db.up(bvec, (size_t)n * e));
+    if (is_complex)
+        hipLaunchKernelGGL(k_band_solve<cplx>, dim3(1), dim3(1), 0, 0, (cplx *)da.d, (cplx *)db.d, n);
+    else
+        hipLaunchKernelGGL(k_band_solve<double>, dim3(1), dim3(1), 0, 0, (double *)da.d, (double *)db.d, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(da.down(amat)); HIP_TRY(db.down(bvec));
+    return 0;
+}
+
+}  // extern "C"

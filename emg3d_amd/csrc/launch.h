@@ -1,0 +1,112 @@
+// Work decomposition shared by the HIP kernels (kernels.hip) and by the CPU emulation
+// harness of the unit tests (tests/emu/emu.cpp): which node / line / cell a global thread
+// index owns, and how large the grids are. Keeping it in one place means the emulation
+// exercises exactly the index arithmetic the GPU runs.
+#pragma once
+#include "stencil.h"
+
+namespace emg {
+
+struct Dim3 { int x, y, z; };
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// number of integers p in [1, n-1] with p % 2 == par
+inline int cnt_par(int n, int par) { return par ? n / 2 : (n - 1) / 2; }
+// first integer >= 1 with parity par
+EMG_HD int first_par(int par) { return par ? 1 : 2; }
+
+// ---- point smoother: colour = ((ix+iz)&1) | (((iy+iz)&1)<<1); global thread (gx,gy,gz) --
+inline Dim3 gs_point_block() { return Dim3{64, 4, 1}; }
+inline Dim3 gs_point_grid(int nx, int ny, int nz)
+{
+    return Dim3{cdiv(cdiv(nx - 1, 2), 64), cdiv(cdiv(ny - 1, 2), 4), nz - 1};
+}
+template <class T> EMG_HD void gs_point_thread(const Level<T> &L, int colour, int gx, int gy, int gz)
+{
+    const int iz = 1 + gz;
+    const int parx = (colour & 1) ^ (iz & 1);
+    const int pary = ((colour >> 1) & 1) ^ (iz & 1);
+    const int ix = first_par(parx) + 2 * gx;
+    const int iy = first_par(pary) + 2 * gy;
+    if (ix > L.nx - 1 || iy > L.ny - 1 || iz > L.nz - 1) return;
+    gs_point_node<T>(L, ix, iy, iz);
+}
+
+// ---- line smoothers: (p,q) = transverse PHYSICAL node indices in memory order (p faster):
+//      DIR 0 (x-lines): (iy,iz)   DIR 1 (y-lines): (ix,iz)   DIR 2 (z-lines): (ix,iy)
+//      colour = (p&1) | ((q&1)<<1); one thread per line.
+inline int line_np(int dir, int nx, int ny, int nz) { (void)nz; return dir == 0 ? ny : nx; }
+inline int line_nq(int dir, int nx, int ny, int nz) { (void)nx; return dir == 2 ? ny : nz; }
+inline int line_n0(int dir, int nx, int ny, int nz) { return dir == 0 ? nx : dir == 1 ? ny : nz; }
+inline Dim3 gs_line_block() { return Dim3{64, 1, 1}; }
+inline Dim3 gs_line_grid(int cntp, int cntq) { return Dim3{cdiv(cntp, 64), cntq, 1}; }
+
+template <class T, int DIR>
+EMG_HD void gs_line_thread(const Level<T> &L, int colour, int cntp, int cntq, int tp, int tq, T *scratch)
+{
+    if (tp >= cntp || tq >= cntq) return;
+    const int p = first_par(colour & 1) + 2 * tp;
+    const int q = first_par((colour >> 1) & 1) + 2 * tq;
+    const int lid = tp + cntp * tq;
+    const int lstride = cntp * cntq;
+    // abstract (i1,i2): DIR 0: (iy,iz)=(p,q); DIR 1: (iz,ix)=(q,p); DIR 2: (ix,iy)=(p,q)
+    const int i1 = DIR == 1 ? q : p;
+    const int i2 = DIR == 1 ? p : q;
+    gs_line<T, DIR>(L, i1, i2, scratch + lid, lstride);
+}
+
+// scratch elements (of T) needed by one line-smoother launch in direction dir
+inline size_t gs_line_scratch_elems(int dir, int nx, int ny, int nz)
+{
+    const size_t lines = (size_t)cnt_par(line_np(dir, nx, ny, nz), 1) * cnt_par(line_nq(dir, nx, ny, nz), 1);
+    return (size_t)6 * (5 * line_n0(dir, nx, ny, nz) - 4) * lines;
+}
+
+// ---- "extended cell" kernels (residual, prolongation, PEC): one thread per node-indexed
+//      cell (ix,iy,iz), 0 <= ix <= nx etc.
+inline Dim3 cell_block() { return Dim3{64, 4, 1}; }
+inline Dim3 cell_grid(int n1, int n2, int n3) { return Dim3{cdiv(n1, 64), cdiv(n2, 4), n3}; }
+
+struct ScDirs { int cx, cy, cz; };
+// which directions are coarsened for a given sc_dir (reference emg3d/solver.py:891-897)
+inline ScDirs sc_flags(int sc_dir)
+{
+    ScDirs f;
+    f.cx = !(sc_dir == 1 || sc_dir == 5 || sc_dir == 6);
+    f.cy = !(sc_dir == 2 || sc_dir == 4 || sc_dir == 6);
+    f.cz = !(sc_dir == 3 || sc_dir == 4 || sc_dir == 5);
+    return f;
+}
+
+template <class T>
+inline Restrict<T> make_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry,
+                                 const void *rz, const double *const w[9], int nx, int ny, int nz, int sc_dir)
+{
+    const ScDirs f = sc_flags(sc_dir);
+    Restrict<T> R;
+    R.cx = f.cx; R.cy = f.cy; R.cz = f.cz;
+    R.nxn = nx + 1; R.nyn = ny + 1; R.nzn = nz + 1;
+    R.cnxn = (f.cx ? nx / 2 : nx) + 1; R.cnyn = (f.cy ? ny / 2 : ny) + 1; R.cnzn = (f.cz ? nz / 2 : nz) + 1;
+    R.rx = (const T *)rx; R.ry = (const T *)ry; R.rz = (const T *)rz;
+    R.crx = (T *)crx; R.cry = (T *)cry; R.crz = (T *)crz;
+    for (int i = 0; i < 3; ++i) { R.wx[i] = w[i]; R.wy[i] = w[3 + i]; R.wz[i] = w[6 + i]; }
+    return R;
+}
+
+template <class T>
+inline Prolong<T> make_prolong(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,
+                               const int *ilx, const int *ily, const int *ilz, const double *wx,
+                               const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir)
+{
+    const ScDirs f = sc_flags(sc_dir);
+    Prolong<T> P;
+    P.cx = f.cx; P.cy = f.cy; P.cz = f.cz;
+    P.nx = nx; P.ny = ny; P.nz = nz;
+    P.cnx = f.cx ? nx / 2 : nx; P.cny = f.cy ? ny / 2 : ny; P.cnz = f.cz ? nz / 2 : nz;
+    P.ex = (T *)ex; P.ey = (T *)ey; P.ez = (T *)ez;
+    P.cex = (const T *)cex; P.cey = (const T *)cey; P.cez = (const T *)cez;
+    P.ilx = ilx; P.ily = ily; P.ilz = ilz; P.wx = wx; P.wy = wy; P.wz = wz;
+    return P;
+}
+
+}  // namespace emg

@@ -1,0 +1,856 @@
+// Per-node / per-line / per-edge bodies of the multigrid inner loop, written once as
+// EMG_HD functions: the HIP kernels in kernels.hip call them with (blockIdx, threadIdx)
+// derived indices; the CPU emulation harness in tests/emu/ (unit tests without a GPU)
+// calls the very same bodies from plain loops.
+//
+// What each body computes follows the reference's numba kernels (emg3d/core.py, cited per
+// function); how it is organised does not: nodes / lines are visited in a four-colour
+// order so that all work items of one launch are independent, the
+// banded line systems are factorised in a streaming row-by-row LDL^T that never
+// materialises the reference's `amat`, and x-, y- and z-line relaxation share ONE body
+// through the cyclic symmetry (x,y,z) -> (y,z,x) of the curl-curl operator.
+//
+// Layout (reference emg3d/fields.py:201-259): Fortran order, x fastest;
+//   ex (nx, ny+1, nz+1), ey (nx+1, ny, nz+1), ez (nx+1, ny+1, nz); eta_*, zeta (nx,ny,nz).
+#pragma once
+#include "cplx.h"
+
+namespace emg {
+
+// One grid level as the kernels see it. All pointers are device pointers (or host
+// pointers in the emulation harness). eta_x/eta_y/eta_z may alias (isotropic / VTI / HTI,
+// reference emg3d/models.py:693-712) and are never written.
+template <class T> struct Level {
+    int nx, ny, nz;                    // cells
+    T *ex, *ey, *ez;                   // electric field (updated in place by the smoothers)
+    const T *sx, *sy, *sz;             // source / right-hand side
+    const T *eta_x, *eta_y, *eta_z;    // -s mu0 sigma V   (field dtype)
+    const double *zeta;                // V / mu_r
+    const double *ihx, *ihy, *ihz;     // inverse cell widths 1/h
+};
+
+// ---------------------------------------------------------------------------------------
+// Axis-permuted accessors. DIR = 0,1,2 selects the "line" axis a0 = x,y,z; (a1,a2) follow
+// cyclically: DIR 0: (x,y,z)  DIR 1: (y,z,x)  DIR 2: (z,x,y). Abstract indices (i0,i1,i2)
+// are indices along (a0,a1,a2). E0/E1/E2 are the field components along a0/a1/a2.
+// ---------------------------------------------------------------------------------------
+template <class T, int DIR> struct Axes {
+    const Level<T> &L;
+    EMG_HD Axes(const Level<T> &l) : L(l) {}
+
+    EMG_HD int n0() const { return DIR == 0 ? L.nx : DIR == 1 ? L.ny : L.nz; }
+    EMG_HD int n1() const { return DIR == 0 ? L.ny : DIR == 1 ? L.nz : L.nx; }
+    EMG_HD int n2() const { return DIR == 0 ? L.nz : DIR == 1 ? L.nx : L.ny; }
+    EMG_HD const double *ih0() const { return DIR == 0 ? L.ihx : DIR == 1 ? L.ihy : L.ihz; }
+    EMG_HD const double *ih1() const { return DIR == 0 ? L.ihy : DIR == 1 ? L.ihz : L.ihx; }
+    EMG_HD const double *ih2() const { return DIR == 0 ? L.ihz : DIR == 1 ? L.ihx : L.ihy; }
+
+    // physical (ix,iy,iz) from abstract (i0,i1,i2)
+    EMG_HD int px(int i0, int i1, int i2) const { return DIR == 0 ? i0 : DIR == 1 ? i2 : i1; }
+    EMG_HD int py(int i0, int i1, int i2) const { return DIR == 0 ? i1 : DIR == 1 ? i0 : i2; }
+    EMG_HD int pz(int i0, int i1, int i2) const { return DIR == 0 ? i2 : DIR == 1 ? i1 : i0; }
+
+    EMG_HD int iex(int x, int y, int z) const { return x + L.nx * (y + (L.ny + 1) * z); }
+    EMG_HD int iey(int x, int y, int z) const { return x + (L.nx + 1) * (y + L.ny * z); }
+    EMG_HD int iez(int x, int y, int z) const { return x + (L.nx + 1) * (y + (L.ny + 1) * z); }
+    EMG_HD int icc(int x, int y, int z) const { return x + L.nx * (y + L.ny * z); }
+
+    // linear index of component c (0: along a0, 1: a1, 2: a2) at abstract position
+    EMG_HD int idx(int c, int i0, int i1, int i2) const
+    {
+        const int x = px(i0, i1, i2), y = py(i0, i1, i2), z = pz(i0, i1, i2);
+        const int phys = (c + DIR) % 3;  // physical component 0:x 1:y 2:z
+        return phys == 0 ? iex(x, y, z) : phys == 1 ? iey(x, y, z) : iez(x, y, z);
+    }
+    EMG_HD T *E(int c) const
+    {
+        const int phys = (c + DIR) % 3;
+        return phys == 0 ? L.ex : phys == 1 ? L.ey : L.ez;
+    }
+    EMG_HD const T *S(int c) const
+    {
+        const int phys = (c + DIR) % 3;
+        return phys == 0 ? L.sx : phys == 1 ? L.sy : L.sz;
+    }
+    EMG_HD const T *ETA(int c) const
+    {
+        const int phys = (c + DIR) % 3;
+        return phys == 0 ? L.eta_x : phys == 1 ? L.eta_y : L.eta_z;
+    }
+    EMG_HD T e(int c, int i0, int i1, int i2) const { return E(c)[idx(c, i0, i1, i2)]; }
+    EMG_HD T s(int c, int i0, int i1, int i2) const { return S(c)[idx(c, i0, i1, i2)]; }
+    EMG_HD T eta(int c, int i0, int i1, int i2) const
+    {
+        return ETA(c)[icc(px(i0, i1, i2), py(i0, i1, i2), pz(i0, i1, i2))];
+    }
+    EMG_HD double zeta(int i0, int i1, int i2) const
+    {
+        return L.zeta[icc(px(i0, i1, i2), py(i0, i1, i2), pz(i0, i1, i2))];
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Residual  r = s - A e  at the three "lower" edges of extended cell (ix,iy,iz),
+// 0 <= ix <= nx etc. Follows core.amat_x (reference emg3d/core.py:57-206) for the cells
+// 0..n-1 and leaves the source value on upper-boundary entries (which core.amat_x never
+// touches), so one launch produces the complete residual buffer of
+// solver.residual (reference emg3d/solver.py:1022-1070). Returns |rx|^2+|ry|^2+|rz|^2 of
+// the entries this cell owns (for the fused l2-norm).
+// `r*` may alias `s*` (in-place form of core.amat_x: r -= A e).
+// ---------------------------------------------------------------------------------------
+template <class T>
+EMG_HD double residual_cell(const Level<T> &L, T *rx, T *ry, T *rz, int ix, int iy, int iz)
+{
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    const Axes<T, 0> A(L);
+    const bool inx = ix < nx, iny = iy < ny, inz = iz < nz;
+    double acc = 0.0;
+
+    if (inx && iny && inz) {
+        const int ixm = ix > 0 ? ix - 1 : 0, iym = iy > 0 ? iy - 1 : 0, izm = iz > 0 ? iz - 1 : 0;
+        const int ixp = ix + 1, iyp = iy + 1, izp = iz + 1;
+        const double hx1 = L.ihx[ix], hx0 = L.ihx[ixm];
+        const double hy1 = L.ihy[iy], hy0 = L.ihy[iym];
+        const double hz1 = L.ihz[iz], hz0 = L.ihz[izm];
+#define EXv(i, j, k) L.ex[A.iex(i, j, k)]
+#define EYv(i, j, k) L.ey[A.iey(i, j, k)]
+#define EZv(i, j, k) L.ez[A.iez(i, j, k)]
+#define ZT(i, j, k) L.zeta[A.icc(i, j, k)]
+        const T ex_c = EXv(ix, iy, iz), ey_c = EYv(ix, iy, iz), ez_c = EZv(ix, iy, iz);
+        // 1. curl on the faces around the three edges (core.py:136-155)
+        T v1pp = (EZv(ix, iyp, iz) - ez_c) * hy1 - (EYv(ix, iy, izp) - ey_c) * hz1;
+        T v1mp = (ez_c - EZv(ix, iym, iz)) * hy0 - (EYv(ix, iym, izp) - EYv(ix, iym, iz)) * hz1;
+        T v1pm = (EZv(ix, iyp, izm) - EZv(ix, iy, izm)) * hy1 - (ey_c - EYv(ix, iy, izm)) * hz0;
+
+        T v2pp = (EXv(ix, iy, izp) - ex_c) * hz1 - (EZv(ixp, iy, iz) - ez_c) * hx1;
+        T v2mp = (EXv(ixm, iy, izp) - EXv(ixm, iy, iz)) * hz1 - (ez_c - EZv(ixm, iy, iz)) * hx0;
+        T v2pm = (ex_c - EXv(ix, iy, izm)) * hz0 - (EZv(ixp, iy, izm) - EZv(ix, iy, izm)) * hx1;
+
+        T v3pp = (EYv(ixp, iy, iz) - ey_c) * hx1 - (EXv(ix, iyp, iz) - ex_c) * hy1;
+        T v3mp = (ey_c - EYv(ixm, iy, iz)) * hx0 - (EXv(ixm, iyp, iz) - EXv(ixm, iy, iz)) * hy1;
+        T v3pm = (EYv(ixp, iym, iz) - EYv(ix, iym, iz)) * hx1 - (ex_c - EXv(ix, iym, iz)) * hy0;
+
+        // 2. face averages of zeta (core.py:160-170)
+        const double z000 = ZT(ixm, iym, izm), z100 = ZT(ix, iym, izm);
+        const double z010 = ZT(ixm, iy, izm), z110 = ZT(ix, iy, izm);
+        const double z001 = ZT(ixm, iym, iz), z101 = ZT(ix, iym, iz);
+        const double z011 = ZT(ixm, iy, iz), z111 = ZT(ix, iy, iz);
+        v1pp *= z011 + z111;
+        v1mp *= z001 + z101;
+        v1pm *= z010 + z110;
+        v2pp *= z101 + z111;
+        v2mp *= z001 + z011;
+        v2pm *= z100 + z110;
+        v3pp *= z110 + z111;
+        v3mp *= z010 + z011;
+        v3pm *= z100 + z101;
+
+        // 3. second curl (core.py:174-176)
+        T rrx = v3pp * hy1 - v3pm * hy0 - v2pp * hz1 + v2pm * hz0;
+        T rry = v1pp * hz1 - v1pm * hz0 - v3pp * hx1 + v3mp * hx0;
+        T rrz = v2pp * hx1 - v2mp * hx0 - v1pp * hy1 + v1mp * hy0;
+
+        // 4. eta edge sums (core.py:181-186)
+#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
+        const T stx = ETv(L.eta_x, ix, iym, izm) + ETv(L.eta_x, ix, iym, iz) +
+                      ETv(L.eta_x, ix, iy, izm) + ETv(L.eta_x, ix, iy, iz);
+        const T sty = ETv(L.eta_y, ixm, iy, izm) + ETv(L.eta_y, ix, iy, izm) +
+                      ETv(L.eta_y, ixm, iy, iz) + ETv(L.eta_y, ix, iy, iz);
+        const T stz = ETv(L.eta_z, ixm, iym, iz) + ETv(L.eta_z, ix, iym, iz) +
+                      ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ix, iy, iz);
+#undef ETv
+        // PEC rows (core.py:193-198)
+        if (iy == 0 || iz == 0) rrx = zero<T>();
+        if (ix == 0 || iz == 0) rry = zero<T>();
+        if (ix == 0 || iy == 0) rrz = zero<T>();
+
+        // 5. r = s - (0.5 rr - 0.25 st e)   (core.py:204-206)
+        const T ox = L.sx[A.iex(ix, iy, iz)] - (0.5 * rrx - 0.25 * (stx * ex_c));
+        const T oy = L.sy[A.iey(ix, iy, iz)] - (0.5 * rry - 0.25 * (sty * ey_c));
+        const T oz = L.sz[A.iez(ix, iy, iz)] - (0.5 * rrz - 0.25 * (stz * ez_c));
+        acc = abs2(ox) + abs2(oy) + abs2(oz);
+        if (rx) {
+            rx[A.iex(ix, iy, iz)] = ox;
+            ry[A.iey(ix, iy, iz)] = oy;
+            rz[A.iez(ix, iy, iz)] = oz;
+        }
+#undef EXv
+#undef EYv
+#undef EZv
+#undef ZT
+    } else {
+        // Upper-boundary entries: r = s (untouched by core.amat_x).
+        if (inx) {  // ex exists for ix < nx, any iy <= ny, iz <= nz
+            const T v = L.sx[A.iex(ix, iy, iz)];
+            acc += abs2(v);
+            if (rx) rx[A.iex(ix, iy, iz)] = v;
+        }
+        if (iny) {
+            const T v = L.sy[A.iey(ix, iy, iz)];
+            acc += abs2(v);
+            if (ry) ry[A.iey(ix, iy, iz)] = v;
+        }
+        if (inz) {
+            const T v = L.sz[A.iez(ix, iy, iz)];
+            acc += abs2(v);
+            if (rz) rz[A.iez(ix, iy, iz)] = v;
+        }
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Point smoother: one node update of core.gauss_seidel (reference emg3d/core.py:346-503).
+// The 6x6 complex-symmetric system of the six edges attached to node (ix,iy,iz) is
+// assembled in registers and solved by an unrolled LDL^T without pivoting (core.solve,
+// core.py:1481-1616, n = 6); entry (1,0) is structurally zero and stays zero.
+// ---------------------------------------------------------------------------------------
+EMG_HD constexpr bool pt_nz(int i, int j) { return !(i == 1 && j == 0); }
+
+template <class T> EMG_HD void solve6(const T (&dg)[6], const double (&od)[6][6], T (&b)[6])
+{
+    T Lm[6][6];
+    T dinv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        T u[6];
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            if (!pt_nz(i, j)) continue;
+            T t = T(od[i][j]);
+#pragma unroll
+            for (int k = 0; k < j; ++k)
+                if (pt_nz(i, k) && pt_nz(j, k)) t -= u[k] * Lm[j][k];
+            u[j] = t;
+            Lm[i][j] = t * dinv[j];
+        }
+        T d = dg[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k)
+            if (pt_nz(i, k)) d -= u[k] * Lm[i][k];
+        dinv[i] = recip(d);
+    }
+    // forward substitution, diagonal scaling, backward substitution (core.py:1597-1616)
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k)
+            if (pt_nz(i, k)) b[i] -= Lm[i][k] * b[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] *= dinv[i];
+#pragma unroll
+    for (int j = 4; j >= 0; --j) {
+#pragma unroll
+        for (int k = j + 1; k < 6; ++k)
+            if (pt_nz(k, j)) b[j] -= Lm[k][j] * b[k];
+    }
+}
+
+template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, int iz)
+{
+    const Axes<T, 0> A(L);
+    const int ixm = ix - 1, ixp = ix + 1, iym = iy - 1, iyp = iy + 1, izm = iz - 1, izp = iz + 1;
+    const double hx0 = L.ihx[ixm], hx1 = L.ihx[ix];
+    const double hy0 = L.ihy[iym], hy1 = L.ihy[iy];
+    const double hz0 = L.ihz[izm], hz1 = L.ihz[iz];
+    const double kx0 = 0.5 * hx0, kx1 = 0.5 * hx1, ky0 = 0.5 * hy0, ky1 = 0.5 * hy1;
+    const double kz0 = 0.5 * hz0, kz1 = 0.5 * hz1;
+
+    // zeta of the 8 cells around the node: z[a][b][c], a/b/c = 0 (minus) or 1 (this)
+    const double z000 = L.zeta[A.icc(ixm, iym, izm)], z100 = L.zeta[A.icc(ix, iym, izm)];
+    const double z010 = L.zeta[A.icc(ixm, iy, izm)], z110 = L.zeta[A.icc(ix, iy, izm)];
+    const double z001 = L.zeta[A.icc(ixm, iym, iz)], z101 = L.zeta[A.icc(ix, iym, iz)];
+    const double z011 = L.zeta[A.icc(ixm, iy, iz)], z111 = L.zeta[A.icc(ix, iy, iz)];
+
+    // the 24 face averages (core.py:351-374), names as in the reference
+    const double mzyLxm = ky0 * (z001 + z000), mzyRxm = ky1 * (z011 + z010);
+    const double myzLxm = kz0 * (z010 + z000), myzRxm = kz1 * (z011 + z001);
+    const double mzyLxp = ky0 * (z101 + z100), mzyRxp = ky1 * (z111 + z110);
+    const double myzLxp = kz0 * (z110 + z100), myzRxp = kz1 * (z111 + z101);
+    const double mzxLym = kx0 * (z001 + z000), mzxRym = kx1 * (z101 + z100);
+    const double mxzLym = kz0 * (z100 + z000), mxzRym = kz1 * (z101 + z001);
+    const double mzxLyp = kx0 * (z011 + z010), mzxRyp = kx1 * (z111 + z110);
+    const double mxzLyp = kz0 * (z110 + z010), mxzRyp = kz1 * (z111 + z011);
+    const double myxLzm = kx0 * (z010 + z000), myxRzm = kx1 * (z110 + z100);
+    const double mxyLzm = ky0 * (z100 + z000), mxyRzm = ky1 * (z110 + z010);
+    const double myxLzp = kx0 * (z011 + z001), myxRzp = kx1 * (z111 + z101);
+    const double mxyLzp = ky0 * (z101 + z001), mxyRzp = ky1 * (z111 + z011);
+
+    // eta edge sums (core.py:377-390)
+#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
+    const T st0 = ETv(L.eta_x, ixm, iy, iz) + ETv(L.eta_x, ixm, iy, izm) +
+                  ETv(L.eta_x, ixm, iym, iz) + ETv(L.eta_x, ixm, iym, izm);
+    const T st1 = ETv(L.eta_x, ix, iy, iz) + ETv(L.eta_x, ix, iy, izm) +
+                  ETv(L.eta_x, ix, iym, iz) + ETv(L.eta_x, ix, iym, izm);
+    const T st2 = ETv(L.eta_y, ix, iym, iz) + ETv(L.eta_y, ix, iym, izm) +
+                  ETv(L.eta_y, ixm, iym, iz) + ETv(L.eta_y, ixm, iym, izm);
+    const T st3 = ETv(L.eta_y, ix, iy, iz) + ETv(L.eta_y, ix, iy, izm) +
+                  ETv(L.eta_y, ixm, iy, iz) + ETv(L.eta_y, ixm, iy, izm);
+    const T st4 = ETv(L.eta_z, ix, iy, izm) + ETv(L.eta_z, ix, iym, izm) +
+                  ETv(L.eta_z, ixm, iy, izm) + ETv(L.eta_z, ixm, iym, izm);
+    const T st5 = ETv(L.eta_z, ix, iy, iz) + ETv(L.eta_z, ix, iym, iz) +
+                  ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ixm, iym, iz);
+#undef ETv
+
+    // diagonal (core.py:396-412): -st/4 + real curl-curl part
+    T dg[6];
+    dg[0] = (mzyRxm * hy1 + mzyLxm * hy0 + myzRxm * hz1 + myzLxm * hz0) - 0.25 * st0;
+    dg[1] = (mzyRxp * hy1 + mzyLxp * hy0 + myzRxp * hz1 + myzLxp * hz0) - 0.25 * st1;
+    dg[2] = (mzxRym * hx1 + mzxLym * hx0 + mxzRym * hz1 + mxzLym * hz0) - 0.25 * st2;
+    dg[3] = (mzxRyp * hx1 + mzxLyp * hx0 + mxzRyp * hz1 + mxzLyp * hz0) - 0.25 * st3;
+    dg[4] = (myxRzm * hx1 + myxLzm * hx0 + mxyRzm * hy1 + mxyLzm * hy0) - 0.25 * st4;
+    dg[5] = (myxRzp * hx1 + myxLzp * hx0 + mxyRzp * hy1 + mxyLzp * hy0) - 0.25 * st5;
+
+    // strictly lower off-diagonals, all real (core.py:419-430); (1,0),(3,2),(5,4) are zero
+    double od[6][6];
+    od[1][0] = 0.0;
+    od[2][0] = -mzyLxm * hx0; od[3][0] = mzyRxm * hx0; od[4][0] = -myzLxm * hx0; od[5][0] = myzRxm * hx0;
+    od[2][1] = mzyLxp * hx1; od[3][1] = -mzyRxp * hx1; od[4][1] = myzLxp * hx1; od[5][1] = -myzRxp * hx1;
+    od[3][2] = 0.0;
+    od[4][2] = -mxzLym * hy0; od[5][2] = mxzRym * hy0;
+    od[4][3] = mxzLyp * hy1; od[5][3] = -mxzRyp * hy1;
+    od[5][4] = 0.0;
+
+    // right-hand side: source + terms of the 24 neighbouring edges (core.py:436-492)
+#define EXv(i, j, k) L.ex[A.iex(i, j, k)]
+#define EYv(i, j, k) L.ey[A.iey(i, j, k)]
+#define EZv(i, j, k) L.ez[A.iez(i, j, k)]
+    T rhs[6];
+    rhs[0] = L.sx[A.iex(ixm, iy, iz)];
+    rhs[1] = L.sx[A.iex(ix, iy, iz)];
+    rhs[2] = L.sy[A.iey(ix, iym, iz)];
+    rhs[3] = L.sy[A.iey(ix, iy, iz)];
+    rhs[4] = L.sz[A.iez(ix, iy, izm)];
+    rhs[5] = L.sz[A.iez(ix, iy, iz)];
+
+    // the 24 neighbour edges, each used twice
+    const T ex_mpc = EXv(ixm, iyp, iz), ex_mmc = EXv(ixm, iym, iz);   // ex[ixm, iy+-1, iz]
+    const T ex_mcp = EXv(ixm, iy, izp), ex_mcm = EXv(ixm, iy, izm);   // ex[ixm, iy, iz+-1]
+    const T ex_cpc = EXv(ix, iyp, iz), ex_cmc = EXv(ix, iym, iz);     // ex[ix, iy+-1, iz]
+    const T ex_ccp = EXv(ix, iy, izp), ex_ccm = EXv(ix, iy, izm);     // ex[ix, iy, iz+-1]
+    const T ey_mcc = EYv(ixm, iy, iz), ey_mmc = EYv(ixm, iym, iz);    // ey[ixm, iy|iym, iz]
+    const T ey_pcc = EYv(ixp, iy, iz), ey_pmc = EYv(ixp, iym, iz);    // ey[ixp, iy|iym, iz]
+    const T ey_cmp = EYv(ix, iym, izp), ey_cmm = EYv(ix, iym, izm);   // ey[ix, iym, iz+-1]
+    const T ey_ccp = EYv(ix, iy, izp), ey_ccm = EYv(ix, iy, izm);     // ey[ix, iy, iz+-1]
+    const T ez_mcc = EZv(ixm, iy, iz), ez_mcm = EZv(ixm, iy, izm);    // ez[ixm, iy, iz|izm]
+    const T ez_pcc = EZv(ixp, iy, iz), ez_pcm = EZv(ixp, iy, izm);    // ez[ixp, iy, iz|izm]
+    const T ez_cmc = EZv(ix, iym, iz), ez_cmm = EZv(ix, iym, izm);    // ez[ix, iym, iz|izm]
+    const T ez_cpc = EZv(ix, iyp, iz), ez_cpm = EZv(ix, iyp, izm);    // ez[ix, iyp, iz|izm]
+#undef EXv
+#undef EYv
+#undef EZv
+
+    rhs[0] += mzyRxm * (ey_mcc * hx0 + ex_mpc * hy1);
+    rhs[0] += mzyLxm * (ex_mmc * hy0 - ey_mmc * hx0);
+    rhs[0] += myzRxm * (ez_mcc * hx0 + ex_mcp * hz1);
+    rhs[0] += myzLxm * (ex_mcm * hz0 - ez_mcm * hx0);
+
+    rhs[1] += mzyRxp * (ex_cpc * hy1 - ey_pcc * hx1);
+    rhs[1] += mzyLxp * (ey_pmc * hx1 + ex_cmc * hy0);
+    rhs[1] += myzRxp * (ex_ccp * hz1 - ez_pcc * hx1);
+    rhs[1] += myzLxp * (ez_pcm * hx1 + ex_ccm * hz0);
+
+    rhs[2] += mzxRym * (ey_pmc * hx1 + ex_cmc * hy0);
+    rhs[2] += mzxLym * (ey_mmc * hx0 - ex_mmc * hy0);
+    rhs[2] += mxzRym * (ez_cmc * hy0 + ey_cmp * hz1);
+    rhs[2] += mxzLym * (ey_cmm * hz0 - ez_cmm * hy0);
+
+    rhs[3] += mzxRyp * (ey_pcc * hx1 - ex_cpc * hy1);
+    rhs[3] += mzxLyp * (ey_mcc * hx0 + ex_mpc * hy1);
+    rhs[3] += mxzRyp * (ey_ccp * hz1 - ez_cpc * hy1);
+    rhs[3] += mxzLyp * (ez_cpm * hy1 + ey_ccm * hz0);
+
+    rhs[4] += myxRzm * (ez_pcm * hx1 + ex_ccm * hz0);
+    rhs[4] += myxLzm * (ez_mcm * hx0 - ex_mcm * hz0);
+    rhs[4] += mxyRzm * (ez_cpm * hy1 + ey_ccm * hz0);
+    rhs[4] += mxyLzm * (ez_cmm * hy0 - ey_cmm * hz0);
+
+    rhs[5] += myxRzp * (ez_pcc * hx1 - ex_ccp * hz1);
+    rhs[5] += myxLzp * (ez_mcc * hx0 + ex_mcp * hz1);
+    rhs[5] += mxyRzp * (ez_cpc * hy1 - ey_ccp * hz1);
+    rhs[5] += mxyLzp * (ez_cmc * hy0 + ey_cmp * hz1);
+
+    solve6<T>(dg, od, rhs);
+
+    // write the six edges (core.py:498-503)
+    L.ex[A.iex(ixm, iy, iz)] = rhs[0];
+    L.ex[A.iex(ix, iy, iz)] = rhs[1];
+    L.ey[A.iey(ix, iym, iz)] = rhs[2];
+    L.ey[A.iey(ix, iy, iz)] = rhs[3];
+    L.ez[A.iez(ix, iy, izm)] = rhs[4];
+    L.ez[A.iez(ix, iy, iz)] = rhs[5];
+}
+
+// ---------------------------------------------------------------------------------------
+// Line smoother (core.gauss_seidel_x/_y/_z, reference emg3d/core.py:506-1348).
+//
+// One line along axis a0 at transverse node (i1,i2), 1 <= i1 <= n1-1, 1 <= i2 <= n2-1.
+// Block k = 0..n0-1 holds the unknowns
+//     [ E0(k,i1,i2) ;  E1(k+1,i1-1,i2), E1(k+1,i1,i2) ;  E2(k+1,i1,i2-1), E2(k+1,i1,i2) ]
+// (the last block only E0). For DIR=0 this is exactly the reference's x-line ordering
+// (core.py:678,733,775-783); for DIR=1,2 it is the cyclic image of it, which is the same
+// linear system as the reference's y-/z-line system with unknowns 1,2 <-> 3,4 exchanged.
+//
+// The symmetric band matrix (half bandwidth 5) is factorised row by row
+// (A = L D L^T without pivoting, the factorisation of core.solve) while it is assembled:
+// row i needs only the rows of the previous block. Per row the five sub-diagonal entries
+// of L and the scaled forward-substituted right-hand side are streamed to a scratch
+// buffer; a backward sweep over that buffer yields the solution. The reference's
+// `amat`/`bvec`/`middle`/`left` arrays (core.py:586-593) never exist.
+//
+// Scratch layout: 6 values of T per unknown row; value c of row i of line `lid` lives at
+// scratch[(i*6 + c) * lstride + lid]  (coalesced across the lines of one launch).
+// ---------------------------------------------------------------------------------------
+template <class T> struct LineState {
+    T Cp[5][5];     // strictly-lower L entries inside the previous block (Cp[r][m], m<r)
+    T dinvp[5];     // 1/D of the previous block
+    T yp[5];        // forward-substituted rhs (unscaled) of the previous block
+};
+
+// Assemble block k of the line (matrix rows of block k): diagonal dg[5], strictly-lower
+// real part mid[r][m] (m<r) inside the block, coupling to the previous block
+// left0[m] = A(row 0, prev col m), leftd[m] = A(row m, prev col m)  (m = 1..4), rhs[5].
+// Follows core.py:638-766 written in the abstract axes (a0,a1,a2).
+template <class T, int DIR>
+EMG_HD void line_assemble(const Axes<T, DIR> &A, int k, int i1, int i2, T (&dg)[5],
+                          double (&mid)[5][5], double (&left0)[5], double (&leftd)[5], T (&rhs)[5])
+{
+    const int n0 = A.n0();
+    const int i0m = k;                               // "ixm": minus index along the line
+    const int i0 = (k + 1 < n0 - 1) ? k + 1 : n0 - 1;  // "ix" clamped (core.py:635)
+    const int i1m = i1 - 1, i1p = i1 + 1, i2m = i2 - 1, i2p = i2 + 1;
+    const double h00 = A.ih0()[i0m], h01 = A.ih0()[i0];
+    const double h10 = A.ih1()[i1m], h11 = A.ih1()[i1];
+    const double h20 = A.ih2()[i2m], h21 = A.ih2()[i2];
+    const double k00 = 0.5 * h00, k01 = 0.5 * h01, k10 = 0.5 * h10, k11 = 0.5 * h11;
+    const double k20 = 0.5 * h20, k21 = 0.5 * h21;
+
+    const double z000 = A.zeta(i0m, i1m, i2m), z100 = A.zeta(i0, i1m, i2m);
+    const double z010 = A.zeta(i0m, i1, i2m), z110 = A.zeta(i0, i1, i2m);
+    const double z001 = A.zeta(i0m, i1m, i2), z101 = A.zeta(i0, i1m, i2);
+    const double z011 = A.zeta(i0m, i1, i2), z111 = A.zeta(i0, i1, i2);
+
+    // face averages with (x,y,z) read as (a0,a1,a2); the four "xp" ones are not needed
+    const double mzyLxm = k10 * (z001 + z000), mzyRxm = k11 * (z011 + z010);
+    const double myzLxm = k20 * (z010 + z000), myzRxm = k21 * (z011 + z001);
+    const double mzxLym = k00 * (z001 + z000), mzxRym = k01 * (z101 + z100);
+    const double mxzLym = k20 * (z100 + z000), mxzRym = k21 * (z101 + z001);
+    const double mzxLyp = k00 * (z011 + z010), mzxRyp = k01 * (z111 + z110);
+    const double mxzLyp = k20 * (z110 + z010), mxzRyp = k21 * (z111 + z011);
+    const double myxLzm = k00 * (z010 + z000), myxRzm = k01 * (z110 + z100);
+    const double mxyLzm = k10 * (z100 + z000), mxyRzm = k11 * (z110 + z010);
+    const double myxLzp = k00 * (z011 + z001), myxRzp = k01 * (z111 + z101);
+    const double mxyLzp = k10 * (z101 + z001), mxyRzp = k11 * (z111 + z011);
+
+    // eta sums (core.py:665-678)
+    const T st0 = A.eta(0, i0m, i1, i2) + A.eta(0, i0m, i1, i2m) + A.eta(0, i0m, i1m, i2) +
+                  A.eta(0, i0m, i1m, i2m);
+    const T st2 = A.eta(1, i0, i1m, i2) + A.eta(1, i0, i1m, i2m) + A.eta(1, i0m, i1m, i2) +
+                  A.eta(1, i0m, i1m, i2m);
+    const T st3 = A.eta(1, i0, i1, i2) + A.eta(1, i0, i1, i2m) + A.eta(1, i0m, i1, i2) +
+                  A.eta(1, i0m, i1, i2m);
+    const T st4 = A.eta(2, i0, i1, i2m) + A.eta(2, i0, i1m, i2m) + A.eta(2, i0m, i1, i2m) +
+                  A.eta(2, i0m, i1m, i2m);
+    const T st5 = A.eta(2, i0, i1, i2) + A.eta(2, i0, i1m, i2) + A.eta(2, i0m, i1, i2) +
+                  A.eta(2, i0m, i1m, i2);
+
+    // diagonal of `middle` (core.py:683-697)
+    dg[0] = (mzyRxm * h11 + mzyLxm * h10 + myzRxm * h21 + myzLxm * h20) - 0.25 * st0;
+    dg[1] = (mzxRym * h01 + mzxLym * h00 + mxzRym * h21 + mxzLym * h20) - 0.25 * st2;
+    dg[2] = (mzxRyp * h01 + mzxLyp * h00 + mxzRyp * h21 + mxzLyp * h20) - 0.25 * st3;
+    dg[3] = (myxRzm * h01 + myxLzm * h00 + mxyRzm * h11 + mxyLzm * h10) - 0.25 * st4;
+    dg[4] = (myxRzp * h01 + myxLzp * h00 + mxyRzp * h11 + mxyLzp * h10) - 0.25 * st5;
+
+    // strictly lower part of `middle` (core.py:704-711); (2,1) and (4,3) are zero
+    mid[1][0] = -mzyLxm * h00; mid[2][0] = mzyRxm * h00; mid[3][0] = -myzLxm * h00; mid[4][0] = myzRxm * h00;
+    mid[2][1] = 0.0;
+    mid[3][1] = -mxzLym * h10; mid[4][1] = mxzRym * h10;
+    mid[3][2] = mxzLyp * h11; mid[4][2] = -mxzRyp * h11;
+    mid[4][3] = 0.0;
+
+    // `left` (core.py:714-721): first row and diagonal
+    left0[0] = 0.0;
+    left0[1] = mzyLxm * h00; left0[2] = -mzyRxm * h00; left0[3] = myzLxm * h00; left0[4] = -myzRxm * h00;
+    leftd[0] = 0.0;
+    leftd[1] = -mzxLym * h00; leftd[2] = -mzxLyp * h00; leftd[3] = -myxLzm * h00; leftd[4] = -myxLzp * h00;
+
+    // right-hand side (core.py:727-766); only edges NOT on the line enter
+    rhs[0] = A.s(0, i0m, i1, i2);
+    rhs[1] = A.s(1, i0, i1m, i2);
+    rhs[2] = A.s(1, i0, i1, i2);
+    rhs[3] = A.s(2, i0, i1, i2m);
+    rhs[4] = A.s(2, i0, i1, i2);
+
+    rhs[0] += (mzyRxm * h11) * A.e(0, i0m, i1p, i2);
+    rhs[0] += (mzyLxm * h10) * A.e(0, i0m, i1m, i2);
+    rhs[0] += (myzRxm * h21) * A.e(0, i0m, i1, i2p);
+    rhs[0] += (myzLxm * h20) * A.e(0, i0m, i1, i2m);
+
+    const T e0_cmc = A.e(0, i0, i1m, i2), e0_mmc = A.e(0, i0m, i1m, i2);
+    rhs[1] += h10 * (mzxRym * e0_cmc - mzxLym * e0_mmc + mxzRym * A.e(2, i0, i1m, i2) -
+                     mxzLym * A.e(2, i0, i1m, i2m));
+    rhs[1] += (mxzRym * h21) * A.e(1, i0, i1m, i2p);
+    rhs[1] += (mxzLym * h20) * A.e(1, i0, i1m, i2m);
+
+    rhs[2] += h11 * (mzxLyp * A.e(0, i0m, i1p, i2) - mzxRyp * A.e(0, i0, i1p, i2) +
+                     mxzLyp * A.e(2, i0, i1p, i2m) - mxzRyp * A.e(2, i0, i1p, i2));
+    rhs[2] += (mxzRyp * h21) * A.e(1, i0, i1, i2p);
+    rhs[2] += (mxzLyp * h20) * A.e(1, i0, i1, i2m);
+
+    rhs[3] += h20 * (myxRzm * A.e(0, i0, i1, i2m) - myxLzm * A.e(0, i0m, i1, i2m) +
+                     mxyRzm * A.e(1, i0, i1, i2m) - mxyLzm * A.e(1, i0, i1m, i2m));
+    rhs[3] += (mxyRzm * h11) * A.e(2, i0, i1p, i2m);
+    rhs[3] += (mxyLzm * h10) * A.e(2, i0, i1m, i2m);
+
+    rhs[4] += h21 * (myxLzp * A.e(0, i0m, i1, i2p) - myxRzp * A.e(0, i0, i1, i2p) +
+                     mxyLzp * A.e(1, i0, i1m, i2p) - mxyRzp * A.e(1, i0, i1, i2p));
+    rhs[4] += (mxyRzp * h11) * A.e(2, i0, i1p, i2);
+    rhs[4] += (mxyLzp * h10) * A.e(2, i0, i1m, i2);
+}
+
+// Factorise the `nrows` (5, or 1 for the last block) rows of one block given the state of
+// the previous block; append L rows + scaled rhs to the scratch; advance the state.
+template <class T>
+EMG_HD void line_factor_block(LineState<T> &st, int nrows, const T (&dg)[5], const double (&mid)[5][5],
+                              const double (&left0)[5], const double (&leftd)[5], const T (&rhs)[5],
+                              T *scr, int row0, int lstride)
+{
+    T P[5][5];   // P[r][m], m>=r : L(row r of this block, col m of previous block)
+    T C[5][5];   // C[r][m], m<r  : L(row r, col m) inside this block
+    T dinv[5], y[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        if (r < nrows) {
+            T uP[5], uC[5];
+            // columns of the previous block, m = r..4
+#pragma unroll
+            for (int m = r; m < 5; ++m) {
+                const double a = (r == 0) ? left0[m] : (m == r ? leftd[m] : 0.0);
+                T t = T(a);
+#pragma unroll
+                for (int kk = r; kk < m; ++kk) t -= uP[kk] * st.Cp[m][kk];
+                uP[m] = t;
+                P[r][m] = t * st.dinvp[m];
+            }
+            // columns inside this block, m = 0..r-1
+#pragma unroll
+            for (int m = 0; m < r; ++m) {
+                T t = T(mid[r][m]);
+#pragma unroll
+                for (int kk = r; kk < 5; ++kk) t -= uP[kk] * P[m][kk];
+#pragma unroll
+                for (int kk = 0; kk < m; ++kk) t -= uC[kk] * C[m][kk];
+                uC[m] = t;
+                C[r][m] = t * dinv[m];
+            }
+            T d = dg[r];
+            T yy = rhs[r];
+#pragma unroll
+            for (int kk = r; kk < 5; ++kk) {
+                d -= uP[kk] * P[r][kk];
+                yy -= P[r][kk] * st.yp[kk];
+            }
+#pragma unroll
+            for (int kk = 0; kk < r; ++kk) {
+                d -= uC[kk] * C[r][kk];
+                yy -= C[r][kk] * y[kk];
+            }
+            dinv[r] = recip(d);
+            y[r] = yy;
+            // stream the row: columns i-5..i-1 are prev cols r..4 then own cols 0..r-1
+            T *o = scr + (size_t)(row0 + r) * 6 * lstride;
+#pragma unroll
+            for (int m = r; m < 5; ++m) o[(size_t)(m - r) * lstride] = P[r][m];
+#pragma unroll
+            for (int m = 0; m < r; ++m) o[(size_t)(5 - r + m) * lstride] = C[r][m];
+            o[(size_t)5 * lstride] = yy * dinv[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        st.dinvp[r] = dinv[r];
+        st.yp[r] = y[r];
+#pragma unroll
+        for (int m = 0; m < r; ++m) st.Cp[r][m] = C[r][m];
+    }
+}
+
+// Complete relaxation of one line: forward (assemble + factorise + forward substitution),
+// then backward substitution and scatter into the field (core.py:772-783).
+template <class T, int DIR>
+EMG_HD void gs_line(const Level<T> &L, int i1, int i2, T *scr, int lstride)
+{
+    const Axes<T, DIR> A(L);
+    const int n0 = A.n0();
+    LineState<T> st;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        st.dinvp[r] = zero<T>();
+        st.yp[r] = zero<T>();
+#pragma unroll
+        for (int m = 0; m < 5; ++m) st.Cp[r][m] = zero<T>();
+    }
+    T dg[5], rhs[5];
+    double mid[5][5], left0[5], leftd[5];
+
+    for (int k = 0; k < n0; ++k) {
+        line_assemble<T, DIR>(A, k, i1, i2, dg, mid, left0, leftd, rhs);
+        if (k == 0) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) { left0[m] = 0.0; leftd[m] = 0.0; }
+        }
+        line_factor_block<T>(st, (k == n0 - 1) ? 1 : 5, dg, mid, left0, leftd, rhs, scr, 5 * k, lstride);
+    }
+
+    // backward: x_i = z_i - sum_{k>i} L_ki x_k, done as a scatter while walking rows down
+    T accC[5], accP[5];
+    {   // last block: single row i = 5(n0-1)
+        const int i = 5 * (n0 - 1);
+        const T *o = scr + (size_t)i * 6 * lstride;
+        const T x = o[(size_t)5 * lstride];
+        A.E(0)[A.idx(0, n0 - 1, i1, i2)] = x;
+        // previous block rows get their z and the scatter of this row
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const T *om = scr + (size_t)(i - 5 + m) * 6 * lstride;
+            accC[m] = om[(size_t)5 * lstride] - o[(size_t)m * lstride] * x;
+        }
+    }
+    for (int k = n0 - 2; k >= 0; --k) {
+        const int row0 = 5 * k;
+        if (k > 0) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+                accP[m] = scr[((size_t)(row0 - 5 + m) * 6 + 5) * lstride];
+        }
+        T x[5];
+#pragma unroll
+        for (int r = 4; r >= 0; --r) {
+            x[r] = accC[r];
+            const T *o = scr + (size_t)(row0 + r) * 6 * lstride;
+#pragma unroll
+            for (int m = 0; m < r; ++m) accC[m] -= o[(size_t)(5 - r + m) * lstride] * x[r];
+            if (k > 0) {
+#pragma unroll
+                for (int m = r; m < 5; ++m) accP[m] -= o[(size_t)(m - r) * lstride] * x[r];
+            }
+        }
+        A.E(0)[A.idx(0, k, i1, i2)] = x[0];
+        A.E(1)[A.idx(1, k + 1, i1 - 1, i2)] = x[1];
+        A.E(1)[A.idx(1, k + 1, i1, i2)] = x[2];
+        A.E(2)[A.idx(2, k + 1, i1, i2 - 1)] = x[3];
+        A.E(2)[A.idx(2, k + 1, i1, i2)] = x[4];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) accC[m] = accP[m];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Restriction of the residual, core.restrict (reference emg3d/core.py:1620-2001).
+// One body for the seven sc_dir variants: c{x,y,z} say whether a direction is coarsened.
+// w?[0..2] point to (wl, w0, wr) of that direction (unused when not coarsened).
+// ---------------------------------------------------------------------------------------
+template <class T> struct Restrict {
+    int cx, cy, cz;              // direction coarsened? (0/1)
+    int nxn, nyn, nzn;           // FINE node counts (nx+1, ...)
+    int cnxn, cnyn, cnzn;        // COARSE node counts
+    const T *rx, *ry, *rz;       // fine residual
+    T *crx, *cry, *crz;          // coarse source
+    const double *wx[3], *wy[3], *wz[3];
+};
+
+template <class T> EMG_HD void restrict_node(const Restrict<T> &R, int cix, int ciy, int ciz)
+{
+    const int nx = R.nxn, ny = R.nyn, nz = R.nzn;
+    const int cnx = R.cnxn, cny = R.cnyn;
+    const int ix = R.cx ? 2 * cix : cix, iy = R.cy ? 2 * ciy : ciy, iz = R.cz ? 2 * ciz : ciz;
+    int ixs[3], iys[3], izs[3];
+    double wxs[3], wys[3], wzs[3];
+    ixs[0] = ix; ixs[1] = ix > 0 ? ix - 1 : 0; ixs[2] = ix + 1 < nx - 1 ? ix + 1 : nx - 1;
+    iys[0] = iy; iys[1] = iy > 0 ? iy - 1 : 0; iys[2] = iy + 1 < ny - 1 ? iy + 1 : ny - 1;
+    izs[0] = iz; izs[1] = iz > 0 ? iz - 1 : 0; izs[2] = iz + 1 < nz - 1 ? iz + 1 : nz - 1;
+    wxs[0] = R.cx ? R.wx[1][cix] : 1.0; wxs[1] = R.cx ? R.wx[0][cix] : 0.0; wxs[2] = R.cx ? R.wx[2][cix] : 0.0;
+    wys[0] = R.cy ? R.wy[1][ciy] : 1.0; wys[1] = R.cy ? R.wy[0][ciy] : 0.0; wys[2] = R.cy ? R.wy[2][ciy] : 0.0;
+    wzs[0] = R.cz ? R.wz[1][ciz] : 1.0; wzs[1] = R.cz ? R.wz[0][ciz] : 0.0; wzs[2] = R.cz ? R.wz[2][ciz] : 0.0;
+    const int nxt = R.cx ? 3 : 1, nyt = R.cy ? 3 : 1, nzt = R.cz ? 3 : 1;
+
+    if (cix < cnx - 1) {   // x-edges: fine shape (nx-1, ny, nz)
+        T acc = zero<T>();
+        for (int a = 0; a < nyt; ++a) {
+            T inner = zero<T>();
+            for (int b = 0; b < nzt; ++b) {
+                T v = R.rx[ix + (nx - 1) * (iys[a] + ny * izs[b])];
+                if (R.cx) v += R.rx[ixs[2] + (nx - 1) * (iys[a] + ny * izs[b])];
+                inner += wzs[b] * v;
+            }
+            acc += wys[a] * inner;
+        }
+        R.crx[cix + (cnx - 1) * (ciy + cny * ciz)] = acc;
+    }
+    if (ciy < cny - 1) {   // y-edges: fine shape (nx, ny-1, nz)
+        T acc = zero<T>();
+        for (int a = 0; a < nxt; ++a) {
+            T inner = zero<T>();
+            for (int b = 0; b < nzt; ++b) {
+                T v = R.ry[ixs[a] + nx * (iy + (ny - 1) * izs[b])];
+                if (R.cy) v += R.ry[ixs[a] + nx * (iys[2] + (ny - 1) * izs[b])];
+                inner += wzs[b] * v;
+            }
+            acc += wxs[a] * inner;
+        }
+        R.cry[cix + cnx * (ciy + (cny - 1) * ciz)] = acc;
+    }
+    if (ciz < R.cnzn - 1) {   // z-edges: fine shape (nx, ny, nz-1)
+        T acc = zero<T>();
+        for (int a = 0; a < nxt; ++a) {
+            T inner = zero<T>();
+            for (int b = 0; b < nyt; ++b) {
+                T v = R.rz[ixs[a] + nx * (iys[b] + ny * iz)];
+                if (R.cz) v += R.rz[ixs[a] + nx * (iys[b] + ny * izs[2])];
+                inner += wys[b] * v;
+            }
+            acc += wxs[a] * inner;
+        }
+        R.crz[cix + cnx * (ciy + cny * ciz)] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Prolongation  efield += P cefield  (reference emg3d/solver.py:947-1019, 1385-1478):
+// bilinear in the two directions transverse to the edge, piecewise constant along it,
+// interior nodes only. Per direction d the host supplies for every FINE node the lower
+// coarse node index il[d][i] and the weight w[d][i] of the UPPER coarse node
+// (solver.py:1457-1462); for a non-coarsened direction il = i (clamped), w = 0/1 exactly
+// as np.searchsorted gives it.
+// ---------------------------------------------------------------------------------------
+template <class T> struct Prolong {
+    int cx, cy, cz;              // direction coarsened?
+    int nx, ny, nz;              // fine cells
+    int cnx, cny, cnz;           // coarse cells
+    T *ex, *ey, *ez;             // fine field (updated)
+    const T *cex, *cey, *cez;    // coarse field
+    const int *ilx, *ily, *ilz;  // lower coarse node per fine node
+    const double *wx, *wy, *wz;  // weight of upper coarse node per fine node
+};
+
+// Fine "extended cell" (ix,iy,iz): updates ex[ix,iy,iz], ey[ix,iy,iz], ez[ix,iy,iz] when
+// they exist and are interior in their transverse directions.
+template <class T> EMG_HD void prolong_cell(const Prolong<T> &P, int ix, int iy, int iz)
+{
+    const int nx = P.nx, ny = P.ny, nz = P.nz, cnx = P.cnx, cny = P.cny;
+    const bool ty = iy >= 1 && iy <= ny - 1, tz = iz >= 1 && iz <= nz - 1, tx = ix >= 1 && ix <= nx - 1;
+    // the four weights are formed in the order of itertools.product((0,1),(0,1)):
+    // (lo,lo),(lo,hi),(hi,lo),(hi,hi) with first index = first transverse direction
+    if (ix < nx && ty && tz) {
+        const int cix = P.cx ? ix / 2 : ix;
+        const int a = P.ily[iy], b = P.ilz[iz];
+        const double wa = P.wy[iy], wb = P.wz[iz];
+        const T *c = P.cex + cix;
+        const T v = c[cnx * (a + (cny + 1) * b)] * ((1 - wa) * (1 - wb)) +
+                    c[cnx * (a + (cny + 1) * (b + 1))] * ((1 - wa) * wb) +
+                    c[cnx * (a + 1 + (cny + 1) * b)] * (wa * (1 - wb)) +
+                    c[cnx * (a + 1 + (cny + 1) * (b + 1))] * (wa * wb);
+        P.ex[ix + nx * (iy + (ny + 1) * iz)] += v;
+    }
+    if (iy < ny && tx && tz) {
+        const int ciy = P.cy ? iy / 2 : iy;
+        const int a = P.ilx[ix], b = P.ilz[iz];
+        const double wa = P.wx[ix], wb = P.wz[iz];
+        const T *c = P.cey + (cnx + 1) * ciy;
+        const T v = c[a + (cnx + 1) * cny * b] * ((1 - wa) * (1 - wb)) +
+                    c[a + (cnx + 1) * cny * (b + 1)] * ((1 - wa) * wb) +
+                    c[a + 1 + (cnx + 1) * cny * b] * (wa * (1 - wb)) +
+                    c[a + 1 + (cnx + 1) * cny * (b + 1)] * (wa * wb);
+        P.ey[ix + (nx + 1) * (iy + ny * iz)] += v;
+    }
+    if (iz < nz && tx && ty) {
+        const int ciz = P.cz ? iz / 2 : iz;
+        const int a = P.ilx[ix], b = P.ily[iy];
+        const double wa = P.wx[ix], wb = P.wy[iy];
+        const T *c = P.cez + (cnx + 1) * (cny + 1) * ciz;
+        const T v = c[a + (cnx + 1) * b] * ((1 - wa) * (1 - wb)) +
+                    c[a + (cnx + 1) * (b + 1)] * ((1 - wa) * wb) +
+                    c[a + 1 + (cnx + 1) * b] * (wa * (1 - wb)) +
+                    c[a + 1 + (cnx + 1) * (b + 1)] * (wa * wb);
+        P.ez[ix + (nx + 1) * (iy + (ny + 1) * iz)] += v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Coarse model parameter = SUM of the 2/4/8 fine cells (reference
+// emg3d/solver.py:1667-1718). fx,fy,fz in {1,2}: coarsening factor per direction.
+// ---------------------------------------------------------------------------------------
+template <class T>
+EMG_HD void restrict_param_cell(T *out, const T *in, int nx, int ny, int cnx, int cny, int fx, int fy,
+                                int fz, int cix, int ciy, int ciz)
+{
+    T acc = zero<T>();
+    for (int c = 0; c < fz; ++c)
+        for (int b = 0; b < fy; ++b)
+            for (int a = 0; a < fx; ++a)
+                acc += in[(fx * cix + a) + nx * ((fy * ciy + b) + ny * (fz * ciz + c))];
+    out[cix + cnx * (ciy + cny * ciz)] = acc;
+}
+
+}  // namespace emg
+
+// ---------------------------------------------------------------------------------------
+// The reference's banded storage, kept only for its known-answer tests
+// (emg3d_core_solve / emg3d_core_blocks_to_amat): A(i,j) -> amat[i+5j].
+// ---------------------------------------------------------------------------------------
+namespace emg {
+
+// core.solve (reference emg3d/core.py:1481-1616) for arbitrary n, sequential.
+template <class T> EMG_HD void band_solve(T *amat, T *bvec, int n)
+{
+    // factorisation, row by row (same L and D as the reference's column sweep)
+    for (int i = 0; i < n; ++i) {
+        const int k0 = i - 5 > 0 ? i - 5 : 0;
+        for (int j = k0; j < i; ++j) {
+            T t = amat[i + 5 * j];
+            for (int k = k0; k < j; ++k) t -= amat[i + 5 * k] * amat[j + 5 * k] * amat[6 * k];
+            amat[i + 5 * j] = t * recip(amat[6 * j]);
+        }
+        T d = amat[6 * i];
+        for (int k = k0; k < i; ++k) d -= amat[i + 5 * k] * amat[i + 5 * k] * amat[6 * k];
+        amat[6 * i] = d;
+    }
+    for (int j = 0; j < n; ++j) amat[6 * j] = recip(amat[6 * j]);   // core.py:1589-1592
+    for (int j = 1; j < n; ++j) {                                   // core.py:1597-1603
+        T h = zero<T>();
+        for (int k = (j - 5 > 0 ? j - 5 : 0); k < j; ++k) h += amat[j + 5 * k] * bvec[k];
+        bvec[j] -= h;
+    }
+    for (int j = 0; j < n; ++j) bvec[j] *= amat[6 * j];             // core.py:1606-1607
+    for (int j = n - 2; j >= 0; --j) {                              // core.py:1610-1616
+        T h = zero<T>();
+        for (int k = j + 1; k < (n < j + 6 ? n : j + 6); ++k) h += amat[k + 5 * j] * bvec[k];
+        bvec[j] -= h;
+    }
+}
+
+// core.blocks_to_amat (reference emg3d/core.py:1351-1477)
+template <class T>
+EMG_HD void blocks_to_amat(T *amat, T *bvec, const T *middle, const double *left, const T *rhs,
+                           int im, int nc)
+{
+    const int fam = 5 * im, mam = fam - 5;
+    if (im == 0) {
+        for (int k = 0; k < 5; ++k) bvec[k] = rhs[k];
+        for (int k = 0; k < 5; ++k)
+            for (int m = 0; m <= k; ++m) amat[k + 5 * m] = middle[k + 5 * m];
+    } else if (im <= nc - 2 && nc > 2) {
+        for (int k = 0; k < 5; ++k) bvec[k + fam] = rhs[k];
+        for (int m = 1; m < 5; ++m)
+            for (int k = 0; k <= m; ++k) amat[k + fam + 5 * (m + mam)] = T(left[k + 5 * m]);
+        for (int k = 0; k < 5; ++k)
+            for (int m = 0; m <= k; ++m) amat[k + fam + 5 * (m + fam)] = middle[k + 5 * m];
+    } else if (im == nc - 1) {
+        bvec[fam] = rhs[0];
+        for (int m = 1; m < 5; ++m) amat[fam + 5 * (m + mam)] = T(left[5 * m]);
+        amat[6 * fam] = middle[0];
+    }
+}
+
+}  // namespace emg

@@ -1,0 +1,144 @@
+/*
+ * emg3d_amd -- C ABI of the MI355X (gfx950) multigrid inner loop.
+ *
+ * Drop-in boundary for the hot path of emsig/emg3d: every entry point replaces one of the
+ * numba kernels of the reference's emg3d/core.py (called from emg3d/solver.py at the
+ * sites cited below) or one of the array-level pieces of emg3d/solver.py that have to live
+ * on the device once the level hierarchy is device-resident.
+ *
+ * Two flavours:
+ *   emg3d_core_*   HOST pointers, synchronous, exactly the arguments of the reference's
+ *                  `core.<fn>` plus explicit sizes -- what a ctypes binding inside the
+ *                  reference would call. Data is staged through HBM
+ *                  per call; this flavour exists for parity tests and literal drop-in use.
+ *   emg3d_dev_*    DEVICE pointers + hipStream_t, asynchronous; used by the device-resident
+ *                  multigrid driver (emg3d_amd/solver.py).
+ *
+ * Conventions
+ *   - All 3-D arrays are Fortran-ordered (x fastest), as in the reference
+ *     (emg3d/fields.py:201-259): ex (nx,ny+1,nz+1), ey (nx+1,ny,nz+1), ez (nx+1,ny+1,nz),
+ *     eta_x/eta_y/eta_z/zeta (nx,ny,nz). nx,ny,nz are CELL counts.
+ *   - is_complex = 1: fields and eta are complex128 (interleaved re,im); 0: float64
+ *     (Laplace domain, emg3d/fields.py:93-98). zeta and all widths/weights are float64.
+ *   - eta_x, eta_y, eta_z may alias each other (isotropic / VTI / HTI models,
+ *     emg3d/models.py:693-712); they are never written.
+ *   - Return value: 0 on success, otherwise a HIP error code (hipError_t) or a negative
+ *     emg3d_amd code; emg3d_last_error() gives the message. Numerical failure (zero
+ *     pivot -> inf/nan) is NOT an error here, exactly as in the reference
+ *     (emg3d/core.py:1560,1576); it surfaces through the residual norm.
+ *   - Smoother ordering: four-colour ordering; the first sweep of
+ *     a call is "backward" (colours 3,2,1,0), the second "forward" (0,1,2,3), ...,
+ *     mirroring the reference's backward-first alternation (emg3d/core.py:301,311).
+ */
+#ifndef EMG3D_AMD_H
+#define EMG3D_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMG3D_AMD_VERSION 100 /* 0.1.0 */
+
+#define EMG3D_ERR_BADARG (-1)
+#define EMG3D_ERR_NODEVICE (-2)
+#define EMG3D_ERR_SCRATCH (-3)
+
+/* One grid level with device-resident arrays (emg3d_dev_* flavour). */
+typedef struct emg3d_level {
+    int32_t nx, ny, nz;        /* cells */
+    int32_t is_complex;        /* 1 complex128, 0 float64 */
+    void *ex, *ey, *ez;        /* electric field, updated in place by the smoothers */
+    const void *sx, *sy, *sz;  /* source field */
+    const void *eta_x, *eta_y, *eta_z;
+    const double *zeta;
+    const double *ihx, *ihy, *ihz; /* INVERSE cell widths 1/h (device) */
+} emg3d_level;
+
+int emg3d_version(void);
+const char *emg3d_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int emg3d_device_count(void);
+
+/* ---------------------------------------------------------------- host flavour ---- */
+
+/* core.amat_x (emg3d/core.py:57-206; called at emg3d/solver.py:695,1060):  r -= A e */
+int emg3d_core_amat_x(void *rx, void *ry, void *rz, const void *ex, const void *ey, const void *ez,
+                      const void *eta_x, const void *eta_y, const void *eta_z, const double *zeta,
+                      const double *hx, const double *hy, const double *hz, int nx, int ny, int nz,
+                      int is_complex);
+
+/* core.gauss_seidel / _x / _y / _z (emg3d/core.py:210-1348; solver.py:837-846).
+ * lr = 0 point, 1 x-line, 2 y-line, 3 z-line. */
+int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx, const void *sy,
+                            const void *sz, const void *eta_x, const void *eta_y, const void *eta_z,
+                            const double *zeta, const double *hx, const double *hy, const double *hz,
+                            int nx, int ny, int nz, int nu, int is_complex);
+
+/* core.restrict (emg3d/core.py:1620-2001; solver.py:937). Coarse/fine NODE counts are
+ * implied: fine cells (nx,ny,nz), coarse cells = fine/2 in every coarsened direction.
+ * w?l/w?0/w?r: weights of emg3d/core.py:2004-2076 (length = coarse nodes; ignored for a
+ * direction that sc_dir does not coarsen). */
+int emg3d_core_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry,
+                        const void *rz, const double *wxl, const double *wx0, const double *wxr,
+                        const double *wyl, const double *wy0, const double *wyr, const double *wzl,
+                        const double *wz0, const double *wzr, int nx, int ny, int nz, int sc_dir,
+                        int is_complex);
+
+/* core.blocks_to_amat (emg3d/core.py:1351-1477) and core.solve (emg3d/core.py:1481-1616)
+ * on the reference's banded storage A(i,j) -> amat[i+5j]. Inside the line smoothers these
+ * never exist (the factorisation is streamed); the entry points are kept for the
+ * reference's known-answer tests and run as single-thread device kernels. */
+int emg3d_core_blocks_to_amat(void *amat, void *bvec, const void *middle, const double *left,
+                              const void *rhs, int im, int nc, int n, int is_complex);
+int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex);
+
+/* -------------------------------------------------------------- device flavour ---- */
+
+/* Bytes of scratch needed by emg3d_dev_gauss_seidel for direction lr (0 for lr = 0). */
+size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex);
+
+/* nu sweeps of the smoother lr (0 point, 1/2/3 line along x/y/z) on level lv. */
+int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, void *scratch, size_t scratch_bytes,
+                           void *stream);
+
+/* Number of doubles of workspace emg3d_dev_residual needs for its block partial sums. */
+size_t emg3d_residual_ws_len(int nx, int ny, int nz);
+
+/* solver.residual (emg3d/solver.py:1022-1070): r = s - A e for the whole buffer
+ * (rx/ry/rz may be NULL: norm only; they may alias lv->s*: in-place core.amat_x form).
+ * If sumsq != NULL, *sumsq (device double) receives sum |r|^2 over all entries
+ * (deterministic two-stage reduction through ws). */
+int emg3d_dev_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double *ws,
+                       size_t ws_len, double *sumsq, void *stream);
+
+/* core.restrict on device pointers; fine cells (nx,ny,nz). w arrays are device pointers. */
+int emg3d_dev_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry,
+                       const void *rz, const double *wxl, const double *wx0, const double *wxr,
+                       const double *wyl, const double *wy0, const double *wyr, const double *wzl,
+                       const double *wz0, const double *wzr, int nx, int ny, int nz, int sc_dir,
+                       int is_complex, void *stream);
+
+/* solver.prolongation (emg3d/solver.py:947-1019): fine e += P coarse e, interior only.
+ * il?/w? (device, length fine nodes): lower coarse node and weight of the upper coarse
+ * node per fine node (emg3d/solver.py:1457-1462). */
+int emg3d_dev_prolong(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,
+                      const int32_t *ilx, const int32_t *ily, const int32_t *ilz, const double *wx,
+                      const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir,
+                      int is_complex, void *stream);
+
+/* solver._restrict_model_parameters (emg3d/solver.py:1667-1718): coarse = sum of the
+ * 2/4/8 fine cells; is_complex refers to the parameter dtype (eta: field dtype, zeta: 0). */
+int emg3d_dev_restrict_param(void *out, const void *in, int nx, int ny, int nz, int sc_dir,
+                             int is_complex, void *stream);
+
+/* Zero the tangential field on the six PEC faces (emg3d/solver.py:349-355). */
+int emg3d_dev_pec_zero(void *ex, void *ey, void *ez, int nx, int ny, int nz, int is_complex,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMG3D_AMD_H */

@@ -1,0 +1,167 @@
+// TEST INFRASTRUCTURE ONLY -- CPU emulation of the HIP launch grids.
+//
+// Compiled with a plain host compiler (EMG_HD expands to `inline`), this file walks the
+// same (grid, block) index spaces as emg3d_amd/csrc/kernels.hip and calls the very same
+// per-thread bodies from emg3d_amd/csrc/{stencil,launch}.h on host arrays. It lets the
+// `-m "not gpu"` unit tests check the kernel BODIES and their index arithmetic against the
+// oracle in the build container, where no GPU exists. It is not a fallback: the product
+// package never loads it, and nothing here is reachable from emg3d_amd/.
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../emg3d_amd/csrc/launch.h"
+
+using emg::cplx;
+
+namespace {
+
+struct LevelArgs {
+    int32_t nx, ny, nz, is_complex;
+    void *ex, *ey, *ez;
+    const void *sx, *sy, *sz;
+    const void *eta_x, *eta_y, *eta_z;
+    const double *zeta;
+    const double *ihx, *ihy, *ihz;
+};
+
+template <class T> emg::Level<T> to_level(const LevelArgs *lv)
+{
+    emg::Level<T> L;
+    L.nx = lv->nx; L.ny = lv->ny; L.nz = lv->nz;
+    L.ex = (T *)lv->ex; L.ey = (T *)lv->ey; L.ez = (T *)lv->ez;
+    L.sx = (const T *)lv->sx; L.sy = (const T *)lv->sy; L.sz = (const T *)lv->sz;
+    L.eta_x = (const T *)lv->eta_x; L.eta_y = (const T *)lv->eta_y; L.eta_z = (const T *)lv->eta_z;
+    L.zeta = lv->zeta; L.ihx = lv->ihx; L.ihy = lv->ihy; L.ihz = lv->ihz;
+    return L;
+}
+
+// Walk a (grid x block) launch; f(gx, gy, gz) gets global thread indices.
+template <class F> void for_threads(emg::Dim3 g, emg::Dim3 b, F f)
+{
+    for (int bz = 0; bz < g.z; ++bz)
+        for (int by = 0; by < g.y; ++by)
+            for (int bx = 0; bx < g.x; ++bx)
+                for (int tz = 0; tz < b.z; ++tz)
+                    for (int ty = 0; ty < b.y; ++ty)
+                        for (int tx = 0; tx < b.x; ++tx)
+                            f(bx * b.x + tx, by * b.y + ty, bz * b.z + tz);
+}
+
+template <class T> void gs(const LevelArgs *lv, int lr, int nu)
+{
+    emg::Level<T> L = to_level<T>(lv);
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    std::vector<T> scratch(lr ? emg::gs_line_scratch_elems(lr - 1, nx, ny, nz) : 1);
+    int iback = 0;
+    for (int it = 0; it < nu; ++it) {
+        iback = 1 - iback;
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = iback ? 3 - cc : cc;
+            if (lr == 0) {
+                for_threads(emg::gs_point_grid(nx, ny, nz), emg::gs_point_block(),
+                            [&](int gx, int gy, int gz) { emg::gs_point_thread<T>(L, c, gx, gy, gz); });
+            } else {
+                const int dir = lr - 1;
+                const int cntp = emg::cnt_par(emg::line_np(dir, nx, ny, nz), c & 1);
+                const int cntq = emg::cnt_par(emg::line_nq(dir, nx, ny, nz), (c >> 1) & 1);
+                if (cntp <= 0 || cntq <= 0) continue;
+                for_threads(emg::gs_line_grid(cntp, cntq), emg::gs_line_block(), [&](int gx, int gy, int) {
+                    if (dir == 0) emg::gs_line_thread<T, 0>(L, c, cntp, cntq, gx, gy, scratch.data());
+                    else if (dir == 1) emg::gs_line_thread<T, 1>(L, c, cntp, cntq, gx, gy, scratch.data());
+                    else emg::gs_line_thread<T, 2>(L, c, cntp, cntq, gx, gy, scratch.data());
+                });
+            }
+        }
+    }
+}
+
+template <class T> double residual(const LevelArgs *lv, void *rx, void *ry, void *rz)
+{
+    emg::Level<T> L = to_level<T>(lv);
+    double acc = 0.0;
+    for_threads(emg::cell_grid(L.nx + 1, L.ny + 1, L.nz + 1), emg::cell_block(), [&](int ix, int iy, int iz) {
+        if (ix <= L.nx && iy <= L.ny) acc += emg::residual_cell<T>(L, (T *)rx, (T *)ry, (T *)rz, ix, iy, iz);
+    });
+    return acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
+{
+    if (lv->is_complex) gs<cplx>(lv, lr, nu); else gs<double>(lv, lr, nu);
+}
+
+double emu_residual(const LevelArgs *lv, void *rx, void *ry, void *rz)
+{
+    return lv->is_complex ? residual<cplx>(lv, rx, ry, rz) : residual<double>(lv, rx, ry, rz);
+}
+
+void emu_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry, const void *rz,
+                  const double *const *w, int nx, int ny, int nz, int sc_dir, int is_complex)
+{
+    if (is_complex) {
+        auto R = emg::make_restrict<cplx>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir);
+        for_threads(emg::cell_grid(R.cnxn, R.cnyn, R.cnzn), emg::cell_block(), [&](int i, int j, int k) {
+            if (i < R.cnxn && j < R.cnyn) emg::restrict_node<cplx>(R, i, j, k);
+        });
+    } else {
+        auto R = emg::make_restrict<double>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir);
+        for_threads(emg::cell_grid(R.cnxn, R.cnyn, R.cnzn), emg::cell_block(), [&](int i, int j, int k) {
+            if (i < R.cnxn && j < R.cnyn) emg::restrict_node<double>(R, i, j, k);
+        });
+    }
+}
+
+void emu_prolong(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,
+                 const int *ilx, const int *ily, const int *ilz, const double *wx, const double *wy,
+                 const double *wz, int nx, int ny, int nz, int sc_dir, int is_complex)
+{
+    if (is_complex) {
+        auto P = emg::make_prolong<cplx>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz, sc_dir);
+        for_threads(emg::cell_grid(nx + 1, ny + 1, nz + 1), emg::cell_block(), [&](int i, int j, int k) {
+            if (i <= nx && j <= ny) emg::prolong_cell<cplx>(P, i, j, k);
+        });
+    } else {
+        auto P = emg::make_prolong<double>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz, sc_dir);
+        for_threads(emg::cell_grid(nx + 1, ny + 1, nz + 1), emg::cell_block(), [&](int i, int j, int k) {
+            if (i <= nx && j <= ny) emg::prolong_cell<double>(P, i, j, k);
+        });
+    }
+}
+
+void emu_restrict_param(void *out, const void *in, int nx, int ny, int nz, int sc_dir, int is_complex)
+{
+    const emg::ScDirs f = emg::sc_flags(sc_dir);
+    const int fx = f.cx ? 2 : 1, fy = f.cy ? 2 : 1, fz = f.cz ? 2 : 1;
+    const int cnx = nx / fx, cny = ny / fy, cnz = nz / fz;
+    for (int k = 0; k < cnz; ++k)
+        for (int j = 0; j < cny; ++j)
+            for (int i = 0; i < cnx; ++i) {
+                if (is_complex)
+                    emg::restrict_param_cell<cplx>((cplx *)out, (const cplx *)in, nx, ny, cnx, cny, fx, fy, fz, i, j, k);
+                else
+                    emg::restrict_param_cell<double>((double *)out, (const double *)in, nx, ny, cnx, cny, fx, fy, fz, i, j, k);
+            }
+}
+
+void emu_solve(void *amat, void *bvec, int n, int is_complex)
+{
+    if (is_complex) emg::band_solve<cplx>((cplx *)amat, (cplx *)bvec, n);
+    else emg::band_solve<double>((double *)amat, (double *)bvec, n);
+}
+
+void emu_blocks_to_amat(void *amat, void *bvec, const void *middle, const double *left, const void *rhs,
+                        int im, int nc, int is_complex)
+{
+    if (is_complex)
+        emg::blocks_to_amat<cplx>((cplx *)amat, (cplx *)bvec, (const cplx *)middle, left, (const cplx *)rhs, im, nc);
+    else
+        emg::blocks_to_amat<double>((double *)amat, (double *)bvec, (const double *)middle, left,
+                                    (const double *)rhs, im, nc);
+}
+
+}  // extern "C"
