@@ -1,0 +1,233 @@
+"""Device-resident grid levels and thin wrappers around the ``emg3d_dev_*`` C ABI.
+
+PyTorch is used for exactly three things here: HBM allocations (tensors), the HIP stream
+the kernels are enqueued on, and (in emg3d_amd/parallel.py) the RCCL process group. All
+arithmetic of the multigrid path happens in the hand-written HIP kernels of
+emg3d_amd/csrc/; no torch operator touches field data in the cycle.
+
+A ``DeviceLevel`` owns, for one grid of the hierarchy: the electric field ``e``, the source
+``s`` and a residual buffer ``r`` (each ONE buffer ``[fx|fy|fz]`` like the reference's
+``Field``, emg3d/fields.py:201-259), the volume-integrated model ``eta_x/eta_y/eta_z/zeta``
+(aliased for isotropic / VTI / HTI models, emg3d/models.py:693-712), inverse cell widths,
+and lazily-built coarse children per semicoarsening direction together with the
+restriction weights (emg3d/solver.py:1721-1780) and prolongation tables
+(emg3d/solver.py:1457-1462) that connect them. The reference re-creates coarse grids,
+models and fields at every visit (emg3d/solver.py:849-944); here they are built once per
+(level, sc_dir) and reused.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from emg3d_amd import _lib, meshes
+from emg3d_amd import core as _core
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, offset_elems=0):
+    return _vp(t.data_ptr() + offset_elems * t.element_size())
+
+
+def coarsen_flags(sc_dir):
+    """(cx, cy, cz): is the direction coarsened for this sc_dir? (solver.py:891-897)"""
+    return (sc_dir not in (1, 5, 6), sc_dir not in (2, 4, 6), sc_dir not in (3, 4, 5))
+
+
+def interp_table(cnodes, nodes):
+    """Lower coarse node index and weight of the upper coarse node for every fine node,
+    as ``np.searchsorted`` yields them in the reference (emg3d/solver.py:1457-1462)."""
+    i = np.searchsorted(cnodes, nodes) - 1
+    i[i < 0] = 0
+    i[i > cnodes.size - 2] = cnodes.size - 2
+    w = (nodes - cnodes[i]) / (cnodes[i + 1] - cnodes[i])
+    return i.astype(np.int32), w.astype(np.float64)
+
+
+class Workspace:
+    """Scratch shared by all levels of one hierarchy (solver lifetime, not per call)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.gs_scratch = None
+        self.gs_bytes = 0
+        self.ws = None
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def need_gs(self, nbytes):
+        if nbytes > self.gs_bytes:
+            self.gs_scratch = None   # release before growing
+            self.gs_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.gs_bytes = nbytes
+
+    def need_ws(self, n):
+        if self.ws is None or self.ws.numel() < n:
+            self.ws = torch.empty(max(int(n), 1), dtype=torch.float64, device=self.device)
+
+
+class DeviceLevel:
+    """One grid level resident in HBM."""
+
+    def __init__(self, grid, case, eta_x, eta_y, eta_z, zeta, dtype, work, device):
+        self.grid = grid
+        self.case = case
+        self.device = device
+        self.work = work
+        self.dtype = dtype                                  # torch.complex128 / float64
+        self.is_complex = int(dtype == torch.complex128)
+        self.eta_x, self.eta_y, self.eta_z, self.zeta = eta_x, eta_y, eta_z, zeta
+        self.ih = [torch.from_numpy(np.ascontiguousarray(1.0 / h)).to(device) for h in grid.h]
+        n = grid.n_edges
+        self.e = torch.zeros(n, dtype=dtype, device=device)
+        self.s = torch.zeros(n, dtype=dtype, device=device)
+        self._r = None
+        self.children = {}
+        self.n_cells = grid.n_cells
+        self._o1, self._o2 = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y
+        nx, ny, nz = grid.shape_cells
+        self._c = _lib.Level(
+            nx, ny, nz, self.is_complex,
+            _ptr(self.e), _ptr(self.e, self._o1), _ptr(self.e, self._o2),
+            _ptr(self.s), _ptr(self.s, self._o1), _ptr(self.s, self._o2),
+            _ptr(eta_x), _ptr(eta_y), _ptr(eta_z), _ptr(zeta),
+            _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]))
+        self._cref = ctypes.byref(self._c)
+        work.need_ws(_lib.lib().emg3d_residual_ws_len(nx, ny, nz))
+
+    # ---------------------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, vmodel, device, work=None):
+        """Upload a host ``VolumeModel`` (finest level)."""
+        work = work or Workspace(device)
+        cplx = np.iscomplexobj(vmodel.eta_x)
+        dtype = torch.complex128 if cplx else torch.float64
+        ndt = np.complex128 if cplx else np.float64
+        up = {}
+
+        def upload(a, dt):
+            key = id(a)
+            if key not in up:      # preserves aliasing of eta_x/eta_y/eta_z
+                up[key] = torch.from_numpy(np.asfortranarray(a, dtype=dt).ravel('F').copy()).to(device)
+            return up[key]
+        return cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case,
+                   upload(vmodel.eta_x, ndt), upload(vmodel.eta_y, ndt), upload(vmodel.eta_z, ndt),
+                   upload(vmodel.zeta, np.float64), dtype, work, device)
+
+    @property
+    def r(self):
+        if self._r is None:
+            self._r = torch.empty(self.grid.n_edges, dtype=self.dtype, device=self.device)
+        return self._r
+
+    def parts(self, t):
+        """(px, py, pz) pointers into a 1-D buffer [fx|fy|fz]."""
+        return _ptr(t), _ptr(t, self._o1), _ptr(t, self._o2)
+
+    # ------------------------------------------------------------------- kernels ------
+    def smooth(self, lr, nu):
+        """nu sweeps of smoother lr (0 point, 1/2/3 x/y/z line) on (e, s)."""
+        lib = _lib.lib()
+        nx, ny, nz = self.grid.shape_cells
+        nbytes = lib.emg3d_gs_scratch_bytes(lr, nx, ny, nz, self.is_complex)
+        self.work.need_gs(nbytes)
+        scr = _ptr(self.work.gs_scratch) if nbytes else None
+        _lib.check(lib.emg3d_dev_gauss_seidel(self._cref, lr, nu, scr, nbytes, _stream()),
+                   'emg3d_dev_gauss_seidel')
+
+    def residual(self, store=True, norm=False):
+        """r = s - A e into self.r (store) and/or its l2-norm (norm; synchronises)."""
+        lib = _lib.lib()
+        rx, ry, rz = self.parts(self.r) if store else (None, None, None)
+        w = self.work
+        _lib.check(lib.emg3d_dev_residual(self._cref, rx, ry, rz, _ptr(w.ws), w.ws.numel(),
+                                          _ptr(w.sumsq) if norm else None, _stream()),
+                   'emg3d_dev_residual')
+        if norm:
+            return float(np.sqrt(w.sumsq.item()))
+        return None
+
+    def pec_zero(self):
+        nx, ny, nz = self.grid.shape_cells
+        _lib.check(_lib.lib().emg3d_dev_pec_zero(*self.parts(self.e), nx, ny, nz,
+                                                 self.is_complex, _stream()), 'emg3d_dev_pec_zero')
+
+    # ------------------------------------------------------------- grid transfer ------
+    def child(self, sc_dir):
+        """Coarse level for semicoarsening code sc_dir (0..6), built on first use:
+        coarse grid (solver.py:899-905), summed model parameters (:916-926), restriction
+        weights (:931) and prolongation tables."""
+        if sc_dir in self.children:
+            return self.children[sc_dir]
+        lib = _lib.lib()
+        g = self.grid
+        cx, cy, cz = coarsen_flags(sc_dir)
+        rx, ry, rz = (2 if cx else 1), (2 if cy else 1), (2 if cz else 1)
+        ch = [np.diff(g.nodes_x[::rx]), np.diff(g.nodes_y[::ry]), np.diff(g.nodes_z[::rz])]
+        cgrid = meshes.BaseMesh(ch, g.origin)
+        nx, ny, nz = g.shape_cells
+
+        def restrict_param(p, is_complex, dtype):
+            out = torch.empty(cgrid.n_cells, dtype=dtype, device=self.device)
+            _lib.check(lib.emg3d_dev_restrict_param(_ptr(out), _ptr(p), nx, ny, nz, sc_dir,
+                                                    is_complex, _stream()),
+                       'emg3d_dev_restrict_param')
+            return out
+        ceta_x = restrict_param(self.eta_x, self.is_complex, self.dtype)
+        ceta_y = (restrict_param(self.eta_y, self.is_complex, self.dtype)
+                  if self.case in ('HTI', 'triaxial') else ceta_x)
+        ceta_z = (restrict_param(self.eta_z, self.is_complex, self.dtype)
+                  if self.case in ('VTI', 'triaxial') else ceta_x)
+        czeta = restrict_param(self.zeta, 0, torch.float64)
+        clevel = DeviceLevel(cgrid, self.case, ceta_x, ceta_y, ceta_z, czeta, self.dtype,
+                             self.work, self.device)
+
+        # restriction weights (only for coarsened directions; others are never read)
+        weights = []
+        for d, coarsened in enumerate((cx, cy, cz)):
+            if coarsened:
+                nodes = (g.nodes_x, g.nodes_y, g.nodes_z)[d]
+                cc = (g.cell_centers_x, g.cell_centers_y, g.cell_centers_z)[d]
+                cnodes = (cgrid.nodes_x, cgrid.nodes_y, cgrid.nodes_z)[d]
+                ccc = (cgrid.cell_centers_x, cgrid.cell_centers_y, cgrid.cell_centers_z)[d]
+                w3 = _core.restrict_weights(nodes, cc, g.h[d], cnodes, ccc, cgrid.h[d])
+                weights.append([torch.from_numpy(np.ascontiguousarray(w)).to(self.device)
+                                for w in w3])
+            else:
+                weights.append([None, None, None])
+        wptr = [(_ptr(w) if w is not None else None) for w3 in weights for w in w3]
+
+        # prolongation tables
+        tabs = [interp_table(cn, n) for cn, n in ((cgrid.nodes_x, g.nodes_x),
+                                                  (cgrid.nodes_y, g.nodes_y),
+                                                  (cgrid.nodes_z, g.nodes_z))]
+        il = [torch.from_numpy(t[0]).to(self.device) for t in tabs]
+        pw = [torch.from_numpy(t[1]).to(self.device) for t in tabs]
+        link = {'level': clevel, 'weights': weights, 'wptr': wptr, 'il': il, 'pw': pw}
+        self.children[sc_dir] = link
+        return link
+
+    def restrict_to(self, sc_dir):
+        """csfield <- R(self.r); cefield <- 0 (solver.py:937-941). Returns the child."""
+        link = self.child(sc_dir)
+        c = link['level']
+        nx, ny, nz = self.grid.shape_cells
+        _lib.check(_lib.lib().emg3d_dev_restrict(
+            *c.parts(c.s), *self.parts(self.r), *link['wptr'], nx, ny, nz, sc_dir,
+            self.is_complex, _stream()), 'emg3d_dev_restrict')
+        c.e.zero_()
+        return c
+
+    def prolong_from(self, sc_dir):
+        """self.e += P child.e (solver.py:947-1019)."""
+        link = self.children[sc_dir]
+        c = link['level']
+        nx, ny, nz = self.grid.shape_cells
+        _lib.check(_lib.lib().emg3d_dev_prolong(
+            *self.parts(self.e), *c.parts(c.e), *[_ptr(t) for t in link['il']],
+            *[_ptr(t) for t in link['pw']], nx, ny, nz, sc_dir, self.is_complex, _stream()),
+            'emg3d_dev_prolong')

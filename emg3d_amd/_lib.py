@@ -1,0 +1,104 @@
+"""Loader of the HIP shared library (emg3d_amd/lib/libemg3d_amd.so) through ctypes.
+
+The library is the product: there is no CPU fallback. If it cannot be loaded, or if a
+device entry point is called without a GPU, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIBDIR = os.path.join(_HERE, 'lib')
+LIBPATH = os.path.join(LIBDIR, 'libemg3d_amd.so')
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'emg3d_amd.h')
+SOURCES = [os.path.join(CSRC, f) for f in ('kernels.hip', 'stencil.h', 'launch.h', 'cplx.h')] + [HEADER]
+
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
+
+
+class Emg3dAmdError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    stale = (not os.path.exists(LIBPATH) or
+             any(os.path.getmtime(s) > os.path.getmtime(LIBPATH) for s in SOURCES))
+    if force or stale:
+        hipcc = os.environ.get('HIPCC', 'hipcc')
+        cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, 'kernels.hip'), '-o', LIBPATH]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIBPATH
+
+
+_vp, _ci, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+
+class Level(ctypes.Structure):
+    """Mirror of `emg3d_level` (include/emg3d_amd.h)."""
+    _fields_ = [('nx', ctypes.c_int32), ('ny', ctypes.c_int32), ('nz', ctypes.c_int32),
+                ('is_complex', ctypes.c_int32),
+                ('ex', _vp), ('ey', _vp), ('ez', _vp),
+                ('sx', _vp), ('sy', _vp), ('sz', _vp),
+                ('eta_x', _vp), ('eta_y', _vp), ('eta_z', _vp),
+                ('zeta', _vp), ('ihx', _vp), ('ihy', _vp), ('ihz', _vp)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/emg3d_amd.h
+SIGNATURES = {
+    'emg3d_version': (_ci, []),
+    'emg3d_last_error': (ctypes.c_char_p, []),
+    'emg3d_device_count': (_ci, []),
+    'emg3d_core_amat_x': (_ci, [_vp] * 13 + [_ci] * 4),
+    'emg3d_core_gauss_seidel': (_ci, [_ci] + [_vp] * 13 + [_ci] * 5),
+    'emg3d_core_restrict': (_ci, [_vp] * 15 + [_ci] * 5),
+    'emg3d_core_blocks_to_amat': (_ci, [_vp] * 5 + [_ci] * 4),
+    'emg3d_core_solve': (_ci, [_vp, _vp, _ci, _ci]),
+    'emg3d_gs_scratch_bytes': (_sz, [_ci] * 5),
+    'emg3d_dev_gauss_seidel': (_ci, [ctypes.POINTER(Level), _ci, _ci, _vp, _sz, _vp]),
+    'emg3d_residual_ws_len': (_sz, [_ci] * 3),
+    'emg3d_dev_residual': (_ci, [ctypes.POINTER(Level), _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'emg3d_dev_restrict': (_ci, [_vp] * 15 + [_ci] * 5 + [_vp]),
+    'emg3d_dev_prolong': (_ci, [_vp] * 12 + [_ci] * 5 + [_vp]),
+    'emg3d_dev_restrict_param': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
+    'emg3d_dev_pec_zero': (_ci, [_vp] * 3 + [_ci] * 4 + [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (ctypes.CDLL) with argument types set. Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise ImportError(
+                f"emg3d_amd: HIP library not found at {LIBPATH}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no CPU fallback.")
+        cdll = ctypes.CDLL(LIBPATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)     # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = cdll
+    return _lib
+
+
+def check(status, what=''):
+    """Turn a non-zero C-ABI status into an exception (reference kernels raise nothing;
+    this only reports HIP / argument errors, see include/emg3d_amd.h)."""
+    if status != 0:
+        msg = lib().emg3d_last_error()
+        raise Emg3dAmdError(f"{what} failed with status {status}: "
+                            f"{msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    if lib().emg3d_device_count() < 1:
+        raise Emg3dAmdError("emg3d_amd: no HIP device visible; the MI355X path has no CPU "
+                            "fallback.")

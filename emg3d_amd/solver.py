@@ -1,0 +1,794 @@
+"""Multigrid solver driver: ``solve`` / ``multigrid`` / ``krylov`` with the reference's
+signatures, keyword arguments, defaults, return conventions, ``info_dict`` keys and exit
+messages (reference emg3d/solver.py:52-449, 471-649, 1074-1381, 1482-1664), running the
+cycle on a device-resident level hierarchy (emg3d_amd/_device.py) with the HIP kernels.
+
+Host side (this file): cycle control flow -- V/W/F recursion, semicoarsening and
+line-relaxation cycling, termination rules, logging. It is O(levels) Python per cycle.
+Device side: everything that touches a field entry.
+
+Differences from the reference that are intended:
+* smoothers use a four-colour ordering (include/emg3d_amd.h); converged fields agree
+  with the reference to the solver tolerance, per-cycle error histories differ slightly;
+* the residual norm on coarse levels (emg3d/solver.py:530) is only evaluated when its
+  value is used (level 0, or ``verb > 4``);
+* coarse grids / models / weights are built once per (level, sc_dir) and reused.
+"""
+import itertools
+import time
+from dataclasses import dataclass
+from datetime import datetime, timedelta
+from typing import Union
+
+import numpy as np
+import torch
+
+from emg3d_amd import _lib, fields, models
+from emg3d_amd._device import DeviceLevel
+
+__all__ = ['solve', 'solve_source', 'multigrid', 'krylov', 'smoothing', 'restriction',
+           'prolongation', 'residual', 'MGParameters', 'RegularGridProlongator']
+
+
+def __dir__():
+    return __all__
+
+
+class Timer:
+    """Wall-clock timer with the reference's attributes (emg3d/utils.py:169-197)."""
+
+    def __init__(self):
+        self._t0 = time.perf_counter()
+
+    @property
+    def t0(self):
+        return self._t0
+
+    @property
+    def now(self):
+        return datetime.now().strftime("%H:%M:%S")
+
+    @property
+    def elapsed(self):
+        return time.perf_counter() - self._t0
+
+    @property
+    def runtime(self):
+        return str(timedelta(seconds=np.round(self.elapsed)))
+
+
+# ------------------------------------------------------------------------------ solve ---
+def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=True, verb=0,
+          **kwargs):
+    """Solver for three-dimensional electromagnetic diffusion on one MI355X.
+
+    Same call as the reference's ``emg3d.solve`` (emg3d/solver.py:52-449): multigrid
+    (cycle 'F', 'V', 'W') as solver or as preconditioner of a Krylov method, with
+    semicoarsening and line relaxation.
+
+    Parameters: ``model`` (Model), ``sfield`` (Field), ``sslsolver`` {True, False,
+    'bicgstab', 'cgs', 'gcrotmk'}, ``semicoarsening`` / ``linerelaxation`` {bool, int},
+    ``verb`` int, and by keyword ``cycle='F'``, ``efield=None``, ``tol=1e-6``,
+    ``maxit=50``, ``nu_init=0``, ``nu_pre=2``, ``nu_coarse=1``, ``nu_post=2``,
+    ``clevel=-1``, ``return_info=False``, ``log=1``, ``plain=False``.
+
+    Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``).
+    """
+    always_return = kwargs.pop('always_return', False)
+    if kwargs.pop('plain', False):
+        sslsolver = False if sslsolver is True else sslsolver
+        semicoarsening = False if semicoarsening is True else semicoarsening
+        linerelaxation = False if linerelaxation is True else linerelaxation
+    efield = kwargs.pop('efield', None)
+
+    var = MGParameters(sslsolver=sslsolver, semicoarsening=semicoarsening,
+                       linerelaxation=linerelaxation, shape_cells=model.shape, verb=verb,
+                       **kwargs)
+
+    var.cprint(f"\n:: emg3d START :: {var.time.now} :: emg3d_amd (MI355X)\n", 2)
+    var.cprint(var, 2)
+
+    var.l2_refe = float(np.linalg.norm(sfield.field))
+    var.error_at_cycle[0] = var.l2_refe
+
+    if sfield.frequency is None:
+        raise ValueError(
+            "Source field is missing frequency information; Create "
+            "it with `emg3d.fields.get_source_field`, or initiate it "
+            "with `emg3d.fields.Field`, providing frequency information.")
+
+    vmodel = models.VolumeModel(model, sfield)
+    info = ""
+
+    if efield is None:
+        efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
+        var.do_return = True
+    else:
+        if sfield.field.dtype != efield.field.dtype:
+            raise ValueError(
+                "Source field and electric field must have the same "
+                "dtype; complex (f-domain) or real (s-domain). Provided:"
+                f"sfield: {sfield.field.dtype}; efield: {efield.field.dtype}.")
+        if efield.frequency is None:
+            efield._frequency = sfield._frequency
+
+        # PEC boundary on the provided field (emg3d/solver.py:349-355)
+        efield.fx[:, 0, :] = efield.fx[:, -1, :] = 0.
+        efield.fx[:, :, 0] = efield.fx[:, :, -1] = 0.
+        efield.fy[0, :, :] = efield.fy[-1, :, :] = 0.
+        efield.fy[:, :, 0] = efield.fy[:, :, -1] = 0.
+        efield.fz[0, :, :] = efield.fz[-1, :, :] = 0.
+        efield.fz[:, 0, :] = efield.fz[:, -1, :] = 0.
+        var.do_return = always_return
+
+        var.l2 = residual(vmodel, sfield, efield, True)
+        if var.l2 < var.tol * var.l2_refe:
+            var.sslsolver = None
+            var.cycle = None
+            var.exit_message = "CONVERGED"
+            info = "   > NOTHING DONE (provided efield already good enough)\n"
+
+    if var.l2_refe < 100 * np.finfo(float).tiny:
+        var.l2_refe = np.nan
+        var.sslsolver = None
+        var.cycle = None
+        var.exit_message = "CONVERGED"
+        info = "   > RETURN ZERO E-FIELD (provided sfield is zero)\n"
+        efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
+
+    header = f"   [hh:mm:ss]  {'rel. error':<22}"
+    if var.sslsolver:
+        header += f"{'solver':<20}"
+        if var.cycle:
+            header += f"{'MG':<11} l s"
+        var.cprint(header + "\n", 3)
+    elif var.cycle:
+        var.cprint(header + f"{'[abs. error, last/prev]':>29}   l s\n", 3)
+
+    if var.sslsolver:
+        krylov(vmodel, sfield, efield, var)
+    elif var.cycle:
+        multigrid(vmodel, sfield, efield, var)
+
+    exit_status = int(var.exit_message != 'CONVERGED')
+
+    if var.verb in [1, 2]:
+        _print_one_liner(var, var.l2, True)
+    elif var.verb > 2:
+        if var.sslsolver:
+            info = f"   > Solver steps     : {var.ssl_it}\n"
+            if var.cycle:
+                info += f"   > MG prec. steps   : {var.it}\n"
+        elif var.cycle:
+            info = f"   > MG cycles        : {var.it}\n"
+        info += f"   > Final rel. error : {var.l2/var.l2_refe:.3e}\n\n"
+        info += f":: emg3d END   :: {var.time.now} :: "
+        info += f"runtime = {var.time.runtime}\n"
+        var.cprint(info, 2)
+    elif var.verb == 0 and exit_status == 1:
+        var.cprint(f"* WARNING :: {var.exit_message}", -1)
+
+    if var.return_info:
+        info_dict = {
+            'exit': exit_status,
+            'exit_message': var.exit_message,
+            'abs_error': var.l2,
+            'rel_error': var.l2 / var.l2_refe,
+            'ref_error': var.l2_refe,
+            'tol': var.tol,
+            'it_mg': var.it,
+            'it_ssl': var.ssl_it,
+            'time': var.runtime_at_cycle[-1],
+            'runtime_at_cycle': var.runtime_at_cycle,
+            'error_at_cycle': var.error_at_cycle,
+            'log': var.log_message,
+            # additions of this package (not in the reference):
+            'smoother_cell_sweeps': var.smoother_cell_sweeps,
+        }
+
+    if var.do_return and var.return_info:
+        return efield, info_dict
+    elif var.do_return:
+        return efield
+    elif var.return_info:
+        return info_dict
+
+
+def solve_source(model, source, frequency, **kwargs):
+    """``get_source_field`` + ``solve`` (emg3d/solver.py:452-467)."""
+    sfield = fields.get_source_field(model.grid, source, frequency)
+    return solve(model, sfield, **kwargs)
+
+
+# -------------------------------------------------------------------------- multigrid ---
+def _device():
+    _lib.require_gpu()
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class Hierarchy:
+    """Level 0 on the device for one (model, frequency): upload once, cycle many times."""
+
+    def __init__(self, vmodel, device=None):
+        self.device = device or _device()
+        self.top = DeviceLevel.from_host(vmodel, self.device)
+
+    def upload(self, sfield, efield):
+        self.top.s.copy_(torch.from_numpy(np.ascontiguousarray(sfield.field)), non_blocking=False)
+        self.top.e.copy_(torch.from_numpy(np.ascontiguousarray(efield.field)), non_blocking=False)
+
+    def download(self, efield):
+        efield.field[:] = self.top.e.cpu().numpy()
+
+
+def multigrid(model, sfield, efield, var, **kwargs):
+    """Multigrid solver (reference emg3d/solver.py:471-649).
+
+    ``model`` is a ``VolumeModel``; the result is stored in place in ``efield``; cycle
+    count in ``var.it``, final error in ``var.l2``. The level hierarchy lives in HBM for the
+    duration of the call; pass ``hierarchy=`` (a ``Hierarchy``) to reuse one.
+    """
+    hier = kwargs.get('hierarchy') or Hierarchy(model)
+    hier.upload(sfield, efield)
+    try:
+        _multigrid(hier.top, var, 0, 0)
+    finally:
+        hier.download(efield)
+
+
+def _smooth(lv, nu, lr_dir, var):
+    """solver.smoothing on a device level (emg3d/solver.py:788-846)."""
+    c = _current_lr_dir(lr_dir, lv.grid)
+    if c == 0:
+        lv.smooth(0, nu)
+    if c in (1, 5, 6, 7):
+        lv.smooth(1, nu)
+    if c in (2, 4, 6, 7):
+        lv.smooth(2, nu)
+    if c in (3, 4, 5, 7):
+        lv.smooth(3, nu)
+    ndir = {0: 1, 1: 1, 2: 1, 3: 1, 4: 2, 5: 2, 6: 2, 7: 3}[int(c)]
+    var.smoother_cell_sweeps += nu * ndir * lv.n_cells
+
+
+def _multigrid(lv, var, level, new_cycmax):
+    """Recursive cycle on device levels; mirrors emg3d/solver.py:512-649."""
+    it = 0
+    if level == var.clevel[var.sc_dir]:
+        cycmax = 1
+    elif new_cycmax == 0 or var.cycle != 'F':
+        cycmax = var.cycmax
+    else:
+        cycmax = new_cycmax
+    cyc = 0
+
+    need_norm = level == 0 or var.verb > 4
+    l2_last = lv.residual(store=False, norm=True) if need_norm else 0.0
+    l2_stag = np.ones(var.maxcycle) * l2_last
+
+    if var.first_cycle and var.verb > 3:
+        var.level_all.append(level)
+
+    if level == 0:
+        var.cprint("     it cycmax               error", 4)
+        var.cprint("      level [  dimension  ]            info\n", 4)
+        if var.verb > 4:
+            _print_gs_info(var, it, level, cycmax, lv.grid, l2_last, "initial error")
+
+    if level == 0 and var.nu_init > 0:
+        _smooth(lv, var.nu_init, var.lr_dir, var)
+        if var.verb > 4:
+            _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
+                           "initial smoothing")
+
+    while level == 0 or (level > 0 and it < cycmax):
+        l2_prev = l2_last
+        l2_stag[(it - 1) % var.maxcycle] = l2_last
+
+        if level == var.clevel[var.sc_dir]:            # (A) coarsest grid
+            _smooth(lv, var.nu_coarse, var.lr_dir, var)
+            if var.verb > 4:
+                _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
+                               "coarsest level")
+        else:                                          # (B) not yet coarsest
+            if var.nu_pre > 0:
+                _smooth(lv, var.nu_pre, var.lr_dir, var)
+                if var.verb > 4:
+                    _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
+                                   "pre-smoothing")
+            sc_dir = _current_sc_dir(var.sc_dir, lv.grid)
+            lv.residual(store=True, norm=False)
+            clv = lv.restrict_to(sc_dir)
+            _multigrid(clv, var, level + 1, cycmax - cyc)
+            lv.prolong_from(sc_dir)
+            if var.first_cycle and var.verb > 3:
+                var.level_all.append(level)
+            if var.nu_post > 0:
+                _smooth(lv, var.nu_post, var.lr_dir, var)
+                if var.verb > 4:
+                    _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
+                                   "post-smoothing")
+
+        it += 1
+        if level == 0:
+            var.it += 1
+        if level > 0:
+            cyc += 1
+        else:
+            l2_last = lv.residual(store=False, norm=True)
+            _print_cycle_info(var, l2_last, l2_prev)
+            if var.sc_cycle:
+                var.sc_dir = next(var.sc_cycle)
+            if var.lr_cycle:
+                var.lr_dir = next(var.lr_cycle)
+            if _terminate(var, l2_last, l2_stag[(it - 1) % var.maxcycle], it):
+                break
+
+    var.l2 = l2_last
+
+
+# ----------------------------------------------------------------------------- krylov ---
+def krylov(model, sfield, efield, var):
+    """Krylov subspace solver with multigrid preconditioner (emg3d/solver.py:652-784).
+
+    The Krylov iteration itself is SciPy's (host), as in the reference; operator and
+    preconditioner applications run on the device with the vectors crossing PCIe per call.
+    (A device-resident BiCGSTAB is the next step)
+    """
+    import scipy.sparse.linalg as ssl
+
+    hier = Hierarchy(model)
+    top = hier.top
+    frequency = sfield._frequency
+    grid = sfield.grid
+    zero = fields.Field(grid, dtype=sfield.field.dtype, frequency=frequency)
+
+    def amatvec(x):
+        # A x = -(0 - A x): residual with zero source (emg3d/solver.py:686-702)
+        hier.upload(zero, fields.Field(grid, np.asarray(x, dtype=sfield.field.dtype)))
+        top.residual(store=True, norm=False)
+        return -top.r.cpu().numpy()
+
+    A = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=sfield.field.dtype,
+                           matvec=amatvec)
+
+    def mg_matvec(b):
+        s = fields.Field(grid, np.asarray(b, dtype=sfield.field.dtype), frequency=frequency)
+        e = fields.Field(grid, dtype=sfield.field.dtype, frequency=frequency)
+        multigrid(model, s, e, var, hierarchy=hier)
+        return e.field
+
+    M = None
+    if var.cycle:
+        M = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=sfield.field.dtype,
+                               matvec=mg_matvec)
+
+    def callback(x):
+        var.ssl_it += 1
+        var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
+        hier.upload(sfield, fields.Field(grid, np.asarray(x, dtype=sfield.field.dtype)))
+        var.l2 = top.residual(store=False, norm=True)
+        var.error_at_cycle = np.r_[var.error_at_cycle, var.l2]
+        if var.verb > 3:
+            log = f"   [{var.time.now}]   {var.l2/var.l2_refe:.3e} "
+            log += f" after {var.ssl_it:3} {var.sslsolver}-cycles"
+            if var.ssl_it == 1 and var.it == 0 and var.cycle is not None:
+                log += "\n"
+            var.cprint(log, 3)
+        elif var.verb in [2, 3]:
+            _print_one_liner(var, var.l2)
+
+    try:
+        x, i = getattr(ssl, var.sslsolver)(
+            A=A, b=sfield.field, x0=efield.field.copy(), rtol=var.tol, maxiter=var.ssl_maxit,
+            atol=1e-30, M=M, callback=callback)
+        efield.field[:] = x
+    except _ConvergenceError:
+        i = -1
+        efield.field[:] = 0
+        var.exit_message += " (returned field is zero)"
+
+    pre = (50 * " " + "\r" if var.verb == 3 else "\n") + "   > "
+    if i < 0:
+        if var.exit_message == '':
+            var.exit_message = f"Error in {var.sslsolver} ({i})"
+        pre = "\n* ERROR   :: "
+    elif i > 0:
+        var.exit_message = "MAX. ITERATION REACHED, NOT CONVERGED"
+    else:
+        var.exit_message = "CONVERGED"
+    var.cprint(pre + var.exit_message, 2)
+
+
+# ----------------------------------------- host-object wrappers (reference signatures) ---
+def _level_for(model, sfield, efield):
+    lv = DeviceLevel.from_host(model, _device())
+    lv.s.copy_(torch.from_numpy(np.ascontiguousarray(sfield.field)))
+    if efield is not None:
+        lv.e.copy_(torch.from_numpy(np.ascontiguousarray(efield.field)))
+    return lv
+
+
+def smoothing(model, sfield, efield, nu, lr_dir):
+    """Smooth ``efield`` in place (emg3d/solver.py:788-846)."""
+    lv = _level_for(model, sfield, efield)
+
+    class _V:
+        smoother_cell_sweeps = 0
+    _smooth(lv, nu, lr_dir, _V)
+    efield.field[:] = lv.e.cpu().numpy()
+
+
+def residual(model, sfield, efield, norm=False):
+    """Residual field, or its l2-norm if ``norm`` (emg3d/solver.py:1022-1070)."""
+    lv = _level_for(model, sfield, efield)
+    if norm:
+        return lv.residual(store=False, norm=True)
+    lv.residual(store=True, norm=False)
+    return fields.Field(sfield.grid, lv.r.cpu().numpy(), frequency=sfield._frequency)
+
+
+class _CoarseModel:
+    """Coarse-grid model as returned by ``restriction`` (emg3d/solver.py:909-926)."""
+
+    def __init__(self, lv):
+        shp = lv.grid.shape_cells
+        self.case, self.grid = lv.case, lv.grid
+        get = {}
+
+        def host(t):
+            if id(t) not in get:
+                get[id(t)] = np.asfortranarray(t.cpu().numpy().reshape(shp, order='F'))
+            return get[id(t)]
+        self.eta_x, self.eta_y, self.eta_z = host(lv.eta_x), host(lv.eta_y), host(lv.eta_z)
+        self.zeta = host(lv.zeta)
+
+
+def restriction(model, sfield, residual, sc_dir):
+    """Coarse model, coarse source (restricted residual) and zero coarse field
+    (emg3d/solver.py:849-944)."""
+    lv = _level_for(model, sfield, None)
+    lv.r.copy_(torch.from_numpy(np.ascontiguousarray(residual.field)))
+    c = lv.restrict_to(sc_dir)
+    cs = fields.Field(c.grid, c.s.cpu().numpy(), frequency=sfield._frequency)
+    ce = fields.Field(c.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
+    return _CoarseModel(c), cs, ce
+
+
+def prolongation(efield, cefield, sc_dir):
+    """``efield += P cefield`` in place, PEC enforced (emg3d/solver.py:947-1019)."""
+
+    class _M:   # prolongation needs the grids only
+        pass
+    m = _M()
+    m.grid, m.case = efield.grid, 'isotropic'
+    one = np.ones(efield.grid.shape_cells, order='F')
+    m.eta_x = m.eta_y = m.eta_z = one.astype(efield.field.dtype)
+    m.zeta = one
+    lv = _level_for(m, efield, efield)
+    c = lv.child(sc_dir)['level']
+    if c.grid.shape_cells != cefield.grid.shape_cells:
+        raise ValueError("prolongation: coarse field does not match sc_dir.")
+    c.e.copy_(torch.from_numpy(np.ascontiguousarray(cefield.field)))
+    lv.prolong_from(sc_dir)
+    efield.field[:] = lv.e.cpu().numpy()
+
+
+# -------------------------------------------------------------------- MGParameters ------
+@dataclass
+class MGParameters:
+    """Multigrid solver settings and state (emg3d/solver.py:1074-1381)."""
+
+    verb: int
+    sslsolver: Union[str, bool]
+    semicoarsening: Union[int, bool]
+    linerelaxation: Union[int, bool]
+    shape_cells: tuple
+
+    cycle: Union[str, None] = 'F'
+    tol: float = 1e-6
+    maxit: int = 50
+    nu_init: int = 0
+    nu_pre: int = 2
+    nu_coarse: int = 1
+    nu_post: int = 2
+    clevel: int = -1
+    return_info: bool = False
+    log: int = 0
+
+    def __post_init__(self):
+        self.level_all = list()
+        self.first_cycle = True
+        self.it = 0
+        self.ssl_it = 0
+        self.l2 = 1.0
+        self.l2_refe = 1.0
+        self._max_level()
+
+        self.exit_message = ''
+        self.log_message = ''
+        self.time = Timer()
+        self.runtime_at_cycle = np.array([0.])
+        self.error_at_cycle = np.array([0.])
+        self.do_return = True
+        self.smoother_cell_sweeps = 0       # sum over smoother calls of nu * n_cells
+
+        self._semicoarsening()
+        self._linerelaxation()
+        self._solver_and_cycle()
+
+    def __repr__(self):
+        nc = self.shape_cells[0] * self.shape_cells[1] * self.shape_cells[2]
+        rc = self._repr_clevel
+        return (
+            f"   MG-cycle       : {self.cycle!r:17}   sslsolver : {self.sslsolver!r}\n"
+            f"   semicoarsening : {self._repr_sc_dir:17}   tol       : {self.tol}\n"
+            f"   linerelaxation : {self._repr_lr_dir:17}   maxit     : {self._repr_maxit}\n"
+            f"   nu_{{i,1,c,2}}   : {self.nu_init}, {self.nu_pre}, {self.nu_coarse}, "
+            f"{self.nu_post}          verb      : {self.verb}\n"
+            f"   Original grid  : {self.shape_cells[0]:3} x {self.shape_cells[1]:3} x "
+            f"{self.shape_cells[2]:3}     => {nc:,} cells\n"
+            f"   Coarsest grid  : {rc['shape_cells'][0]:3} x {rc['shape_cells'][1]:3} x "
+            f"{rc['shape_cells'][2]:3}     => {rc['n_cells']:,} cells\n"
+            f"   Coarsest level : {rc['clevel'][0]:3} ; {rc['clevel'][1]:3} ;"
+            f"{rc['clevel'][2]:4}   {rc['message']}\n")
+
+    def cprint(self, info, verbosity, **kwargs):
+        """Print and/or log ``info`` if ``self.verb > verbosity`` (solver.py:1181-1200)."""
+        if self.verb > verbosity:
+            if self.log != 0:
+                self.log_message += str(info) + '\n'
+            if self.log >= 0:
+                print(info, **kwargs)
+
+    def _max_level(self):
+        """Coarsening depth per semicoarsening direction (solver.py:1202-1270)."""
+        inp_clevel = np.inf if self.clevel < 0 else self.clevel
+        clevel = np.zeros(3, dtype=np.int64)
+        for i in range(3):
+            n = self.shape_cells[i]
+            while n % 2 == 0 and n > 2:
+                clevel[i] += 1
+                n /= 2
+        for i in range(3):
+            if -1 < self.clevel < clevel[i]:
+                clevel[i] = self.clevel
+        self.clevel = np.array([max(clevel), max(clevel[1], clevel[2]),
+                                max(clevel[0], clevel[2]), max(clevel[0], clevel[1])])
+
+        sx, sy, sz = (int(self.shape_cells[i] / 2 ** clevel[i]) for i in range(3))
+        self._repr_clevel = {'n_cells': sx * sy * sz, 'shape_cells': (sx, sy, sz),
+                             'clevel': clevel}
+        max_low = any(cl < inp_clevel and sl > 7 for cl, sl in zip(clevel, (sx, sy, sz)))
+        min_div = any(clevel < min(inp_clevel, 3))
+        self._repr_clevel['message'] = (
+            "  :: Grid not optimal for MG solver ::" if max_low or min_div else "")
+
+        if np.any(np.array(self.shape_cells) < 2):
+            raise ValueError(
+                "Nr. of cells must be at least two in each direction "
+                f"Provided shape: ({self.shape_cells[0]}, {self.shape_cells[1]}, "
+                f"{self.shape_cells[2]}).")
+
+    @staticmethod
+    def _parse_cycle(value, default, nmax, name):
+        """bool/int/multi-digit-int -> (cycle iterator or False, list of directions)."""
+        if value is True:
+            lst = np.array(default)
+            return itertools.cycle(lst), lst
+        if value in np.arange(nmax):
+            return False, np.array([int(value)])
+        lst = np.array([int(x) for x in str(abs(value))])
+        if np.any(lst < 0) or np.any(lst > nmax - 1):
+            if name == 'semicoarsening':
+                raise ValueError(
+                    "`semicoarsening` must be one of {False;True;0;1;2;3}. "
+                    "Or a combination of {0;1;2;3} to cycle, e.g. 1213. "
+                    f"Provided: {value}.")
+            raise ValueError(
+                "`linerelaxation` must be one of "
+                "{False;True;0;1;2;3;4;5;6;7}. Or a combination of "
+                "{1;2;3;4;5;6;7} to cycle, e.g. 1213. "
+                f"Provided: {value}.")
+        return itertools.cycle(lst), lst
+
+    def _semicoarsening(self):
+        """solver.py:1272-1304."""
+        self.sc_cycle, lst = self._parse_cycle(self.semicoarsening, [1, 2, 3], 4,
+                                               'semicoarsening')
+        self.sc_dir = next(self.sc_cycle) if self.sc_cycle else lst[0]
+        self.semicoarsening = self.sc_dir != 0
+        self._repr_sc_dir = f"{self.semicoarsening} {lst}"
+        self.raw_sc_cycle = lst
+
+    def _linerelaxation(self):
+        """solver.py:1306-1339."""
+        self.lr_cycle, lst = self._parse_cycle(self.linerelaxation, [4, 5, 6], 8,
+                                               'linerelaxation')
+        self.lr_dir = next(self.lr_cycle) if self.lr_cycle else lst[0]
+        self.linerelaxation = self.lr_dir != 0
+        self._repr_lr_dir = f"{self.linerelaxation} {lst}"
+        self.raw_lr_cycle = lst
+
+    def _solver_and_cycle(self):
+        """solver.py:1341-1381."""
+        solvers = ['bicgstab', 'cgs', 'gcrotmk']
+        if self.sslsolver is True:
+            self.sslsolver = 'bicgstab'
+        elif self.sslsolver is not False and self.sslsolver not in solvers:
+            raise ValueError(
+                f"`sslsolver` must be True, False, or one of {solvers}. "
+                f"Provided: {self.sslsolver!r}.")
+        if self.cycle not in ['F', 'V', 'W', None]:
+            raise ValueError(
+                "`cycle` must be one of {'F';'V';'W';None}. "
+                f"Provided: {self.cycle}.")
+        self.cycmax = 2 if self.cycle in ['F', 'W'] else 1
+        if not self.sslsolver and not self.cycle:
+            raise ValueError(
+                "At least `cycle` or `sslsolver` is required. Provided"
+                f"input: cycle={self.cycle}; sslsolver={self.sslsolver}.")
+        self.ssl_maxit = 0
+        self._repr_maxit = f"{self.maxit}"
+        self.maxcycle = max(len(self.raw_sc_cycle), len(self.raw_lr_cycle))
+        if self.sslsolver:
+            self.ssl_maxit = self.maxit
+            if self.cycle is not None:
+                self.maxit = self.maxcycle
+                self._repr_maxit += f" ({self.maxit})"
+
+
+class RegularGridProlongator:
+    """Bilinear interpolation from a coarse to a fine 2-D tensor grid with precomputed
+    weights (emg3d/solver.py:1385-1478). Host utility with the reference's call
+    signature; the device prolongation kernel uses the same 1-D tables
+    (emg3d_amd/_device.py:interp_table)."""
+
+    def __init__(self, cx, cy, x, y):
+        from emg3d_amd._device import interp_table
+        self._ix, self._wx = interp_table(np.asarray(cx, float), np.asarray(x, float))
+        self._iy, self._wy = interp_table(np.asarray(cy, float), np.asarray(y, float))
+        self.size = self._ix.size * self._iy.size
+
+    def __call__(self, values):
+        ix, iy = self._ix[:, None], self._iy[None, :]
+        wx, wy = self._wx[:, None], self._wy[None, :]
+        out = (values[ix, iy] * ((1 - wx) * (1 - wy)) + values[ix, iy + 1] * ((1 - wx) * wy) +
+               values[ix + 1, iy] * (wx * (1 - wy)) + values[ix + 1, iy + 1] * (wx * wy))
+        return out.ravel('F')
+
+
+# --------------------------------------------------------------------------- helpers ---
+def _current_sc_dir(sc_dir, grid):
+    """Semicoarsening code for this grid (emg3d/solver.py:1482-1531): a direction is
+    coarsened only if its cell count is even, > 2, and it is not the sc direction."""
+    n = grid.shape_cells
+    keep_x = n[0] % 2 != 0 or n[0] < 3 or sc_dir == 1
+    keep_y = n[1] % 2 != 0 or n[1] < 3 or sc_dir == 2
+    keep_z = n[2] % 2 != 0 or n[2] < 3 or sc_dir == 3
+    return {(False, False, False): 0, (True, False, False): 1, (False, True, False): 2,
+            (False, False, True): 3, (False, True, True): 4, (True, False, True): 5,
+            (True, True, False): 6, (True, True, True): 6}[(keep_x, keep_y, keep_z)]
+
+
+def _current_lr_dir(lr_dir, grid):
+    """Drop line relaxation along directions with only two cells
+    (emg3d/solver.py:1534-1588)."""
+    c = int(lr_dir)
+    n = grid.shape_cells
+    if n[0] == 2:
+        c = {1: 0, 5: 3, 6: 2, 7: 4}.get(c, c)
+    if n[1] == 2:
+        c = {2: 0, 4: 3, 6: 1, 7: 5}.get(c, c)
+    if n[2] == 2:
+        c = {3: 0, 4: 2, 5: 1, 7: 6}.get(c, c)
+    return c
+
+
+def _terminate(var, l2_last, l2_stag, it):
+    """Termination criteria of a multigrid cycle (emg3d/solver.py:1591-1664)."""
+    finished = False
+    sslabort = False
+    if l2_last < var.tol * var.l2_refe:
+        var.exit_message = "CONVERGED"
+        finished = True
+    elif l2_last > 10 * var.l2_refe or not np.isfinite(l2_last):
+        var.exit_message = "DIVERGED"
+        finished = True
+        sslabort = True
+    elif it > 2 and l2_last >= l2_stag:
+        var.exit_message = "STAGNATED"
+        finished = True
+        sslabort = True
+    elif it == var.maxit:
+        if not var.sslsolver:
+            var.exit_message = "MAX. ITERATION REACHED, NOT CONVERGED"
+        finished = True
+
+    if finished:
+        if var.sslsolver and sslabort:
+            raise _ConvergenceError
+        elif not var.sslsolver:
+            add = 50 * " " + "\r" if var.verb == 3 else ("\n" if var.verb < 5 else "")
+            var.cprint(add + "   > " + var.exit_message, 2)
+    return finished
+
+
+def _restrict_model_parameters(param, sc_dir):
+    """Sum of the 2/4/8 fine cells (emg3d/solver.py:1667-1718), on the device."""
+    from emg3d_amd._device import _ptr, _stream, coarsen_flags
+    _lib.require_gpu()
+    dev = _device()
+    p = np.asfortranarray(param)
+    cplx = int(np.iscomplexobj(p))
+    nx, ny, nz = p.shape
+    cx, cy, cz = coarsen_flags(sc_dir)
+    cshape = (nx // (2 if cx else 1), ny // (2 if cy else 1), nz // (2 if cz else 1))
+    tin = torch.from_numpy(p.ravel('F').copy()).to(dev)
+    tout = torch.empty(int(np.prod(cshape)), dtype=tin.dtype, device=dev)
+    _lib.check(_lib.lib().emg3d_dev_restrict_param(_ptr(tout), _ptr(tin), nx, ny, nz, sc_dir,
+                                                   cplx, _stream()), 'emg3d_dev_restrict_param')
+    return np.asfortranarray(tout.cpu().numpy().reshape(cshape, order='F'))
+
+
+def _get_restriction_weights(grid, cgrid, sc_dir):
+    """(wx, wy, wz), each (wl, w0, wr); dummies for non-coarsened directions
+    (emg3d/solver.py:1721-1780)."""
+    from emg3d_amd import core
+    out = []
+    for d, skip in enumerate(([1, 5, 6], [2, 4, 6], [3, 4, 5])):
+        if sc_dir not in skip:
+            nodes = (grid.nodes_x, grid.nodes_y, grid.nodes_z)[d]
+            cc = (grid.cell_centers_x, grid.cell_centers_y, grid.cell_centers_z)[d]
+            cnodes = (cgrid.nodes_x, cgrid.nodes_y, cgrid.nodes_z)[d]
+            ccc = (cgrid.cell_centers_x, cgrid.cell_centers_y, cgrid.cell_centers_z)[d]
+            out.append(core.restrict_weights(nodes, cc, grid.h[d], cnodes, ccc, cgrid.h[d]))
+        else:
+            z = np.zeros(grid.shape_nodes[d], dtype=np.float64)
+            out.append((z, np.ones(grid.shape_nodes[d], dtype=np.float64), z))
+    return tuple(out)
+
+
+class _ConvergenceError(Exception):
+    """Raised inside ``_terminate`` to abort a SciPy Krylov solver."""
+
+
+def _print_cycle_info(var, l2_last, l2_prev):
+    """Per-cycle bookkeeping and log line (emg3d/solver.py:1788-1862; the ASCII picture
+    of the first cycle is not reproduced)."""
+    var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
+    var.error_at_cycle = np.r_[var.error_at_cycle, l2_last]
+    if var.verb in [2, 3]:
+        _print_one_liner(var, l2_last)
+    if var.verb < 4:
+        return
+    info = "\n" if var.verb > 4 else ""
+    var.first_cycle = False
+    info += f"   [{var.time.now}]   {l2_last/var.l2_refe:.3e}  "
+    if var.sslsolver:
+        info += f"after {19*' '} {var.it:3} {var.cycle}-cycles "
+    else:
+        info += f"after {var.it:3} {var.cycle}-cycles   "
+        info += f"[{l2_last:.3e}, {l2_last/l2_prev:.3f}]"
+    info += f"   {var.lr_dir} {var.sc_dir}"
+    if var.verb > 4:
+        info += "\n"
+    var.cprint(info, 3)
+
+
+def _print_gs_info(var, it, level, cycmax, grid, norm, add):
+    """Log line after a smoothing step (emg3d/solver.py:1865-1892)."""
+    info = f"     {it:2} {level} {cycmax} [{grid.shape_cells[0]:3}, "
+    info += f"{grid.shape_cells[1]:3}, {grid.shape_cells[2]:3}]: {norm:.3e} "
+    var.cprint(info + add, 4)
+
+
+def _print_one_liner(var, l2_last, last=False):
+    """Continuously updated one-liner (emg3d/solver.py:1895-1919)."""
+    info = f":: emg3d :: {l2_last/var.l2_refe:.1e}; "
+    info += f"{var.ssl_it}({var.it}); " if var.sslsolver else f"{var.it}; "
+    info += f"{var.time.runtime}"
+    if last:
+        var.cprint(info + f"; {var.exit_message}", -100)
+    else:
+        var.cprint(info, -100, end='\r')

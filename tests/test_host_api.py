@@ -1,0 +1,207 @@
+"""Host-side logic of emg3d_amd (no GPU needed): data containers, parameter handling, cycle
+control helpers, restriction weights, and that the C-ABI library loads and exports every
+symbol declared in include/emg3d_amd.h."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import emg3d_amd as emg3d
+from emg3d_amd import _lib, core, solver
+from oracle import core as ocore
+from helpers import relerr, widths
+
+
+def test_library_loads_and_exports_all_declared_symbols():
+    lib = _lib.lib()
+    assert lib.emg3d_version() == 100
+    header = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'emg3d_amd.h')).read()
+    declared = set(re.findall(r'\b(emg3d_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.emg3d_device_count() >= 0
+    # pure-arithmetic helpers of the ABI work without a device
+    assert lib.emg3d_gs_scratch_bytes(0, 8, 8, 8, 1) == 0
+    assert lib.emg3d_gs_scratch_bytes(1, 8, 6, 4, 1) == 6 * (5 * 8 - 4) * 3 * 2 * 16
+    assert lib.emg3d_residual_ws_len(64, 8, 4) == 2 * 3 * 5
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _lib.lib().emg3d_device_count() > 0:
+        pytest.skip("GPU present")
+    a = np.zeros(36)
+    with pytest.raises(_lib.Emg3dAmdError, match="no HIP device"):
+        core.solve(a, np.zeros(6))
+    grid = emg3d.TensorMesh([np.ones(4)] * 3, (0, 0, 0))
+    sfield = emg3d.get_source_field(grid, (2, 2, 2, 0, 0), 1.0)
+    with pytest.raises(_lib.Emg3dAmdError):
+        emg3d.solve(emg3d.Model(grid), sfield, sslsolver=False)
+
+
+def test_field_layout_and_views():
+    grid = emg3d.TensorMesh([np.ones(3), np.ones(4), np.ones(5)], (0, 0, 0))
+    f = emg3d.Field(grid, frequency=2.0)
+    assert f.field.dtype == np.complex128 and f.field.size == grid.n_edges
+    assert f.fx.shape == (3, 5, 6) and f.fy.shape == (4, 4, 6) and f.fz.shape == (4, 5, 5)
+    f.fx[1, 2, 3] = 7
+    assert f.field[1 + 3 * (2 + 5 * 3)] == 7          # Fortran order, x fastest
+    f.fz[3, 4, 4] = 9
+    assert f.field[-1] == 9
+    assert f.fx.flags.f_contiguous and not f.fx.flags.owndata
+    assert np.isclose(f.sval, 2j * np.pi * 2.0) and np.isclose(f.smu0, f.sval * 1.25663706127e-06)
+    lap = emg3d.Field(grid, frequency=-3.0)
+    assert lap.field.dtype == np.float64 and lap.sval == 3.0 and lap.frequency == 3.0
+    with pytest.raises(ValueError, match="must be f>0"):
+        emg3d.Field(grid, frequency=0)
+    g = f.copy()
+    assert g == f
+    g.fy[1, 1, 1] = 1e-3
+    assert g != f
+
+
+def test_source_field_and_volume_model_match_reference_fixtures(golden_solves):
+    g = golden_solves
+    for name in g['meta_cases']:
+        p = str(name) + '_'
+        grid = emg3d.TensorMesh([g[p + 'hx'], g[p + 'hy'], g[p + 'hz']], g[p + 'origin'])
+        sf = emg3d.get_source_field(grid, g[p + 'source'], float(g[p + 'frequency']))
+        assert relerr(sf.field, g[p + 'sfield']) < 1e-12
+        kw = {k: g[p + 'res_' + k[-1]] for k in ('property_x', 'property_y', 'property_z')
+              if p + 'res_' + k[-1] in g}
+        model = emg3d.Model(grid, **kw)
+        assert model.case == str(g[p + 'case'])
+        vm = emg3d.models.VolumeModel(model, sf)
+        for k in ('eta_x', 'eta_y', 'eta_z', 'zeta'):
+            assert relerr(getattr(vm, k), g[p + k]) < 1e-15
+        if model.case in ('isotropic', 'VTI'):
+            assert vm.eta_y is vm.eta_x                 # aliasing rule
+        if model.case in ('isotropic', 'HTI'):
+            assert vm.eta_z is vm.eta_x
+    with pytest.raises(ValueError, match="outside grid"):
+        emg3d.get_source_field(grid, (1e9, 0, 0, 0, 0), 1.0)
+
+
+def test_source_field_moment_and_finite_dipole():
+    grid = emg3d.TensorMesh([widths(4, 2, 10, 1.5)] * 3, (-50, -50, -50))
+    vec = emg3d.get_source_field(grid, (1.3, -2.2, 4.1, 30, 10), None)
+    d = emg3d.fields._direction(30, 10)
+    assert np.isclose(vec.fx.sum(), d[0]) and np.isclose(vec.fy.sum(), d[1])
+    assert np.isclose(vec.fz.sum(), d[2])
+    fin = emg3d.get_source_field(grid, (-20, 25, -3, -3, 7, 7), None, strength=2.0)
+    assert np.isclose(fin.fx.sum(), 90.0) and fin.fy.sum() == 0 and fin.fz.sum() == 0
+
+
+def test_restrict_weights_known_answer_and_vs_oracle():
+    edges = np.array([0., 500, 1200, 2000, 3000])
+    width = edges[1:] - edges[:-1]
+    centr = edges[:-1] + width / 2
+    c_edges = edges[::2]
+    c_width = c_edges[1:] - c_edges[:-1]
+    c_centr = c_edges[:-1] + c_width / 2
+    wl, w0, wr = core.restrict_weights(edges, centr, width, c_edges, c_centr, c_width)
+    assert np.allclose(wl, [350 / 250, 250 / 600, 400 / 900], rtol=1e-15)
+    assert np.allclose(w0, 1.0)
+    assert np.allclose(wr, [350 / 600, 500 / 900, 400 / 500], rtol=1e-15)
+    grid = emg3d.TensorMesh([widths(2, 3, 200, 1.8), [1, 1], [1, 1]], (-1e5, 0, 0))
+    cg = emg3d.TensorMesh([np.diff(grid.nodes_x[::2]), [1, 1], [1, 1]], grid.origin)
+    a = core.restrict_weights(grid.nodes_x, grid.cell_centers_x, grid.h[0], cg.nodes_x,
+                              cg.cell_centers_x, cg.h[0])
+    b = ocore.restrict_weights(grid.nodes_x, grid.cell_centers_x, grid.h[0], cg.nodes_x,
+                               cg.cell_centers_x, cg.h[0])
+    for x, y in zip(a, b):
+        assert np.allclose(x, y, rtol=1e-14, atol=0)
+
+
+def test_mgparameters():
+    """Rules of emg3d/solver.py:1202-1381 (cf. the reference's TestMGParameters)."""
+    var = solver.MGParameters(verb=0, sslsolver=False, semicoarsening=False, linerelaxation=False,
+                              shape_cells=(2 ** 3, 2 ** 5, 2 ** 4))
+    assert list(var.clevel) == [4, 4, 3, 4] and var.cycmax == 2 and var.maxcycle == 1
+    assert var.sc_dir == 0 and var.lr_dir == 0 and not var.sc_cycle and not var.lr_cycle
+    var = solver.MGParameters(verb=0, sslsolver=True, semicoarsening=True, linerelaxation=True,
+                              shape_cells=(20, 20, 20), cycle='V', maxit=33)
+    assert var.sslsolver == 'bicgstab' and var.ssl_maxit == 33 and var.maxit == 3
+    assert var.cycmax == 1 and var.sc_dir == 1 and var.lr_dir == 4
+    assert [next(var.sc_cycle) for _ in range(4)] == [2, 3, 1, 2]
+    assert [next(var.lr_cycle) for _ in range(4)] == [5, 6, 4, 5]
+    assert list(var.clevel) == [2, 2, 2, 2]        # 20 -> 10 -> 5 (odd)
+    assert 'not optimal' in var._repr_clevel['message']
+    var = solver.MGParameters(verb=0, sslsolver=False, semicoarsening=1213, linerelaxation=7,
+                              shape_cells=(16, 16, 16), clevel=2)
+    assert var.sc_dir == 1 and var.maxcycle == 4 and list(var.clevel) == [2, 2, 2, 2]
+    assert [next(var.sc_cycle) for _ in range(4)] == [2, 1, 3, 1]
+    for bad in (dict(semicoarsening=5), dict(linerelaxation=9), dict(sslsolver='cg'),
+                dict(cycle='G'), dict(cycle=None, sslsolver=False)):
+        kw = dict(verb=0, sslsolver=False, semicoarsening=False, linerelaxation=False,
+                  shape_cells=(8, 8, 8))
+        kw.update(bad)
+        with pytest.raises(ValueError):
+            solver.MGParameters(**kw)
+    with pytest.raises(ValueError, match="at least two"):
+        solver.MGParameters(verb=0, sslsolver=False, semicoarsening=False, linerelaxation=False,
+                            shape_cells=(1, 8, 8))
+    assert 'MG-cycle' in repr(var) and 'Coarsest grid' in repr(var)
+
+
+def test_current_sc_and_lr_dir():
+    """emg3d/solver.py:1482-1588 (cf. reference tests test_current_sc_dir/_lr_dir)."""
+    mk = lambda n: emg3d.TensorMesh([np.ones(n[0]), np.ones(n[1]), np.ones(n[2])], (0, 0, 0))
+    g = mk((4, 2, 2))
+    assert [solver._current_sc_dir(s, g) for s in range(4)] == [4, 6, 4, 4]
+    g = mk((4, 4, 4))
+    assert [solver._current_sc_dir(s, g) for s in range(4)] == [0, 1, 2, 3]
+    g = mk((4, 4, 2))
+    assert [solver._current_sc_dir(s, g) for s in range(4)] == [3, 5, 4, 3]
+    g = mk((3, 4, 8))
+    assert [solver._current_sc_dir(s, g) for s in range(4)] == [1, 1, 6, 5]
+    g = mk((4, 4, 4))
+    assert [solver._current_lr_dir(c, g) for c in range(8)] == list(range(8))
+    g = mk((2, 4, 4))
+    assert [solver._current_lr_dir(c, g) for c in range(8)] == [0, 0, 2, 3, 4, 3, 2, 4]
+    g = mk((4, 2, 4))
+    assert [solver._current_lr_dir(c, g) for c in range(8)] == [0, 1, 0, 3, 3, 5, 1, 5]
+    g = mk((4, 4, 2))
+    assert [solver._current_lr_dir(c, g) for c in range(8)] == [0, 1, 2, 0, 2, 1, 6, 6]
+    g = mk((2, 2, 4))
+    assert solver._current_lr_dir(7, g) == 3 and solver._current_lr_dir(6, g) == 0
+
+
+def test_terminate():
+    """emg3d/solver.py:1591-1664 (cf. reference test_terminate)."""
+    class V:
+        tol, l2_refe, sslsolver, maxit, verb, exit_message = 1e-3, 1e-3, False, 5, 0, ''
+
+        def cprint(self, *a, **k):
+            pass
+    v = V()
+    assert solver._terminate(v, 1e-7, 1, 1) and v.exit_message == 'CONVERGED'
+    assert solver._terminate(v, np.inf, 1, 1) and v.exit_message == 'DIVERGED'
+    assert solver._terminate(v, 1e-1, 1, 1) and v.exit_message == 'DIVERGED'
+    assert solver._terminate(v, 1e-5, 1e-6, 3) and v.exit_message == 'STAGNATED'
+    assert not solver._terminate(v, 1e-5, 1e-6, 2)
+    assert solver._terminate(v, 1e-5, 1e-4, 5) and v.exit_message.startswith('MAX. ITERATION')
+    v.sslsolver = True
+    with pytest.raises(solver._ConvergenceError):
+        solver._terminate(v, np.nan, 1, 1)
+
+
+def test_regular_grid_prolongator_vs_scipy():
+    import scipy.interpolate as si
+    cx, cy = np.array([0., 1, 3, 7]), np.array([-2., 0, 5])
+    x, y = np.array([0., .5, 1, 2, 3, 5, 7]), np.array([-2., -1, 0, 2.5, 5])
+    vals = np.arange(12.).reshape(4, 3) ** 1.5
+    fn = solver.RegularGridProlongator(cx, cy, x, y)
+    ref = si.RegularGridInterpolator((cx, cy), vals, bounds_error=False, fill_value=None)
+    X, Y = np.meshgrid(x, y, indexing='ij')
+    assert np.allclose(fn(vals).reshape(7, 5, order='F'), ref((X, Y)), rtol=1e-14)
+
+
+def test_get_restriction_weights_shapes():
+    grid = emg3d.TensorMesh([widths(2, 1, 10, 1.5), widths(4, 2, 10, 1.2), np.ones(2)], (0, 0, 0))
+    cg = emg3d.TensorMesh([np.diff(grid.nodes_x[::2]), grid.h[1], grid.h[2]], grid.origin)
+    wx, wy, wz = solver._get_restriction_weights(grid, cg, 4)
+    assert wx[0].size == cg.shape_nodes[0]
+    assert wy[0].size == grid.shape_nodes[1] and np.all(wy[0] == 0) and np.all(wy[1] == 1)
+    assert wz[1].size == grid.shape_nodes[2]
