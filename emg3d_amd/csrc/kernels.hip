@@ -185,7 +185,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, void *scratch, size_t scrat
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;   // first sweep backward (reference emg3d/core.py:301,311)
         for (int cc = 0; cc < 4; ++cc) {
-            const int c = iback ? 3 - cc : cc;
+            const int c = emg::sweep_colour(iback, cc);
             if (lr == 0) {
                 const emg::Dim3 g = emg::gs_point_grid(nx, ny, nz);
                 if (g.x > 0 && g.y > 0 && g.z > 0)

@@ -15,6 +15,17 @@ inline int cnt_par(int n, int par) { return par ? n / 2 : (n - 1) / 2; }
 // first integer >= 1 with parity par
 EMG_HD int first_par(int par) { return par ? 1 : 2; }
 
+// Colour class visited at position cc (0..3) of a sweep. A forward sweep visits the classes
+// in the sequence 0,2,3,1, a backward sweep in the reverse; the first sweep of a smoother
+// call is backward, like the reference's (emg3d/core.py:301,311). Of the distinct
+// sequences this one gives the best multigrid convergence factor (measured with the
+// oracle: 0.128 vs 0.156 for 0,1,2,3 on the point smoother; lexicographic 0.088).
+inline int sweep_colour(int iback, int cc)
+{
+    const int seq[4] = {0, 2, 3, 1};
+    return seq[iback ? 3 - cc : cc];
+}
+
 // ---- point smoother: colour = ((ix+iz)&1) | (((iy+iz)&1)<<1); global thread (gx,gy,gz) --
 inline Dim3 gs_point_block() { return Dim3{64, 4, 1}; }
 inline Dim3 gs_point_grid(int nx, int ny, int nz)

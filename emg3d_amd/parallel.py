@@ -1,0 +1,187 @@
+"""Sharding of independent (source, frequency) solves over the GPUs of one node.
+
+The reference parallelises exclusively over source-frequency pairs with a process pool
+(reference emg3d/_multiprocessing.py:33-153, emg3d/simulations.py:835-880, 1453-1464): one
+pair = one complete ``solve``; nothing is exchanged inside a solve. The MI355X equivalent:
+
+* one process per GPU (``python -m torch.distributed.run --nproc-per-node 8 ...``);
+* the model's property arrays are broadcast ONCE from rank 0 (RCCL over xGMI on GPUs; gloo
+  on CPU for the tests); every rank builds eta(f), zeta and its sources locally;
+* pairs are assigned statically (longest-processing-time first when costs are known,
+  round-robin otherwise); each rank runs its pairs one after the other on its GPU;
+* small per-pair results (info dicts, receiver responses) are gathered on request; the
+  fields stay where they were computed.
+
+There is no collective inside a solve and no all-reduce on the forward path.
+"""
+import itertools
+import os
+
+import numpy as np
+
+__all__ = ['init', 'finalize', 'srcfreq_pairs', 'shard', 'broadcast_model', 'solve',
+           'compute', 'gather_objects']
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def init(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    (as set by torch.distributed.run). Returns (rank, world, device).
+
+    backend: 'nccl' (= RCCL on ROCm) when a GPU is visible, else 'gloo'."""
+    import torch
+    dist = _dist()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    use_gpu = torch.cuda.is_available()
+    if backend is None:
+        backend = 'nccl' if use_gpu else 'gloo'
+    device = torch.device('cpu')
+    if use_gpu and backend == 'nccl':
+        local = int(os.environ.get('LOCAL_RANK', rank % max(torch.cuda.device_count(), 1)))
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29512')
+        kw = {'device_id': device} if device.type == 'cuda' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def finalize():
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def srcfreq_pairs(sources, frequencies):
+    """All (source, frequency) keys in the reference's order: product(sources, frequencies)
+    (emg3d/simulations.py:1453-1464)."""
+    return list(itertools.product(list(sources), list(frequencies)))
+
+
+def shard(n_items, rank, world, costs=None):
+    """Indices of the items rank `rank` computes.
+
+    Without costs: round-robin (item i -> rank i % world). With costs: longest-processing
+    -time-first greedy assignment, deterministic and identical on every rank."""
+    if costs is None:
+        return list(range(rank, n_items, world))
+    order = sorted(range(n_items), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    mine = []
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += float(costs[i])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def _bcast_tensor(t, src, device):
+    dist = _dist()
+    t = t.to(device)
+    dist.broadcast(t, src)
+    return t
+
+
+def broadcast_model(model, src=0, device=None):
+    """Make rank `src`'s ``Model`` available on every rank.
+
+    Metadata (grid widths, origin, mapping, which properties exist) goes as one small
+    pickled object; each property array (float64, nx*ny*nz) is ONE broadcast of the raw
+    buffer. `model` may be None on ranks != src."""
+    import torch
+    from emg3d_amd import meshes, models
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    rank = dist.get_rank()
+    device = device or torch.device('cpu')
+    names = ('property_x', 'property_y', 'property_z', 'mu_r', 'epsilon_r')
+    meta = [None]
+    if rank == src:
+        meta = [{'h': [h.copy() for h in model.grid.h], 'origin': model.grid.origin.copy(),
+                 'mapping': model.mapping,
+                 'present': [getattr(model, n) is not None for n in names]}]
+    dist.broadcast_object_list(meta, src)
+    meta = meta[0]
+    grid = model.grid if rank == src else meshes.TensorMesh(meta['h'], meta['origin'])
+    kw = {}
+    for n, present in zip(names, meta['present']):
+        if not present:
+            continue
+        if rank == src:
+            t = torch.from_numpy(np.ascontiguousarray(getattr(model, n).ravel('F')))
+        else:
+            t = torch.empty(grid.n_cells, dtype=torch.float64)
+        t = _bcast_tensor(t, src, device)
+        kw[n] = t.cpu().numpy().reshape(grid.shape_cells, order='F')
+    if rank == src:
+        return model
+    return models.Model(grid, mapping=meta['mapping'], **kw)
+
+
+def solve(inp):
+    """Worker: one source-frequency pair, the contract of the reference's
+    ``_multiprocessing.solve`` (emg3d/_multiprocessing.py:72-153). ``inp`` has the keys
+    [model, sfield, efield, solver_opts] or [model, grid, source, frequency, efield,
+    solver_opts]; always returns (efield, info_dict)."""
+    from emg3d_amd import fields, solver
+    opts = dict(inp['solver_opts'])
+    if 'sfield' in inp:
+        sfield = inp['sfield']
+        grid = sfield.grid
+    else:
+        grid = inp['grid']
+        sfield = fields.get_source_field(grid, inp['source'], inp['frequency'])
+    model = inp['model'].interpolate_to_grid(grid)
+    return solver.solve(model=model, sfield=sfield, efield=inp.get('efield'),
+                        return_info=True, always_return=True, **opts)
+
+
+def gather_objects(obj, dst=0):
+    """Gather one small picklable object per rank on `dst` (list there, None elsewhere)."""
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(obj, out, dst)
+    return out
+
+
+def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, solve_fn=None,
+            keep_fields=True):
+    """Solve all source-frequency pairs, sharded over the ranks of the process group.
+
+    model: on rank 0 (None elsewhere is fine; it is broadcast). sources: dict name ->
+    source coordinates; frequencies: dict name -> Hz. Returns, on every rank, a dict
+    {(src, freq): (efield or None, info)} for the pairs THIS rank computed; rank 0
+    additionally gets key '_all_info': {(src, freq): info} gathered from all ranks.
+    """
+    rank, world, device = init()
+    model = broadcast_model(model, 0, device)
+    pairs = srcfreq_pairs(sources, frequencies)
+    mine = shard(len(pairs), rank, world, costs)
+    solve_fn = solve_fn or solve
+    out = {}
+    for i in mine:
+        s, f = pairs[i]
+        inp = {'model': model, 'grid': grid or model.grid, 'source': sources[s],
+               'frequency': frequencies[f], 'efield': None, 'solver_opts': solver_opts or {}}
+        efield, info = solve_fn(inp)
+        out[(s, f)] = (efield if keep_fields else None, info)
+    small = {k: {kk: vv for kk, vv in v[1].items() if kk not in ('log',)} for k, v in out.items()}
+    gathered = gather_objects(small, 0)
+    if rank == 0:
+        allinfo = {}
+        for d in gathered:
+            allinfo.update(d)
+        out['_all_info'] = allinfo
+    return out

@@ -321,6 +321,10 @@ def _multigrid(lv, var, level, new_cycmax):
                 var.sc_dir = next(var.sc_cycle)
             if var.lr_cycle:
                 var.lr_dir = next(var.lr_cycle)
+            if getattr(var, 'fixed_cycles', None):     # benchmarking: exactly n cycles
+                if it >= var.fixed_cycles:
+                    break
+                continue
             if _terminate(var, l2_last, l2_stag[(it - 1) % var.maxcycle], it):
                 break
 

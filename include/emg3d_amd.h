@@ -26,9 +26,13 @@
  *     emg3d_amd code; emg3d_last_error() gives the message. Numerical failure (zero
  *     pivot -> inf/nan) is NOT an error here, exactly as in the reference
  *     (emg3d/core.py:1560,1576); it surfaces through the residual norm.
- *   - Smoother ordering: four-colour ordering; the first sweep of
- *     a call is "backward" (colours 3,2,1,0), the second "forward" (0,1,2,3), ...,
- *     mirroring the reference's backward-first alternation (emg3d/core.py:301,311).
+ *   - Smoother ordering: four-colour ordering. A "forward" sweep
+ *     visits the colour classes in the sequence 0,2,3,1, a "backward" sweep in the
+ *     reverse; the first sweep of a call is backward, the second forward, ..., mirroring
+ *     the reference's backward-first alternation (emg3d/core.py:301,311).
+ *     point:  colour = ((ix+iz)&1) | (((iy+iz)&1)<<1);
+ *     lines:  colour = (p&1) | ((q&1)<<1), (p,q) the transverse node indices in memory
+ *             order: x-lines (iy,iz), y-lines (ix,iz), z-lines (ix,iy).
  */
 #ifndef EMG3D_AMD_H
 #define EMG3D_AMD_H

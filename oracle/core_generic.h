@@ -20,8 +20,9 @@
  *      point:  colour = ((ix+iz)&1) | (((iy+iz)&1)<<1)
  *      lines:  colour = (a&1) | ((b&1)<<1), (a,b) the two transverse node indices
  *              x-line: (iy,iz); y-line: (ix,iz); z-line: (ix,iy)
- *      forward sweep visits colours 0,1,2,3, backward sweep 3,2,1,0; inside a
- *      colour the nodes/lines are independent, so any order gives the same result.
+ *      forward sweep visits colours 0,2,3,1 (oracle_colour_order), backward sweep the
+ *      reverse; inside a colour the nodes/lines are independent, so any order gives
+ *      the same result.
  */
 
 #define EX(a, i, j, k) (a)[(size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)(ny + 1) * (size_t)(k))]
@@ -349,7 +350,7 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
             }
         } else {
             for (cc = 0; cc < 4; cc++) {
-                c = iback ? 3 - cc : cc;
+                c = oracle_colour_order[iback ? 3 - cc : cc];
                 for (izh = 1; izh < nz; izh++)
                     for (iyh = 1; iyh < ny; iyh++)
                         for (ixh = 1; ixh < nx; ixh++)
@@ -493,7 +494,7 @@ void FN(gauss_seidel_x)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
             }
         } else {
             for (cc = 0; cc < 4; cc++) {
-                c = iback ? 3 - cc : cc;
+                c = oracle_colour_order[iback ? 3 - cc : cc];
                 for (izh = 1; izh < nz; izh++)
                     for (iyh = 1; iyh < ny; iyh++)
                         if (((iyh & 1) | ((izh & 1) << 1)) == c)
@@ -638,7 +639,7 @@ void FN(gauss_seidel_y)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
             }
         } else {
             for (cc = 0; cc < 4; cc++) {
-                c = iback ? 3 - cc : cc;
+                c = oracle_colour_order[iback ? 3 - cc : cc];
                 for (izh = 1; izh < nz; izh++)
                     for (ixh = 1; ixh < nx; ixh++)
                         if (((ixh & 1) | ((izh & 1) << 1)) == c)
@@ -782,7 +783,7 @@ void FN(gauss_seidel_z)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
             }
         } else {
             for (cc = 0; cc < 4; cc++) {
-                c = iback ? 3 - cc : cc;
+                c = oracle_colour_order[iback ? 3 - cc : cc];
                 for (iyh = 1; iyh < ny; iyh++)
                     for (ixh = 1; ixh < nx; ixh++)
                         if (((ixh & 1) | ((iyh & 1) << 1)) == c)

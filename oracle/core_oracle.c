@@ -16,6 +16,17 @@
 #include <stdlib.h>
 #include <stddef.h>
 
+/* Sequence in which a FORWARD four-colour sweep visits the colour classes (backward =
+ * reversed). Default 0,2,3,1 = the order of the HIP kernels (emg3d_amd/csrc/launch.h; chosen
+ * because it converges fastest of the 4!/4 distinct sequences); settable for
+ * experiments. */
+int oracle_colour_order[4] = {0, 2, 3, 1};
+void oracle_set_colour_order(int a, int b, int c, int d)
+{
+    oracle_colour_order[0] = a; oracle_colour_order[1] = b;
+    oracle_colour_order[2] = c; oracle_colour_order[3] = d;
+}
+
 #define PASTE_(a, b) a##b
 #define PASTE(a, b) PASTE_(a, b)
 

@@ -316,6 +316,10 @@ class Params:
         return itertools.cycle(lst), lst
 
 
+# number of smoother kernel calls per smoothing() for a (current) lr_dir
+NDIR = {0: 1, 1: 1, 2: 1, 3: 1, 4: 2, 5: 2, 6: 2, 7: 3}
+
+
 def terminate(var, l2_last, l2_stag, it):
     """solver.py:1591-1664 (stand-alone multigrid branch)."""
     if l2_last < var.tol * var.l2_refe:
@@ -347,28 +351,28 @@ def multigrid(model, sfield, efield, var, level=0, new_cycmax=0):
         l2_last = residual(model, sfield, efield, True)
         l2_stag = np.ones(var.maxcycle) * l2_last
         if var.nu_init > 0:
-            smoothing(model, sfield, efield, var.nu_init, var.lr_dir, var.order)
-            var.smooth_work += var.nu_init * ncell
+            c = smoothing(model, sfield, efield, var.nu_init, var.lr_dir, var.order)
+            var.smooth_work += var.nu_init * ncell * NDIR[c]
 
     while level == 0 or it < cycmax:
         if level == 0:
             l2_prev = l2_last  # noqa: F841
             l2_stag[(it - 1) % var.maxcycle] = l2_last
         if level == var.clevel[var.sc_dir]:
-            smoothing(model, sfield, efield, var.nu_coarse, var.lr_dir, var.order)
-            var.smooth_work += var.nu_coarse * ncell
+            c = smoothing(model, sfield, efield, var.nu_coarse, var.lr_dir, var.order)
+            var.smooth_work += var.nu_coarse * ncell * NDIR[c]
         else:
             if var.nu_pre > 0:
-                smoothing(model, sfield, efield, var.nu_pre, var.lr_dir, var.order)
-                var.smooth_work += var.nu_pre * ncell
+                c = smoothing(model, sfield, efield, var.nu_pre, var.lr_dir, var.order)
+                var.smooth_work += var.nu_pre * ncell * NDIR[c]
             sc_dir = current_sc_dir(var.sc_dir, model.grid)
             res = residual(model, sfield, efield)
             cmodel, csfield, cefield = restriction(model, sfield, res, sc_dir)
             multigrid(cmodel, csfield, cefield, var, level + 1, cycmax - cyc)
             prolongation(efield, cefield, sc_dir)
             if var.nu_post > 0:
-                smoothing(model, sfield, efield, var.nu_post, var.lr_dir, var.order)
-                var.smooth_work += var.nu_post * ncell
+                c = smoothing(model, sfield, efield, var.nu_post, var.lr_dir, var.order)
+                var.smooth_work += var.nu_post * ncell * NDIR[c]
         it += 1
         if level == 0:
             var.it += 1

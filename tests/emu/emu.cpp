@@ -57,7 +57,7 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;
         for (int cc = 0; cc < 4; ++cc) {
-            const int c = iback ? 3 - cc : cc;
+            const int c = emg::sweep_colour(iback, cc);
             if (lr == 0) {
                 for_threads(emg::gs_point_grid(nx, ny, nz), emg::gs_point_block(),
                             [&](int gx, int gy, int gz) { emg::gs_point_thread<T>(L, c, gx, gy, gz); });
