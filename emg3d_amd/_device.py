@@ -87,6 +87,7 @@ class DeviceLevel:
         self.s = torch.zeros(n, dtype=dtype, device=device)
         self._r = None
         self.children = {}
+        self._factors = {}
         self.n_cells = grid.n_cells
         self._o1, self._o2 = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y
         nx, ny, nz = grid.shape_cells
@@ -129,14 +130,34 @@ class DeviceLevel:
         return _ptr(t), _ptr(t, self._o1), _ptr(t, self._o2)
 
     # ------------------------------------------------------------------- kernels ------
+    def line_factors(self, lr):
+        """Block factorisation of all lines of direction lr (1/2/3), built on first use
+        and kept for the lifetime of the level (the model does not change in a solve)."""
+        if lr not in self._factors:
+            lib = _lib.lib()
+            nx, ny, nz = self.grid.shape_cells
+            fac = torch.empty(lib.emg3d_line_fac_bytes(lr, nx, ny, nz, self.is_complex),
+                              dtype=torch.uint8, device=self.device)
+            lfac = torch.empty(lib.emg3d_line_lfac_bytes(lr, nx, ny, nz), dtype=torch.uint8,
+                               device=self.device)
+            _lib.check(lib.emg3d_dev_line_setup(self._cref, lr, _ptr(fac), _ptr(lfac), _stream()),
+                       'emg3d_dev_line_setup')
+            self._factors[lr] = (fac, lfac)
+        return self._factors[lr]
+
     def smooth(self, lr, nu):
         """nu sweeps of smoother lr (0 point, 1/2/3 x/y/z line) on (e, s)."""
         lib = _lib.lib()
         nx, ny, nz = self.grid.shape_cells
-        nbytes = lib.emg3d_gs_scratch_bytes(lr, nx, ny, nz, self.is_complex)
-        self.work.need_gs(nbytes)
-        scr = _ptr(self.work.gs_scratch) if nbytes else None
-        _lib.check(lib.emg3d_dev_gauss_seidel(self._cref, lr, nu, scr, nbytes, _stream()),
+        fac = lfac = scr = None
+        nbytes = 0
+        if lr:
+            f, lf = self.line_factors(lr)
+            fac, lfac = _ptr(f), _ptr(lf)
+            nbytes = lib.emg3d_gs_scratch_bytes(lr, nx, ny, nz, self.is_complex)
+            self.work.need_gs(nbytes)
+            scr = _ptr(self.work.gs_scratch)
+        _lib.check(lib.emg3d_dev_gauss_seidel(self._cref, lr, nu, fac, lfac, scr, nbytes, _stream()),
                    'emg3d_dev_gauss_seidel')
 
     def residual(self, store=True, norm=False):

@@ -53,13 +53,18 @@ SIGNATURES = {
     'emg3d_version': (_ci, []),
     'emg3d_last_error': (ctypes.c_char_p, []),
     'emg3d_device_count': (_ci, []),
+    'emg3d_set_option': (_ci, [ctypes.c_char_p, _ci]),
+    'emg3d_get_option': (_ci, [ctypes.c_char_p]),
     'emg3d_core_amat_x': (_ci, [_vp] * 13 + [_ci] * 4),
     'emg3d_core_gauss_seidel': (_ci, [_ci] + [_vp] * 13 + [_ci] * 5),
     'emg3d_core_restrict': (_ci, [_vp] * 15 + [_ci] * 5),
     'emg3d_core_blocks_to_amat': (_ci, [_vp] * 5 + [_ci] * 4),
     'emg3d_core_solve': (_ci, [_vp, _vp, _ci, _ci]),
     'emg3d_gs_scratch_bytes': (_sz, [_ci] * 5),
-    'emg3d_dev_gauss_seidel': (_ci, [ctypes.POINTER(Level), _ci, _ci, _vp, _sz, _vp]),
+    'emg3d_line_fac_bytes': (_sz, [_ci] * 5),
+    'emg3d_line_lfac_bytes': (_sz, [_ci] * 4),
+    'emg3d_dev_line_setup': (_ci, [ctypes.POINTER(Level), _ci, _vp, _vp, _vp]),
+    'emg3d_dev_gauss_seidel': (_ci, [ctypes.POINTER(Level), _ci, _ci, _vp, _vp, _vp, _sz, _vp]),
     'emg3d_residual_ws_len': (_sz, [_ci] * 3),
     'emg3d_dev_residual': (_ci, [ctypes.POINTER(Level), _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'emg3d_dev_restrict': (_ci, [_vp] * 15 + [_ci] * 5 + [_vp]),

@@ -57,25 +57,60 @@ using emg::ScDirs;
 
 inline dim3 d3(emg::Dim3 d) { return dim3(d.x, d.y, d.z); }
 
+// Plane-slab thickness of the point smoother's launch schedule (launch.h:
+// gs_point_schedule). 0 = plain four launches per sweep. Tunable at run time through
+// emg3d_set_option("point_slab", T); the result does not depend on it.
+int g_point_slab = 0;
+
 // ----------------------------------------------------------------------------- kernels --
 
 // Point smoother, one colour. colour = ((ix+iz)&1) | (((iy+iz)&1)<<1).
 template <class T>
-__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, int colour)
+__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, int colour, int iz0)
 {
-    emg::gs_point_thread<T>(L, colour, blockIdx.x * blockDim.x + threadIdx.x,
+    emg::gs_point_thread<T>(L, colour, iz0, blockIdx.x * blockDim.x + threadIdx.x,
                             blockIdx.y * blockDim.y + threadIdx.y, blockIdx.z);
 }
 
-// Line smoother along DIR, one colour; one thread per line. (p,q) are the two transverse
-// PHYSICAL node indices in memory order (p faster): DIR 0 -> (iy,iz), 1 -> (ix,iz),
-// 2 -> (ix,iy). colour = (p&1) | ((q&1)<<1).
+// Line smoothers (stencil.h: line_setup / line_rhs / line_forward / line_backward /
+// line_scatter); thread mappings in launch.h.
 template <class T, int DIR>
-__global__ __launch_bounds__(64) void k_gs_line(emg::Level<T> L, int colour, int cntp, int cntq,
-                                                T *scratch)
+__global__ __launch_bounds__(64) void k_line_setup(emg::Level<T> L, int colour, int cntp, int cntq, T *fac,
+                                                   double *lfac)
 {
-    emg::gs_line_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
-                                scratch);
+    emg::line_setup_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
+                                   fac, lfac);
+}
+
+template <class T, int DIR>
+__global__ __launch_bounds__(64) void k_line_rhs(emg::Level<T> L, int colour, int cntp, int cntq, T *vec)
+{
+    emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
+                                 blockIdx.z, vec);
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void k_line_forward(int n0, int cntp, int cntq, const T *fac,
+                                                     const double *lfac, T *vec)
+{
+    emg::line_forward_thread<T>(n0, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, fac, lfac,
+                                vec);
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void k_line_backward(int n0, int cntp, int cntq, const T *fac,
+                                                      const double *lfac, T *vec)
+{
+    emg::line_backward_thread<T>(n0, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, fac, lfac,
+                                 vec);
+}
+
+template <class T, int DIR>
+__global__ __launch_bounds__(64) void k_line_scatter(emg::Level<T> L, int colour, int cntp, int cntq,
+                                                     const T *vec)
+{
+    emg::line_scatter_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
+                                     blockIdx.z, vec);
 }
 
 // Residual + per-block partial sums of |r|^2.
@@ -173,35 +208,74 @@ __global__ void k_blocks_to_amat(T *amat, T *bvec, const T *middle, const double
 
 // --------------------------------------------------------------------------- launchers --
 
+template <class T, int DIR>
+void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac, T *vec, hipStream_t st)
+{
+    const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
+    if (lc.lines <= 0) return;
+    const dim3 lb = d3(emg::line_block()), lg = d3(emg::line_grid(lc));
+    const dim3 bb = d3(emg::lineblk_block()), bg = d3(emg::lineblk_grid(lc));
+    const T *f = fac + lc.fac_off;
+    const double *lf = lfac + lc.lfac_off;
+    hipLaunchKernelGGL((k_line_rhs<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
+    hipLaunchKernelGGL(k_line_forward<T>, lg, lb, 0, st, lc.n0, lc.cntp, lc.cntq, f, lf, vec);
+    hipLaunchKernelGGL(k_line_backward<T>, lg, lb, 0, st, lc.n0, lc.cntp, lc.cntq, f, lf, vec);
+    hipLaunchKernelGGL((k_line_scatter<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, (const T *)vec);
+}
+
 template <class T>
-int launch_gs(const emg3d_level *lv, int lr, int nu, void *scratch, size_t scratch_bytes, hipStream_t st)
+int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const double *lfac, void *scratch,
+              size_t scratch_bytes, hipStream_t st)
 {
     emg::Level<T> L = to_level<T>(lv);
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     if (nx < 2 || ny < 2 || nz < 2) return fail(EMG3D_ERR_BADARG, "gauss_seidel: need >= 2 cells per direction");
-    if (lr != 0 && scratch_bytes < emg3d_gs_scratch_bytes(lr, nx, ny, nz, lv->is_complex))
-        return fail(EMG3D_ERR_SCRATCH, "gauss_seidel: scratch buffer too small");
+    if (lr != 0) {
+        if (!fac || !lfac) return fail(EMG3D_ERR_BADARG, "gauss_seidel: line factors missing (emg3d_dev_line_setup)");
+        if (!scratch || scratch_bytes < emg3d_gs_scratch_bytes(lr, nx, ny, nz, lv->is_complex))
+            return fail(EMG3D_ERR_SCRATCH, "gauss_seidel: scratch buffer too small");
+    }
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;   // first sweep backward (reference emg3d/core.py:301,311)
+        if (lr == 0) {
+            emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
+                const emg::Dim3 g = emg::gs_point_grid(nx, ny, izn);
+                if (g.x > 0 && g.y > 0 && g.z > 0)
+                    hipLaunchKernelGGL(k_gs_point<T>, d3(g), d3(emg::gs_point_block()), 0, st, L, c, iz0);
+            });
+            continue;
+        }
         for (int cc = 0; cc < 4; ++cc) {
             const int c = emg::sweep_colour(iback, cc);
-            if (lr == 0) {
-                const emg::Dim3 g = emg::gs_point_grid(nx, ny, nz);
-                if (g.x > 0 && g.y > 0 && g.z > 0)
-                    hipLaunchKernelGGL(k_gs_point<T>, d3(g), d3(emg::gs_point_block()), 0, st, L, c);
-            } else {
-                const int dir = lr - 1;
-                const int cntp = cnt_par(emg::line_np(dir, nx, ny, nz), c & 1);
-                const int cntq = cnt_par(emg::line_nq(dir, nx, ny, nz), (c >> 1) & 1);
-                if (cntp <= 0 || cntq <= 0) continue;
-                const dim3 grid = d3(emg::gs_line_grid(cntp, cntq)), block = d3(emg::gs_line_block());
-                if (dir == 0) hipLaunchKernelGGL((k_gs_line<T, 0>), grid, block, 0, st, L, c, cntp, cntq, (T *)scratch);
-                else if (dir == 1) hipLaunchKernelGGL((k_gs_line<T, 1>), grid, block, 0, st, L, c, cntp, cntq, (T *)scratch);
-                else hipLaunchKernelGGL((k_gs_line<T, 2>), grid, block, 0, st, L, c, cntp, cntq, (T *)scratch);
-            }
+            if (lr == 1) launch_line_colour<T, 0>(L, c, (const T *)fac, lfac, (T *)scratch, st);
+            else if (lr == 2) launch_line_colour<T, 1>(L, c, (const T *)fac, lfac, (T *)scratch, st);
+            else launch_line_colour<T, 2>(L, c, (const T *)fac, lfac, (T *)scratch, st);
         }
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T, int DIR>
+void launch_line_setup_dir(const emg::Level<T> &L, T *fac, double *lfac, hipStream_t st)
+{
+    for (int c = 0; c < 4; ++c) {
+        const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
+        if (lc.lines <= 0) continue;
+        hipLaunchKernelGGL((k_line_setup<T, DIR>), d3(emg::line_grid(lc)), d3(emg::line_block()), 0, st, L, c,
+                           lc.cntp, lc.cntq, fac + lc.fac_off, lfac + lc.lfac_off);
+    }
+}
+
+template <class T>
+int launch_line_setup(const emg3d_level *lv, int lr, void *fac, double *lfac, hipStream_t st)
+{
+    emg::Level<T> L = to_level<T>(lv);
+    if (L.nx < 2 || L.ny < 2 || L.nz < 2) return fail(EMG3D_ERR_BADARG, "line_setup: need >= 2 cells per direction");
+    if (lr == 1) launch_line_setup_dir<T, 0>(L, (T *)fac, lfac, st);
+    else if (lr == 2) launch_line_setup_dir<T, 1>(L, (T *)fac, lfac, st);
+    else launch_line_setup_dir<T, 2>(L, (T *)fac, lfac, st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -330,6 +404,19 @@ extern "C" {
 int emg3d_version(void) { return EMG3D_AMD_VERSION; }
 const char *emg3d_last_error(void) { return g_err.c_str(); }
 
+int emg3d_set_option(const char *name, int value)
+{
+    if (!name) return fail(EMG3D_ERR_BADARG, "set_option: null name");
+    if (!std::strcmp(name, "point_slab")) { g_point_slab = value; return 0; }
+    return fail(EMG3D_ERR_BADARG, "set_option: unknown option");
+}
+
+int emg3d_get_option(const char *name)
+{
+    if (name && !std::strcmp(name, "point_slab")) return g_point_slab;
+    return -1;
+}
+
 int emg3d_device_count(void)
 {
     int n = 0;
@@ -340,15 +427,34 @@ int emg3d_device_count(void)
 size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex)
 {
     if (lr < 1 || lr > 3) return 0;
-    return emg::gs_line_scratch_elems(lr - 1, nx, ny, nz) * (is_complex ? 16 : 8);
+    return emg::line_vec_elems(lr - 1, nx, ny, nz) * (is_complex ? 16 : 8);
 }
 
-int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, void *scratch, size_t scratch_bytes,
-                           void *stream)
+size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex)
+{
+    if (lr < 1 || lr > 3) return 0;
+    return emg::line_fac_elems(lr - 1, nx, ny, nz) * (is_complex ? 16 : 8);
+}
+
+size_t emg3d_line_lfac_bytes(int lr, int nx, int ny, int nz)
+{
+    if (lr < 1 || lr > 3) return 0;
+    return emg::line_lfac_elems(lr - 1, nx, ny, nz) * 8;
+}
+
+int emg3d_dev_line_setup(const emg3d_level *lv, int lr, void *fac, double *lfac, void *stream)
+{
+    if (!lv || lr < 1 || lr > 3 || !fac || !lfac) return fail(EMG3D_ERR_BADARG, "line_setup: bad argument");
+    return lv->is_complex ? launch_line_setup<cplx>(lv, lr, fac, lfac, (hipStream_t)stream)
+                          : launch_line_setup<double>(lv, lr, fac, lfac, (hipStream_t)stream);
+}
+
+int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, const void *fac, const double *lfac,
+                           void *scratch, size_t scratch_bytes, void *stream)
 {
     if (!lv || lr < 0 || lr > 3 || nu < 0) return fail(EMG3D_ERR_BADARG, "gauss_seidel: bad argument");
-    return lv->is_complex ? launch_gs<cplx>(lv, lr, nu, scratch, scratch_bytes, (hipStream_t)stream)
-                          : launch_gs<double>(lv, lr, nu, scratch, scratch_bytes, (hipStream_t)stream);
+    return lv->is_complex ? launch_gs<cplx>(lv, lr, nu, fac, lfac, scratch, scratch_bytes, (hipStream_t)stream)
+                          : launch_gs<double>(lv, lr, nu, fac, lfac, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 size_t emg3d_residual_ws_len(int nx, int ny, int nz)
@@ -456,6 +562,9 @@ int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx
     HIP_TRY(upload_inverse(dhx, hx, nx)); HIP_TRY(upload_inverse(dhy, hy, ny)); HIP_TRY(upload_inverse(dhz, hz, nz));
     const size_t sb = emg3d_gs_scratch_bytes(lr, nx, ny, nz, is_complex);
     HIP_TRY(scr.alloc(sb));
+    DevBuf dfac, dlfac;
+    HIP_TRY(dfac.alloc(emg3d_line_fac_bytes(lr, nx, ny, nz, is_complex)));
+    HIP_TRY(dlfac.alloc(emg3d_line_lfac_bytes(lr, nx, ny, nz)));
     emg3d_level lv;
     lv.nx = nx; lv.ny = ny; lv.nz = nz; lv.is_complex = is_complex;
     lv.ex = dex.d; lv.ey = dey.d; lv.ez = dez.d;
@@ -463,7 +572,10 @@ int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx
     lv.eta_x = eta.dptr[0]; lv.eta_y = eta.dptr[1]; lv.eta_z = eta.dptr[2];
     lv.zeta = (const double *)dz.d;
     lv.ihx = (const double *)dhx.d; lv.ihy = (const double *)dhy.d; lv.ihz = (const double *)dhz.d;
-    int rc = emg3d_dev_gauss_seidel(&lv, lr, nu, scr.d, sb, nullptr);
+    int rc = 0;
+    if (lr != 0) rc = emg3d_dev_line_setup(&lv, lr, dfac.d, (double *)dlfac.d, nullptr);
+    if (rc) return rc;
+    rc = emg3d_dev_gauss_seidel(&lv, lr, nu, dfac.d, (const double *)dlfac.d, scr.d, sb, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(dex.down(ex)); HIP_TRY(dey.down(ey)); HIP_TRY(dez.down(ez));

@@ -26,15 +26,17 @@ inline int sweep_colour(int iback, int cc)
     return seq[iback ? 3 - cc : cc];
 }
 
-// ---- point smoother: colour = ((ix+iz)&1) | (((iy+iz)&1)<<1); global thread (gx,gy,gz) --
+// ---- point smoother: colour = ((ix+iz)&1) | (((iy+iz)&1)<<1); global thread (gx,gy,gz);
+//      one launch covers the node planes iz0 .. iz0+izn-1.
 inline Dim3 gs_point_block() { return Dim3{64, 4, 1}; }
-inline Dim3 gs_point_grid(int nx, int ny, int nz)
+inline Dim3 gs_point_grid(int nx, int ny, int izn)
 {
-    return Dim3{cdiv(cdiv(nx - 1, 2), 64), cdiv(cdiv(ny - 1, 2), 4), nz - 1};
+    return Dim3{cdiv(cdiv(nx - 1, 2), 64), cdiv(cdiv(ny - 1, 2), 4), izn};
 }
-template <class T> EMG_HD void gs_point_thread(const Level<T> &L, int colour, int gx, int gy, int gz)
+template <class T>
+EMG_HD void gs_point_thread(const Level<T> &L, int colour, int iz0, int gx, int gy, int gz)
 {
-    const int iz = 1 + gz;
+    const int iz = iz0 + gz;
     const int parx = (colour & 1) ^ (iz & 1);
     const int pary = ((colour >> 1) & 1) ^ (iz & 1);
     const int ix = first_par(parx) + 2 * gx;
@@ -43,34 +45,152 @@ template <class T> EMG_HD void gs_point_thread(const Level<T> &L, int colour, in
     gs_point_node<T>(L, ix, iy, iz);
 }
 
+// Launch schedule of ONE four-colour sweep of the point smoother.
+//
+// slab <= 0: four launches, one per colour class, each over all planes (the plain
+// schedule). slab = T > 0: the planes are processed in rounds of T; in round r the colour
+// at sweep position cc = 0..3 runs on planes [1 + rT - cc, 1 + (r+1)T - cc). The skew by
+// one plane per position keeps every dependency of the plain schedule (a node conflicts
+// only with nodes in planes iz-1, iz, iz+1): position cc at plane k sees positions < cc
+// already updated and positions > cc not yet updated on k-1..k+1 -- the result is
+// bit-identical to the plain schedule, but the ~4 consecutive launches of a round touch
+// the same T+3 planes, which then come from the 256 MiB Infinity Cache instead of HBM.
+// launch(colour, iz0, izn) is called for every kernel launch, in order.
+template <class F> inline void gs_point_schedule(int nz, int slab, int iback, F launch)
+{
+    const int nplanes = nz - 1;
+    if (nplanes <= 0) return;
+    if (slab <= 0 || slab >= nplanes) {
+        for (int cc = 0; cc < 4; ++cc) launch(sweep_colour(iback, cc), 1, nplanes);
+        return;
+    }
+    const int rounds = cdiv(nplanes + 3, slab);
+    for (int r = 0; r < rounds; ++r)
+        for (int cc = 0; cc < 4; ++cc) {
+            int a = 1 + r * slab - cc, b = a + slab;
+            if (a < 1) a = 1;
+            if (b > nz) b = nz;
+            if (b > a) launch(sweep_colour(iback, cc), a, b - a);
+        }
+}
+
 // ---- line smoothers: (p,q) = transverse PHYSICAL node indices in memory order (p faster):
 //      DIR 0 (x-lines): (iy,iz)   DIR 1 (y-lines): (ix,iz)   DIR 2 (z-lines): (ix,iy)
-//      colour = (p&1) | ((q&1)<<1); one thread per line.
+//      colour = (p&1) | ((q&1)<<1). Lines of one colour class are numbered
+//      lid = tp + cntp*tq with p = first_par(colour&1) + 2 tp, q likewise.
 inline int line_np(int dir, int nx, int ny, int nz) { (void)nz; return dir == 0 ? ny : nx; }
 inline int line_nq(int dir, int nx, int ny, int nz) { (void)nx; return dir == 2 ? ny : nz; }
 inline int line_n0(int dir, int nx, int ny, int nz) { return dir == 0 ? nx : dir == 1 ? ny : nz; }
-inline Dim3 gs_line_block() { return Dim3{64, 1, 1}; }
-inline Dim3 gs_line_grid(int cntp, int cntq) { return Dim3{cdiv(cntp, 64), cntq, 1}; }
 
-template <class T, int DIR>
-EMG_HD void gs_line_thread(const Level<T> &L, int colour, int cntp, int cntq, int tp, int tq, T *scratch)
+// Geometry of one colour class of one direction on one level.
+struct LineClass {
+    int n0, cntp, cntq, lines;     // blocks per line, lines along p / q, total
+    size_t fac_off, lfac_off;      // element offsets of the class in the factor buffers
+};
+inline LineClass line_class(int dir, int nx, int ny, int nz, int colour)
 {
-    if (tp >= cntp || tq >= cntq) return;
-    const int p = first_par(colour & 1) + 2 * tp;
-    const int q = first_par((colour >> 1) & 1) + 2 * tq;
-    const int lid = tp + cntp * tq;
-    const int lstride = cntp * cntq;
-    // abstract (i1,i2): DIR 0: (iy,iz)=(p,q); DIR 1: (iz,ix)=(q,p); DIR 2: (ix,iy)=(p,q)
-    const int i1 = DIR == 1 ? q : p;
-    const int i2 = DIR == 1 ? p : q;
-    gs_line<T, DIR>(L, i1, i2, scratch + lid, lstride);
+    LineClass c;
+    c.n0 = line_n0(dir, nx, ny, nz);
+    size_t before = 0;
+    for (int cc = 0; cc <= colour; ++cc) {
+        const int cp = cnt_par(line_np(dir, nx, ny, nz), cc & 1);
+        const int cq = cnt_par(line_nq(dir, nx, ny, nz), (cc >> 1) & 1);
+        if (cc == colour) { c.cntp = cp; c.cntq = cq; c.lines = cp * cq; }
+        else before += (size_t)cp * cq;
+    }
+    c.fac_off = (size_t)15 * c.n0 * before;
+    c.lfac_off = (size_t)8 * c.n0 * before;
+    return c;
+}
+// all lines of a direction: (np-1)(nq-1)
+inline size_t line_total(int dir, int nx, int ny, int nz)
+{
+    return (size_t)(line_np(dir, nx, ny, nz) - 1) * (line_nq(dir, nx, ny, nz) - 1);
+}
+// elements of the factor buffers and of the rhs/solution scratch of one direction
+inline size_t line_fac_elems(int dir, int nx, int ny, int nz)
+{
+    return (size_t)15 * line_n0(dir, nx, ny, nz) * line_total(dir, nx, ny, nz);
+}
+inline size_t line_lfac_elems(int dir, int nx, int ny, int nz)
+{
+    return (size_t)8 * line_n0(dir, nx, ny, nz) * line_total(dir, nx, ny, nz);
+}
+inline size_t line_vec_elems(int dir, int nx, int ny, int nz)
+{   // largest colour class (odd,odd)
+    const size_t lines = (size_t)cnt_par(line_np(dir, nx, ny, nz), 1) * cnt_par(line_nq(dir, nx, ny, nz), 1);
+    return (size_t)5 * line_n0(dir, nx, ny, nz) * lines;
 }
 
-// scratch elements (of T) needed by one line-smoother launch in direction dir
-inline size_t gs_line_scratch_elems(int dir, int nx, int ny, int nz)
+// per-line kernels (setup, forward, backward): one thread per line
+inline Dim3 line_block() { return Dim3{64, 1, 1}; }
+inline Dim3 line_grid(const LineClass &c) { return Dim3{cdiv(c.cntp, 64), c.cntq, 1}; }
+// per-(line, block) kernels (rhs, scatter): thread (tp, tq, k)
+inline Dim3 lineblk_block() { return Dim3{64, 1, 1}; }
+inline Dim3 lineblk_grid(const LineClass &c) { return Dim3{cdiv(c.cntp, 64), c.cntq, c.n0}; }
+
+// (i1, i2, lid) of thread (tp, tq) in colour class `colour`; false if out of range
+template <int DIR>
+EMG_HD bool line_of_thread(int colour, int cntp, int cntq, int tp, int tq, int &i1, int &i2, int &lid)
 {
-    const size_t lines = (size_t)cnt_par(line_np(dir, nx, ny, nz), 1) * cnt_par(line_nq(dir, nx, ny, nz), 1);
-    return (size_t)6 * (5 * line_n0(dir, nx, ny, nz) - 4) * lines;
+    if (tp >= cntp || tq >= cntq) return false;
+    const int p = first_par(colour & 1) + 2 * tp;
+    const int q = first_par((colour >> 1) & 1) + 2 * tq;
+    lid = tp + cntp * tq;
+    // abstract (i1,i2): DIR 0: (iy,iz)=(p,q); DIR 1: (iz,ix)=(q,p); DIR 2: (ix,iy)=(p,q)
+    i1 = DIR == 1 ? q : p;
+    i2 = DIR == 1 ? p : q;
+    return true;
+}
+
+template <class T, int DIR>
+EMG_HD void line_setup_thread(const Level<T> &L, int colour, int cntp, int cntq, int tp, int tq, T *fac,
+                              double *lfac)
+{
+    int i1, i2, lid;
+    if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
+    line_setup<T, DIR>(L, i1, i2, fac + lid, lfac + lid, cntp * cntq);
+}
+
+template <class T, int DIR>
+EMG_HD void line_rhs_thread(const Level<T> &L, int colour, int cntp, int cntq, int tp, int tq, int k, T *vec)
+{
+    int i1, i2, lid;
+    if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
+    const Axes<T, DIR> A(L);
+    T rhs[5];
+    line_rhs<T, DIR>(A, k, i1, i2, rhs);
+    const int ls = cntp * cntq;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) vec[(size_t)(k * 5 + r) * ls + lid] = rhs[r];
+}
+
+template <class T>
+EMG_HD void line_forward_thread(int n0, int cntp, int cntq, int tp, int tq, const T *fac, const double *lfac,
+                                T *vec)
+{
+    if (tp >= cntp || tq >= cntq) return;
+    const int lid = tp + cntp * tq;
+    line_forward<T>(n0, fac + lid, lfac + lid, vec + lid, cntp * cntq);
+}
+
+template <class T>
+EMG_HD void line_backward_thread(int n0, int cntp, int cntq, int tp, int tq, const T *fac, const double *lfac,
+                                 T *vec)
+{
+    if (tp >= cntp || tq >= cntq) return;
+    const int lid = tp + cntp * tq;
+    line_backward<T>(n0, fac + lid, lfac + lid, vec + lid, cntp * cntq);
+}
+
+template <class T, int DIR>
+EMG_HD void line_scatter_thread(const Level<T> &L, int colour, int cntp, int cntq, int tp, int tq, int k,
+                                const T *vec)
+{
+    int i1, i2, lid;
+    if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
+    const Axes<T, DIR> A(L);
+    line_scatter<T, DIR>(A, k, i1, i2, vec + lid, cntp * cntq);
 }
 
 // ---- "extended cell" kernels (residual, prolongation, PEC): one thread per node-indexed

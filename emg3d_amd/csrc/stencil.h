@@ -392,34 +392,39 @@ template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, 
 // (core.py:678,733,775-783); for DIR=1,2 it is the cyclic image of it, which is the same
 // linear system as the reference's y-/z-line system with unknowns 1,2 <-> 3,4 exchanged.
 //
-// The symmetric band matrix (half bandwidth 5) is factorised row by row
-// (A = L D L^T without pivoting, the factorisation of core.solve) while it is assembled:
-// row i needs only the rows of the previous block. Per row the five sub-diagonal entries
-// of L and the scaled forward-substituted right-hand side are streamed to a scratch
-// buffer; a backward sweep over that buffer yields the solution. The reference's
-// `amat`/`bvec`/`middle`/`left` arrays (core.py:586-593) never exist.
+// The line matrix is block tridiagonal: diagonal blocks M_k (5x5 complex symmetric,
+// `middle`), sub-diagonal blocks B_k (real, only first row and diagonal non-zero, `left`).
+// It depends on eta, zeta and h only -- NOT on the field -- so its block factorisation
+//     S_0 = M_0,   S_k = M_k - B_k S_{k-1}^{-1} B_k^T,   S_k = C_k D_k C_k^T  (LDL^T, no pivoting)
+// is computed ONCE per level and direction (line_setup) and kept in HBM (MI355X has the
+// capacity: 304 B per cell and direction); it is the factorisation core.solve
+// (core.py:1481-1616) performs on every call, in block form. A smoothing sweep then is
+//     (1) rhs_k  : source + terms of edges NOT on the line          (parallel, line_rhs)
+//     (2) forward: c_k = rhs_k - B_k w_{k-1},  w_k = S_k^{-1} c_k    (per line, line_forward)
+//     (3) backward: x_k = w_k - S_k^{-1} B_{k+1}^T x_{k+1}           (per line, line_backward)
+//     (4) scatter x into the field                                   (parallel, line_scatter)
+// The reference's `amat`/`bvec`/`middle`/`left` arrays (core.py:586-593) never exist.
 //
-// Scratch layout: 6 values of T per unknown row; value c of row i of line `lid` lives at
-// scratch[(i*6 + c) * lstride + lid]  (coalesced across the lines of one launch).
+// Storage (coalesced across the lines of one colour class; lid = line index inside the
+// class, lstride = lines in the class):
+//   fac [(k*15 + j) * lstride + lid]   j = 0..9: C_k strictly lower, row-major
+//                                      (1,0),(2,0),(2,1),(3,0)...(4,3); j = 10..14: 1/D_k
+//   lfac[(k*8  + j) * lstride + lid]   j = 0..3: B_k(0, m), m = 1..4; j = 4..7: B_k(m, m)
+//   vec [(k*5  + r) * lstride + lid]   rhs -> w -> x in place
 // ---------------------------------------------------------------------------------------
-template <class T> struct LineState {
-    T Cp[5][5];     // strictly-lower L entries inside the previous block (Cp[r][m], m<r)
-    T dinvp[5];     // 1/D of the previous block
-    T yp[5];        // forward-substituted rhs (unscaled) of the previous block
-};
+EMG_HD constexpr int tri(int r, int m) { return r * (r - 1) / 2 + m; }   // index of C(r,m), m<r
 
-// Assemble block k of the line (matrix rows of block k): diagonal dg[5], strictly-lower
-// real part mid[r][m] (m<r) inside the block, coupling to the previous block
-// left0[m] = A(row 0, prev col m), leftd[m] = A(row m, prev col m)  (m = 1..4), rhs[5].
-// Follows core.py:638-766 written in the abstract axes (a0,a1,a2).
+// Matrix part of block k (core.py:638-721 in the abstract axes): diagonal dg[5], strictly
+// lower real part mid[r][m] (m<r), coupling to the previous block left0[m] = B(0,m),
+// leftd[m] = B(m,m), m = 1..4.
 template <class T, int DIR>
-EMG_HD void line_assemble(const Axes<T, DIR> &A, int k, int i1, int i2, T (&dg)[5],
-                          double (&mid)[5][5], double (&left0)[5], double (&leftd)[5], T (&rhs)[5])
+EMG_HD void line_matrix(const Axes<T, DIR> &A, int k, int i1, int i2, T (&dg)[5], double (&mid)[5][5],
+                        double (&left0)[5], double (&leftd)[5])
 {
     const int n0 = A.n0();
-    const int i0m = k;                               // "ixm": minus index along the line
-    const int i0 = (k + 1 < n0 - 1) ? k + 1 : n0 - 1;  // "ix" clamped (core.py:635)
-    const int i1m = i1 - 1, i1p = i1 + 1, i2m = i2 - 1, i2p = i2 + 1;
+    const int i0m = k;                                  // "ixm": minus index along the line
+    const int i0 = (k + 1 < n0 - 1) ? k + 1 : n0 - 1;   // "ix" clamped (core.py:635)
+    const int i1m = i1 - 1, i2m = i2 - 1;
     const double h00 = A.ih0()[i0m], h01 = A.ih0()[i0];
     const double h10 = A.ih1()[i1m], h11 = A.ih1()[i1];
     const double h20 = A.ih2()[i2m], h21 = A.ih2()[i2];
@@ -474,22 +479,55 @@ EMG_HD void line_assemble(const Axes<T, DIR> &A, int k, int i1, int i2, T (&dg)[
     left0[1] = mzyLxm * h00; left0[2] = -mzyRxm * h00; left0[3] = myzLxm * h00; left0[4] = -myzRxm * h00;
     leftd[0] = 0.0;
     leftd[1] = -mzxLym * h00; leftd[2] = -mzxLyp * h00; leftd[3] = -myxLzm * h00; leftd[4] = -myxLzp * h00;
+}
 
-    // right-hand side (core.py:727-766); only edges NOT on the line enter
+// Right-hand side of block k (core.py:727-766): source + terms of the edges that are NOT
+// on the line, with the current field values. nrows = 5, or 1 for the last block.
+template <class T, int DIR>
+EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
+{
+    const int n0 = A.n0();
+    const int i0m = k;
+    const int i0 = (k + 1 < n0 - 1) ? k + 1 : n0 - 1;
+    const int i1m = i1 - 1, i1p = i1 + 1, i2m = i2 - 1, i2p = i2 + 1;
+    const double h00 = A.ih0()[i0m], h01 = A.ih0()[i0];
+    const double h10 = A.ih1()[i1m], h11 = A.ih1()[i1];
+    const double h20 = A.ih2()[i2m], h21 = A.ih2()[i2];
+    const double k00 = 0.5 * h00, k01 = 0.5 * h01, k10 = 0.5 * h10, k11 = 0.5 * h11;
+    const double k20 = 0.5 * h20, k21 = 0.5 * h21;
+
+    const double z000 = A.zeta(i0m, i1m, i2m), z010 = A.zeta(i0m, i1, i2m);
+    const double z001 = A.zeta(i0m, i1m, i2), z011 = A.zeta(i0m, i1, i2);
+    const double mzyLxm = k10 * (z001 + z000), mzyRxm = k11 * (z011 + z010);
+    const double myzLxm = k20 * (z010 + z000), myzRxm = k21 * (z011 + z001);
+
     rhs[0] = A.s(0, i0m, i1, i2);
+    rhs[0] += (mzyRxm * h11) * A.e(0, i0m, i1p, i2);
+    rhs[0] += (mzyLxm * h10) * A.e(0, i0m, i1m, i2);
+    rhs[0] += (myzRxm * h21) * A.e(0, i0m, i1, i2p);
+    rhs[0] += (myzLxm * h20) * A.e(0, i0m, i1, i2m);
+    if (k == n0 - 1) {   // last block: only the along-line edge
+        rhs[1] = rhs[2] = rhs[3] = rhs[4] = zero<T>();
+        return;
+    }
+    const double z100 = A.zeta(i0, i1m, i2m), z110 = A.zeta(i0, i1, i2m);
+    const double z101 = A.zeta(i0, i1m, i2), z111 = A.zeta(i0, i1, i2);
+    const double mzxLym = k00 * (z001 + z000), mzxRym = k01 * (z101 + z100);
+    const double mxzLym = k20 * (z100 + z000), mxzRym = k21 * (z101 + z001);
+    const double mzxLyp = k00 * (z011 + z010), mzxRyp = k01 * (z111 + z110);
+    const double mxzLyp = k20 * (z110 + z010), mxzRyp = k21 * (z111 + z011);
+    const double myxLzm = k00 * (z010 + z000), myxRzm = k01 * (z110 + z100);
+    const double mxyLzm = k10 * (z100 + z000), mxyRzm = k11 * (z110 + z010);
+    const double myxLzp = k00 * (z011 + z001), myxRzp = k01 * (z111 + z101);
+    const double mxyLzp = k10 * (z101 + z001), mxyRzp = k11 * (z111 + z011);
+
     rhs[1] = A.s(1, i0, i1m, i2);
     rhs[2] = A.s(1, i0, i1, i2);
     rhs[3] = A.s(2, i0, i1, i2m);
     rhs[4] = A.s(2, i0, i1, i2);
 
-    rhs[0] += (mzyRxm * h11) * A.e(0, i0m, i1p, i2);
-    rhs[0] += (mzyLxm * h10) * A.e(0, i0m, i1m, i2);
-    rhs[0] += (myzRxm * h21) * A.e(0, i0m, i1, i2p);
-    rhs[0] += (myzLxm * h20) * A.e(0, i0m, i1, i2m);
-
-    const T e0_cmc = A.e(0, i0, i1m, i2), e0_mmc = A.e(0, i0m, i1m, i2);
-    rhs[1] += h10 * (mzxRym * e0_cmc - mzxLym * e0_mmc + mxzRym * A.e(2, i0, i1m, i2) -
-                     mxzLym * A.e(2, i0, i1m, i2m));
+    rhs[1] += h10 * (mzxRym * A.e(0, i0, i1m, i2) - mzxLym * A.e(0, i0m, i1m, i2) +
+                     mxzRym * A.e(2, i0, i1m, i2) - mxzLym * A.e(2, i0, i1m, i2m));
     rhs[1] += (mxzRym * h21) * A.e(1, i0, i1m, i2p);
     rhs[1] += (mxzLym * h20) * A.e(1, i0, i1m, i2m);
 
@@ -509,140 +547,220 @@ EMG_HD void line_assemble(const Axes<T, DIR> &A, int k, int i1, int i2, T (&dg)[
     rhs[4] += (mxyLzp * h10) * A.e(2, i0, i1m, i2);
 }
 
-// Factorise the `nrows` (5, or 1 for the last block) rows of one block given the state of
-// the previous block; append L rows + scaled rhs to the scratch; advance the state.
-template <class T>
-EMG_HD void line_factor_block(LineState<T> &st, int nrows, const T (&dg)[5], const double (&mid)[5][5],
-                              const double (&left0)[5], const double (&leftd)[5], const T (&rhs)[5],
-                              T *scr, int row0, int lstride)
+// In-register LDL^T of a symmetric 5x5 block given by its lower triangle S (S[r][m], m<=r):
+// C[tri(r,m)] (m<r) and dinv[r]. nrows < 5 factorises the leading nrows x nrows part.
+template <class T> EMG_HD void ldlt5(const T (&S)[5][5], int nrows, T (&C)[10], T (&dinv)[5])
 {
-    T P[5][5];   // P[r][m], m>=r : L(row r of this block, col m of previous block)
-    T C[5][5];   // C[r][m], m<r  : L(row r, col m) inside this block
-    T dinv[5], y[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
         if (r < nrows) {
-            T uP[5], uC[5];
-            // columns of the previous block, m = r..4
-#pragma unroll
-            for (int m = r; m < 5; ++m) {
-                const double a = (r == 0) ? left0[m] : (m == r ? leftd[m] : 0.0);
-                T t = T(a);
-#pragma unroll
-                for (int kk = r; kk < m; ++kk) t -= uP[kk] * st.Cp[m][kk];
-                uP[m] = t;
-                P[r][m] = t * st.dinvp[m];
-            }
-            // columns inside this block, m = 0..r-1
+            T u[5];
 #pragma unroll
             for (int m = 0; m < r; ++m) {
-                T t = T(mid[r][m]);
+                T t = S[r][m];
 #pragma unroll
-                for (int kk = r; kk < 5; ++kk) t -= uP[kk] * P[m][kk];
-#pragma unroll
-                for (int kk = 0; kk < m; ++kk) t -= uC[kk] * C[m][kk];
-                uC[m] = t;
-                C[r][m] = t * dinv[m];
+                for (int kk = 0; kk < m; ++kk) t -= u[kk] * C[tri(m, kk)];
+                u[m] = t;
+                C[tri(r, m)] = t * dinv[m];
             }
-            T d = dg[r];
-            T yy = rhs[r];
+            T d = S[r][r];
 #pragma unroll
-            for (int kk = r; kk < 5; ++kk) {
-                d -= uP[kk] * P[r][kk];
-                yy -= P[r][kk] * st.yp[kk];
-            }
-#pragma unroll
-            for (int kk = 0; kk < r; ++kk) {
-                d -= uC[kk] * C[r][kk];
-                yy -= C[r][kk] * y[kk];
-            }
+            for (int kk = 0; kk < r; ++kk) d -= u[kk] * C[tri(r, kk)];
             dinv[r] = recip(d);
-            y[r] = yy;
-            // stream the row: columns i-5..i-1 are prev cols r..4 then own cols 0..r-1
-            T *o = scr + (size_t)(row0 + r) * 6 * lstride;
+        } else {
+            dinv[r] = T(1.0);
 #pragma unroll
-            for (int m = r; m < 5; ++m) o[(size_t)(m - r) * lstride] = P[r][m];
-#pragma unroll
-            for (int m = 0; m < r; ++m) o[(size_t)(5 - r + m) * lstride] = C[r][m];
-            o[(size_t)5 * lstride] = yy * dinv[r];
+            for (int m = 0; m < r; ++m) C[tri(r, m)] = zero<T>();
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        st.dinvp[r] = dinv[r];
-        st.yp[r] = y[r];
-#pragma unroll
-        for (int m = 0; m < r; ++m) st.Cp[r][m] = C[r][m];
     }
 }
 
-// Complete relaxation of one line: forward (assemble + factorise + forward substitution),
-// then backward substitution and scatter into the field (core.py:772-783).
+// v <- S^{-1} v with the LDL^T factors (C, dinv) of S.
+template <class T> EMG_HD void ldlt5_solve(const T (&C)[10], const T (&dinv)[5], T (&v)[5])
+{
+#pragma unroll
+    for (int r = 1; r < 5; ++r) {
+#pragma unroll
+        for (int m = 0; m < r; ++m) v[r] -= C[tri(r, m)] * v[m];
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) v[r] *= dinv[r];
+#pragma unroll
+    for (int m = 3; m >= 0; --m) {
+#pragma unroll
+        for (int r = m + 1; r < 5; ++r) v[m] -= C[tri(r, m)] * v[r];
+    }
+}
+
+// Setup of one line: block factorisation, stored in (fac, lfac). Sequential along the line.
 template <class T, int DIR>
-EMG_HD void gs_line(const Level<T> &L, int i1, int i2, T *scr, int lstride)
+EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int lstride)
 {
     const Axes<T, DIR> A(L);
     const int n0 = A.n0();
-    LineState<T> st;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        st.dinvp[r] = zero<T>();
-        st.yp[r] = zero<T>();
-#pragma unroll
-        for (int m = 0; m < 5; ++m) st.Cp[r][m] = zero<T>();
-    }
-    T dg[5], rhs[5];
+    T C[10], dinv[5];        // factors of the previous block's S
+    T dg[5];
     double mid[5][5], left0[5], leftd[5];
-
     for (int k = 0; k < n0; ++k) {
-        line_assemble<T, DIR>(A, k, i1, i2, dg, mid, left0, leftd, rhs);
-        if (k == 0) {
+        line_matrix<T, DIR>(A, k, i1, i2, dg, mid, left0, leftd);
+        T S[5][5];
 #pragma unroll
-            for (int m = 0; m < 5; ++m) { left0[m] = 0.0; leftd[m] = 0.0; }
-        }
-        line_factor_block<T>(st, (k == n0 - 1) ? 1 : 5, dg, mid, left0, leftd, rhs, scr, 5 * k, lstride);
-    }
-
-    // backward: x_i = z_i - sum_{k>i} L_ki x_k, done as a scatter while walking rows down
-    T accC[5], accP[5];
-    {   // last block: single row i = 5(n0-1)
-        const int i = 5 * (n0 - 1);
-        const T *o = scr + (size_t)i * 6 * lstride;
-        const T x = o[(size_t)5 * lstride];
-        A.E(0)[A.idx(0, n0 - 1, i1, i2)] = x;
-        // previous block rows get their z and the scatter of this row
+        for (int r = 0; r < 5; ++r) {
+            S[r][r] = dg[r];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            const T *om = scr + (size_t)(i - 5 + m) * 6 * lstride;
-            accC[m] = om[(size_t)5 * lstride] - o[(size_t)m * lstride] * x;
+            for (int m = 0; m < r; ++m) S[r][m] = T(mid[r][m]);
         }
-    }
-    for (int k = n0 - 2; k >= 0; --k) {
-        const int row0 = 5 * k;
         if (k > 0) {
+            // S -= B T B^T with T = S_{k-1}^{-1} and B = e0 l0^T + diag(0, d1..d4):
+            // columns of T that are needed: T l0 and T e_m (m=1..4) -> 5 solves
+            T tl[5];                              // T l0
+            tl[0] = zero<T>();
 #pragma unroll
-            for (int m = 0; m < 5; ++m)
-                accP[m] = scr[((size_t)(row0 - 5 + m) * 6 + 5) * lstride];
-        }
-        T x[5];
+            for (int m = 1; m < 5; ++m) tl[m] = T(left0[m]);
+            ldlt5_solve<T>(C, dinv, tl);
+            T s00 = zero<T>();
 #pragma unroll
-        for (int r = 4; r >= 0; --r) {
-            x[r] = accC[r];
-            const T *o = scr + (size_t)(row0 + r) * 6 * lstride;
+            for (int m = 1; m < 5; ++m) s00 += left0[m] * tl[m];
+            S[0][0] -= s00;
 #pragma unroll
-            for (int m = 0; m < r; ++m) accC[m] -= o[(size_t)(5 - r + m) * lstride] * x[r];
-            if (k > 0) {
+            for (int r = 1; r < 5; ++r) S[r][0] -= leftd[r] * tl[r];       // (D T l0)_r
+            // D T D, lower triangle: columns T e_m
 #pragma unroll
-                for (int m = r; m < 5; ++m) accP[m] -= o[(size_t)(m - r) * lstride] * x[r];
+            for (int m = 1; m < 5; ++m) {
+                T col[5];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) col[r] = (r == m) ? T(1.0) : zero<T>();
+                ldlt5_solve<T>(C, dinv, col);
+#pragma unroll
+                for (int r = m; r < 5; ++r) S[r][m] -= (leftd[r] * leftd[m]) * col[r];
             }
         }
-        A.E(0)[A.idx(0, k, i1, i2)] = x[0];
-        A.E(1)[A.idx(1, k + 1, i1 - 1, i2)] = x[1];
-        A.E(1)[A.idx(1, k + 1, i1, i2)] = x[2];
-        A.E(2)[A.idx(2, k + 1, i1, i2 - 1)] = x[3];
-        A.E(2)[A.idx(2, k + 1, i1, i2)] = x[4];
+        ldlt5<T>(S, (k == n0 - 1) ? 1 : 5, C, dinv);
 #pragma unroll
-        for (int m = 0; m < 5; ++m) accC[m] = accP[m];
+        for (int j = 0; j < 10; ++j) fac[(size_t)(k * 15 + j) * lstride] = C[j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) fac[(size_t)(k * 15 + 10 + j) * lstride] = dinv[j];
+#pragma unroll
+        for (int m = 1; m < 5; ++m) {
+            lfac[(size_t)(k * 8 + m - 1) * lstride] = (k > 0) ? left0[m] : 0.0;
+            // the last block has a single row: its B has a first row only
+            lfac[(size_t)(k * 8 + 3 + m) * lstride] = (k > 0 && k < n0 - 1) ? leftd[m] : 0.0;
+        }
+    }
+}
+
+template <class T> struct BlockFac {
+    T C[10], dinv[5];
+    double l0[4], ld[4];
+    EMG_HD void load(const T *fac, const double *lfac, int k, int lstride)
+    {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) C[j] = fac[(size_t)(k * 15 + j) * lstride];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dinv[j] = fac[(size_t)(k * 15 + 10 + j) * lstride];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            l0[j] = lfac[(size_t)(k * 8 + j) * lstride];
+            ld[j] = lfac[(size_t)(k * 8 + 4 + j) * lstride];
+        }
+    }
+};
+
+// Forward substitution of one line: vec holds rhs on entry, w on exit.
+template <class T>
+EMG_HD void line_forward(int n0, const T *fac, const double *lfac, T *vec, int lstride)
+{
+    T w[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) w[r] = zero<T>();
+    BlockFac<T> cur, nxt;
+    T c[5], cn[5];
+    cur.load(fac, lfac, 0, lstride);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) c[r] = vec[(size_t)r * lstride];
+    for (int k = 0; k < n0; ++k) {
+        if (k + 1 < n0) {   // prefetch the next block while this one is being solved
+            nxt.load(fac, lfac, k + 1, lstride);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) cn[r] = vec[(size_t)((k + 1) * 5 + r) * lstride];
+        }
+        // c = rhs - B_k w_{k-1}
+        T v0 = zero<T>();
+#pragma unroll
+        for (int m = 1; m < 5; ++m) v0 += cur.l0[m - 1] * w[m];
+        c[0] -= v0;
+#pragma unroll
+        for (int m = 1; m < 5; ++m) c[m] -= cur.ld[m - 1] * w[m];
+        ldlt5_solve<T>(cur.C, cur.dinv, c);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            w[r] = c[r];
+            vec[(size_t)(k * 5 + r) * lstride] = c[r];
+        }
+        cur = nxt;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) c[r] = cn[r];
+    }
+}
+
+// Backward substitution of one line: vec holds w on entry, the solution x on exit.
+template <class T>
+EMG_HD void line_backward(int n0, const T *fac, const double *lfac, T *vec, int lstride)
+{
+    // last block: x = w (single row), nothing to do; walk down from block n0-2
+    T x[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) x[r] = vec[(size_t)((n0 - 1) * 5 + r) * lstride];
+    BlockFac<T> cur, nxt;           // cur: factors of S_k; up: B_{k+1}
+    double up0[4], upd[4];
+    {
+        BlockFac<T> last;
+        last.load(fac, lfac, n0 - 1, lstride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { up0[j] = last.l0[j]; upd[j] = last.ld[j]; }
+    }
+    T wv[5], wn[5];
+    if (n0 >= 2) {
+        cur.load(fac, lfac, n0 - 2, lstride);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) wv[r] = vec[(size_t)((n0 - 2) * 5 + r) * lstride];
+    }
+    for (int k = n0 - 2; k >= 0; --k) {
+        if (k > 0) {
+            nxt.load(fac, lfac, k - 1, lstride);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) wn[r] = vec[(size_t)((k - 1) * 5 + r) * lstride];
+        }
+        // h = B_{k+1}^T x_{k+1}:  h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
+        T h[5];
+        h[0] = zero<T>();
+#pragma unroll
+        for (int m = 1; m < 5; ++m) h[m] = up0[m - 1] * x[0] + upd[m - 1] * x[m];
+        ldlt5_solve<T>(cur.C, cur.dinv, h);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            x[r] = wv[r] - h[r];
+            vec[(size_t)(k * 5 + r) * lstride] = x[r];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { up0[j] = cur.l0[j]; upd[j] = cur.ld[j]; }
+        cur = nxt;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) wv[r] = wn[r];
+    }
+}
+
+// Scatter block k of the solution into the field (core.py:775-783).
+template <class T, int DIR>
+EMG_HD void line_scatter(const Axes<T, DIR> &A, int k, int i1, int i2, const T *vec, int lstride)
+{
+    const int n0 = A.n0();
+    A.E(0)[A.idx(0, k, i1, i2)] = vec[(size_t)(k * 5 + 0) * lstride];
+    if (k < n0 - 1) {
+        A.E(1)[A.idx(1, k + 1, i1 - 1, i2)] = vec[(size_t)(k * 5 + 1) * lstride];
+        A.E(1)[A.idx(1, k + 1, i1, i2)] = vec[(size_t)(k * 5 + 2) * lstride];
+        A.E(2)[A.idx(2, k + 1, i1, i2 - 1)] = vec[(size_t)(k * 5 + 3) * lstride];
+        A.E(2)[A.idx(2, k + 1, i1, i2)] = vec[(size_t)(k * 5 + 4) * lstride];
     }
 }
 

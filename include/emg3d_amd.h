@@ -65,6 +65,10 @@ int emg3d_version(void);
 const char *emg3d_last_error(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int emg3d_device_count(void);
+/* Tuning knobs that never change results. "point_slab": plane-slab thickness of the point
+ * smoother's launch schedule (0 = one launch per colour over all planes). */
+int emg3d_set_option(const char *name, int value);
+int emg3d_get_option(const char *name);
 
 /* ---------------------------------------------------------------- host flavour ---- */
 
@@ -101,12 +105,23 @@ int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex);
 
 /* -------------------------------------------------------------- device flavour ---- */
 
-/* Bytes of scratch needed by emg3d_dev_gauss_seidel for direction lr (0 for lr = 0). */
-size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex);
+/* Line relaxation keeps the block factorisation of every line matrix in HBM: it depends
+ * on eta, zeta and h only, so it is computed once per level and direction
+ * (emg3d_dev_line_setup) and reused by every sweep -- the work core.solve
+ * (emg3d/core.py:1481-1616) repeats on every call of the reference's line smoothers.
+ * Sizes of the two factor buffers (complex/real part `fac`, real coupling part `lfac`)
+ * and of the per-call scratch (right-hand sides / solutions of one colour class): */
+size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex);
+size_t emg3d_line_lfac_bytes(int lr, int nx, int ny, int nz);
+size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex); /* 0 for lr = 0 */
 
-/* nu sweeps of the smoother lr (0 point, 1/2/3 line along x/y/z) on level lv. */
-int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, void *scratch, size_t scratch_bytes,
-                           void *stream);
+/* Factorise all lines of direction lr (1/2/3 = x/y/z) of level lv into fac / lfac. */
+int emg3d_dev_line_setup(const emg3d_level *lv, int lr, void *fac, double *lfac, void *stream);
+
+/* nu sweeps of the smoother lr (0 point, 1/2/3 line along x/y/z) on level lv.
+ * fac/lfac: from emg3d_dev_line_setup for the same level and lr (NULL for lr = 0). */
+int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, const void *fac, const double *lfac,
+                           void *scratch, size_t scratch_bytes, void *stream);
 
 /* Number of doubles of workspace emg3d_dev_residual needs for its block partial sums. */
 size_t emg3d_residual_ws_len(int nx, int ny, int nz);

@@ -25,6 +25,8 @@ struct LevelArgs {
     const double *ihx, *ihy, *ihz;
 };
 
+int g_point_slab = 0;
+
 template <class T> emg::Level<T> to_level(const LevelArgs *lv)
 {
     emg::Level<T> L;
@@ -48,30 +50,63 @@ template <class F> void for_threads(emg::Dim3 g, emg::Dim3 b, F f)
                             f(bx * b.x + tx, by * b.y + ty, bz * b.z + tz);
 }
 
+template <class T, int DIR>
+void line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac, T *vec)
+{
+    const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
+    if (lc.lines <= 0) return;
+    const T *f = fac + lc.fac_off;
+    const double *lf = lfac + lc.lfac_off;
+    for_threads(emg::lineblk_grid(lc), emg::lineblk_block(), [&](int gx, int gy, int gz) {
+        emg::line_rhs_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, vec);
+    });
+    for_threads(emg::line_grid(lc), emg::line_block(), [&](int gx, int gy, int) {
+        emg::line_forward_thread<T>(lc.n0, lc.cntp, lc.cntq, gx, gy, f, lf, vec);
+    });
+    for_threads(emg::line_grid(lc), emg::line_block(), [&](int gx, int gy, int) {
+        emg::line_backward_thread<T>(lc.n0, lc.cntp, lc.cntq, gx, gy, f, lf, vec);
+    });
+    for_threads(emg::lineblk_grid(lc), emg::lineblk_block(), [&](int gx, int gy, int gz) {
+        emg::line_scatter_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, (const T *)vec);
+    });
+}
+
+template <class T, int DIR> void line_setup_all(const emg::Level<T> &L, T *fac, double *lfac)
+{
+    for (int c = 0; c < 4; ++c) {
+        const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
+        if (lc.lines <= 0) continue;
+        for_threads(emg::line_grid(lc), emg::line_block(), [&](int gx, int gy, int) {
+            emg::line_setup_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, fac + lc.fac_off, lfac + lc.lfac_off);
+        });
+    }
+}
+
 template <class T> void gs(const LevelArgs *lv, int lr, int nu)
 {
     emg::Level<T> L = to_level<T>(lv);
     const int nx = L.nx, ny = L.ny, nz = L.nz;
-    std::vector<T> scratch(lr ? emg::gs_line_scratch_elems(lr - 1, nx, ny, nz) : 1);
+    std::vector<T> vec(lr ? emg::line_vec_elems(lr - 1, nx, ny, nz) : 1);
+    std::vector<T> fac(lr ? emg::line_fac_elems(lr - 1, nx, ny, nz) : 1);
+    std::vector<double> lfac(lr ? emg::line_lfac_elems(lr - 1, nx, ny, nz) : 1);
+    if (lr == 1) line_setup_all<T, 0>(L, fac.data(), lfac.data());
+    if (lr == 2) line_setup_all<T, 1>(L, fac.data(), lfac.data());
+    if (lr == 3) line_setup_all<T, 2>(L, fac.data(), lfac.data());
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;
+        if (lr == 0) {
+            emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
+                for_threads(emg::gs_point_grid(nx, ny, izn), emg::gs_point_block(),
+                            [&](int gx, int gy, int gz) { emg::gs_point_thread<T>(L, c, iz0, gx, gy, gz); });
+            });
+            continue;
+        }
         for (int cc = 0; cc < 4; ++cc) {
             const int c = emg::sweep_colour(iback, cc);
-            if (lr == 0) {
-                for_threads(emg::gs_point_grid(nx, ny, nz), emg::gs_point_block(),
-                            [&](int gx, int gy, int gz) { emg::gs_point_thread<T>(L, c, gx, gy, gz); });
-            } else {
-                const int dir = lr - 1;
-                const int cntp = emg::cnt_par(emg::line_np(dir, nx, ny, nz), c & 1);
-                const int cntq = emg::cnt_par(emg::line_nq(dir, nx, ny, nz), (c >> 1) & 1);
-                if (cntp <= 0 || cntq <= 0) continue;
-                for_threads(emg::gs_line_grid(cntp, cntq), emg::gs_line_block(), [&](int gx, int gy, int) {
-                    if (dir == 0) emg::gs_line_thread<T, 0>(L, c, cntp, cntq, gx, gy, scratch.data());
-                    else if (dir == 1) emg::gs_line_thread<T, 1>(L, c, cntp, cntq, gx, gy, scratch.data());
-                    else emg::gs_line_thread<T, 2>(L, c, cntp, cntq, gx, gy, scratch.data());
-                });
-            }
+            if (lr == 1) line_colour<T, 0>(L, c, fac.data(), lfac.data(), vec.data());
+            else if (lr == 2) line_colour<T, 1>(L, c, fac.data(), lfac.data(), vec.data());
+            else line_colour<T, 2>(L, c, fac.data(), lfac.data(), vec.data());
         }
     }
 }
@@ -89,6 +124,8 @@ template <class T> double residual(const LevelArgs *lv, void *rx, void *ry, void
 }  // namespace
 
 extern "C" {
+
+void emu_set_point_slab(int t) { g_point_slab = t; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
 {

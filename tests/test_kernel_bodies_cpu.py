@@ -158,3 +158,25 @@ def test_smoothers_odd_and_tiny_grids(shape):
                            vm.zeta, *grid.h, 2, order=1)
         emu.gauss_seidel(b, s, vm, lr, 2)
         assert relerr(b.field, a.field) < 2e-12, (shape, fn)
+
+
+@pytest.mark.parametrize('slab', [1, 2, 3, 5, 64])
+def test_point_slab_schedule_is_bit_identical(golden_kernels, slab):
+    """The skewed plane-slab launch schedule of the point smoother (launch.h) must give
+    exactly the values of the plain one-launch-per-colour schedule."""
+    g = golden_kernels
+    for name in ('c_tri', 'c_iso', 'r_tri', 'c_z2'):
+        p = name + '_'
+        grid, vm = _case(g, name)
+        s = mg_ref.Field(grid, g[p + 'gs_s'].copy())
+        for nu in (1, 2):
+            a = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
+            b = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
+            emu.lib().emu_set_point_slab(0)
+            emu.gauss_seidel(a, s, vm, 0, nu)
+            emu.lib().emu_set_point_slab(slab)
+            try:
+                emu.gauss_seidel(b, s, vm, 0, nu)
+            finally:
+                emu.lib().emu_set_point_slab(0)
+            assert np.array_equal(a.field, b.field), (name, nu, slab)

@@ -1,0 +1,100 @@
+"""GPU micro-benchmarks of single kernels at full size (run through gpurun).
+
+    python tools/microbench.py point --n 256 --slabs 0,4,8,16,32
+    python tools/microbench.py lines --n 128
+    python tools/microbench.py residual --n 256
+Values: complex standard normal fields (PEC zeroed), model from the config.
+Timing: torch.cuda events on the launch stream, warm-up 2, median of `reps`.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from emg3d_amd import _lib                      # noqa: E402
+from emg3d_amd._device import DeviceLevel       # noqa: E402
+import emg3d_amd as emg3d                       # noqa: E402
+from bench import widths, BYTES_PER_CELL_SWEEP  # noqa: E402
+
+
+def make_level(n, case, stretch=1.03, shape=None):
+    shape = shape or (n, n, n)
+    rng = np.random.default_rng(1)
+    h = [widths(m // 2, m // 4, 25., stretch) for m in shape]
+    grid = emg3d.TensorMesh(h, (0, 0, 0))
+    vol = grid.cell_volumes.reshape(shape, order='F')
+    smu0 = 2j * np.pi * 1.25663706127e-06
+
+    class VM:
+        pass
+    vm = VM()
+    vm.grid, vm.case = grid, case
+    sig = 10 ** rng.uniform(-1.5, 0.5, shape)
+    vm.eta_x = np.asfortranarray(-smu0 * vol * sig)
+    vm.eta_y = np.asfortranarray(vm.eta_x / 1.5) if case == 'triaxial' else vm.eta_x
+    vm.eta_z = np.asfortranarray(vm.eta_x / 2.5) if case in ('VTI', 'triaxial') else vm.eta_x
+    vm.zeta = np.asfortranarray(vol)
+    lv = DeviceLevel.from_host(vm, torch.device('cuda'))
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    for t in (lv.e, lv.s):
+        t.copy_(torch.complex(torch.randn(grid.n_edges, generator=gen, device='cuda', dtype=torch.float64),
+                              torch.randn(grid.n_edges, generator=gen, device='cuda', dtype=torch.float64)))
+    lv.pec_zero()
+    return lv, grid
+
+
+def timeit(fn, reps=7, warm=2):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def report(name, ms, ncells, nsweeps, case):
+    b = BYTES_PER_CELL_SWEEP[case] * ncells * nsweeps
+    print(f"{name:40s} {ms:9.3f} ms  {ncells * nsweeps / ms / 1e6:8.2f} Gcell-sweeps/s  "
+          f"{b / ms / 1e6:8.1f} GB/s algorithmic  ({100 * b / ms / 1e6 / 8000:5.1f}% of 8 TB/s)", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('what', choices=['point', 'lines', 'residual', 'all'])
+    ap.add_argument('--n', type=int, default=256)
+    ap.add_argument('--case', default='triaxial')
+    ap.add_argument('--slabs', default='0,2,4,8,16,32')
+    ap.add_argument('--nu', type=int, default=2)
+    args = ap.parse_args()
+    lib = _lib.lib()
+    lv, grid = make_level(args.n, args.case)
+    nc = grid.n_cells
+    print(f"# {args.n}^3 {args.case}, nu={args.nu}")
+    if args.what in ('point', 'all'):
+        for slab in [int(x) for x in args.slabs.split(',')]:
+            lib.emg3d_set_option(b'point_slab', slab)
+            med, mn = timeit(lambda: lv.smooth(0, args.nu))
+            report(f"gauss_seidel (point) slab={slab}", med, nc, args.nu, args.case)
+        lib.emg3d_set_option(b'point_slab', 0)
+    if args.what in ('lines', 'all'):
+        for lr in (1, 2, 3):
+            med, mn = timeit(lambda: lv.smooth(lr, args.nu), reps=5, warm=1)
+            report(f"gauss_seidel_{'xyz'[lr - 1]} (line)", med, nc, args.nu, args.case)
+    if args.what in ('residual', 'all'):
+        med, mn = timeit(lambda: lv.residual(store=True, norm=False))
+        report("residual (store)", med, nc, 1, args.case)
+        med, mn = timeit(lambda: lv.residual(store=False, norm=True))
+        report("residual (norm only, incl. sync)", med, nc, 1, args.case)
+
+
+if __name__ == '__main__':
+    main()
