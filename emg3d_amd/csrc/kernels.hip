@@ -89,20 +89,149 @@ __global__ __launch_bounds__(64) void k_line_rhs(emg::Level<T> L, int colour, in
                                  blockIdx.z, vec);
 }
 
-template <class T>
-__global__ __launch_bounds__(64) void k_line_forward(int n0, int cntp, int cntq, const T *fac,
-                                                     const double *lfac, T *vec)
+// ---- forward / backward substitution along the lines: four lanes per line -------------
+// Lane j of a quad loads the units u = 4s + j (s = 0..4) of a block record (15 factor
+// entries + 5 rhs/solution entries) and the coupling pair (B(0,j+1), B(j+1,j+1)); the quad
+// then all-gathers the record through DPP quad_perm broadcasts and every lane evaluates
+// the (tiny) 5x5 step redundantly. Records of the next QD blocks are kept in flight in a
+// register ring, so that a wave has 16 lines x QD blocks x 464 B outstanding instead of
+// 64 lines x 1 block: the block recurrence is bound by HBM latency, not by arithmetic.
+template <int LN> __device__ __forceinline__ double quad_bcast_lane(double x)
 {
-    emg::line_forward_thread<T>(n0, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, fac, lfac,
-                                vec);
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, LN * 0x55, 0xf, 0xf, true);   // quad_perm:[LN,LN,LN,LN]
+    hi = __builtin_amdgcn_mov_dpp(hi, LN * 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_bcast(double x, int ln)
+{
+    switch (ln) {   // ln is a compile-time constant after unrolling
+        case 0: return quad_bcast_lane<0>(x);
+        case 1: return quad_bcast_lane<1>(x);
+        case 2: return quad_bcast_lane<2>(x);
+        default: return quad_bcast_lane<3>(x);
+    }
+}
+__device__ __forceinline__ cplx quad_bcast(cplx x, int ln)
+{
+    return cplx(quad_bcast(x.re, ln), quad_bcast(x.im, ln));
+}
+
+template <class T> struct QuadRec {
+    T u[5];
+    double l0, ld;
+    __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, int j)
+    {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int unit = 4 * s + j;
+            const T *p = unit < 15 ? fac + rec * 15 + unit : vec + rec * 5 + (unit - 15);
+            u[s] = *p;
+        }
+        l0 = lfac[rec * 8 + j];
+        ld = lfac[rec * 8 + 4 + j];
+    }
+    // all-gather inside the quad
+    __device__ __forceinline__ void gather(T (&C)[10], T (&dinv)[5], T (&v)[5], double (&b0)[4],
+                                           double (&bd)[4]) const
+    {
+#pragma unroll
+        for (int unit = 0; unit < 20; ++unit) {
+            const T val = quad_bcast(u[unit >> 2], unit & 3);
+            if (unit < 10) C[unit] = val;
+            else if (unit < 15) dinv[unit - 10] = val;
+            else v[unit - 15] = val;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            b0[m] = quad_bcast(l0, m);
+            bd[m] = quad_bcast(ld, m);
+        }
+    }
+};
+
+constexpr int QD = 4;   // blocks in flight per line
+
+template <class T>
+__global__ __launch_bounds__(64) void k_line_forward(int n0, int nlines, const T *fac, const double *lfac,
+                                                     T *vec)
+{
+    const int gt = blockIdx.x * 64 + threadIdx.x;
+    const int j = gt & 3;
+    int line = gt >> 2;
+    const bool active = line < nlines;
+    if (!active) line = nlines - 1;   // keep every quad complete for the DPP exchange
+    QuadRec<T> ring[QD];
+#pragma unroll
+    for (int d = 0; d < QD; ++d)
+        if (d < n0) ring[d].load(fac, lfac, vec, (size_t)d * nlines + line, j);
+    T w[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) w[r] = emg::zero<T>();
+    for (int k0 = 0; k0 < n0; k0 += QD) {
+#pragma unroll
+        for (int d = 0; d < QD; ++d) {
+            const int k = k0 + d;
+            if (k < n0) {
+                T C[10], dinv[5], c[5];
+                double b0[4], bd[4];
+                ring[d].gather(C, dinv, c, b0, bd);
+                if (k + QD < n0) ring[d].load(fac, lfac, vec, (size_t)(k + QD) * nlines + line, j);
+                emg::line_forward_step<T>(C, dinv, b0, bd, c, w);
+                if (active) {
+                    T *o = vec + ((size_t)k * nlines + line) * 5;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r)
+                        if (((15 + r) & 3) == j) o[r] = w[r];
+                }
+            }
+        }
+    }
 }
 
 template <class T>
-__global__ __launch_bounds__(64) void k_line_backward(int n0, int cntp, int cntq, const T *fac,
-                                                      const double *lfac, T *vec)
+__global__ __launch_bounds__(64) void k_line_backward(int n0, int nlines, const T *fac, const double *lfac,
+                                                      T *vec)
 {
-    emg::line_backward_thread<T>(n0, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, fac, lfac,
-                                 vec);
+    const int gt = blockIdx.x * 64 + threadIdx.x;
+    const int j = gt & 3;
+    int line = gt >> 2;
+    const bool active = line < nlines;
+    if (!active) line = nlines - 1;
+    QuadRec<T> ring[QD];
+    // walk kk = 0..n0-1 over the blocks k = n0-1-kk
+#pragma unroll
+    for (int d = 0; d < QD; ++d)
+        if (d < n0) ring[d].load(fac, lfac, vec, (size_t)(n0 - 1 - d) * nlines + line, j);
+    T x[5];
+    double up0[4], upd[4];
+    for (int k0 = 0; k0 < n0; k0 += QD) {
+#pragma unroll
+        for (int d = 0; d < QD; ++d) {
+            const int kk = k0 + d;
+            if (kk < n0) {
+                const int k = n0 - 1 - kk;
+                T C[10], dinv[5], wk[5];
+                double b0[4], bd[4];
+                ring[d].gather(C, dinv, wk, b0, bd);
+                if (kk + QD < n0) ring[d].load(fac, lfac, vec, (size_t)(k - QD) * nlines + line, j);
+                if (kk == 0) {
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) x[r] = wk[r];          // x_{n0-1} = w_{n0-1}
+                } else {
+                    emg::line_backward_step<T>(C, dinv, up0, upd, wk, x);
+                    if (active) {
+                        T *o = vec + ((size_t)k * nlines + line) * 5;
+#pragma unroll
+                        for (int r = 0; r < 5; ++r)
+                            if (((15 + r) & 3) == j) o[r] = x[r];
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { up0[m] = b0[m]; upd[m] = bd[m]; }
+            }
+        }
+    }
 }
 
 template <class T, int DIR>
@@ -213,13 +342,13 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
 {
     const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
     if (lc.lines <= 0) return;
-    const dim3 lb = d3(emg::line_block()), lg = d3(emg::line_grid(lc));
     const dim3 bb = d3(emg::lineblk_block()), bg = d3(emg::lineblk_grid(lc));
     const T *f = fac + lc.fac_off;
     const double *lf = lfac + lc.lfac_off;
+    const dim3 qb = d3(emg::linequad_block()), qg = d3(emg::linequad_grid(lc));
     hipLaunchKernelGGL((k_line_rhs<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
-    hipLaunchKernelGGL(k_line_forward<T>, lg, lb, 0, st, lc.n0, lc.cntp, lc.cntq, f, lf, vec);
-    hipLaunchKernelGGL(k_line_backward<T>, lg, lb, 0, st, lc.n0, lc.cntp, lc.cntq, f, lf, vec);
+    hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0, lc.lines, f, lf, vec);
+    hipLaunchKernelGGL(k_line_backward<T>, qg, qb, 0, st, lc.n0, lc.lines, f, lf, vec);
     hipLaunchKernelGGL((k_line_scatter<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, (const T *)vec);
 }
 

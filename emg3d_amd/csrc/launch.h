@@ -149,7 +149,7 @@ EMG_HD void line_setup_thread(const Level<T> &L, int colour, int cntp, int cntq,
 {
     int i1, i2, lid;
     if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
-    line_setup<T, DIR>(L, i1, i2, fac + lid, lfac + lid, cntp * cntq);
+    line_setup<T, DIR>(L, i1, i2, fac, lfac, cntp * cntq, lid);
 }
 
 template <class T, int DIR>
@@ -160,27 +160,9 @@ EMG_HD void line_rhs_thread(const Level<T> &L, int colour, int cntp, int cntq, i
     const Axes<T, DIR> A(L);
     T rhs[5];
     line_rhs<T, DIR>(A, k, i1, i2, rhs);
-    const int ls = cntp * cntq;
+    T *o = vec + ((size_t)k * (cntp * cntq) + lid) * 5;
 #pragma unroll
-    for (int r = 0; r < 5; ++r) vec[(size_t)(k * 5 + r) * ls + lid] = rhs[r];
-}
-
-template <class T>
-EMG_HD void line_forward_thread(int n0, int cntp, int cntq, int tp, int tq, const T *fac, const double *lfac,
-                                T *vec)
-{
-    if (tp >= cntp || tq >= cntq) return;
-    const int lid = tp + cntp * tq;
-    line_forward<T>(n0, fac + lid, lfac + lid, vec + lid, cntp * cntq);
-}
-
-template <class T>
-EMG_HD void line_backward_thread(int n0, int cntp, int cntq, int tp, int tq, const T *fac, const double *lfac,
-                                 T *vec)
-{
-    if (tp >= cntp || tq >= cntq) return;
-    const int lid = tp + cntp * tq;
-    line_backward<T>(n0, fac + lid, lfac + lid, vec + lid, cntp * cntq);
+    for (int r = 0; r < 5; ++r) o[r] = rhs[r];
 }
 
 template <class T, int DIR>
@@ -190,8 +172,12 @@ EMG_HD void line_scatter_thread(const Level<T> &L, int colour, int cntp, int cnt
     int i1, i2, lid;
     if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
     const Axes<T, DIR> A(L);
-    line_scatter<T, DIR>(A, k, i1, i2, vec + lid, cntp * cntq);
+    line_scatter<T, DIR>(A, k, i1, i2, vec + ((size_t)k * (cntp * cntq) + lid) * 5);
 }
+
+// forward/backward kernels: FOUR lanes per line, 16 lines per wave
+inline Dim3 linequad_block() { return Dim3{64, 1, 1}; }
+inline Dim3 linequad_grid(const LineClass &c) { return Dim3{cdiv(c.lines * 4, 64), 1, 1}; }
 
 // ---- "extended cell" kernels (residual, prolongation, PEC): one thread per node-indexed
 //      cell (ix,iy,iz), 0 <= ix <= nx etc.

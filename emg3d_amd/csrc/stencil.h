@@ -405,12 +405,17 @@ template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, 
 //     (4) scatter x into the field                                   (parallel, line_scatter)
 // The reference's `amat`/`bvec`/`middle`/`left` arrays (core.py:586-593) never exist.
 //
-// Storage (coalesced across the lines of one colour class; lid = line index inside the
-// class, lstride = lines in the class):
-//   fac [(k*15 + j) * lstride + lid]   j = 0..9: C_k strictly lower, row-major
-//                                      (1,0),(2,0),(2,1),(3,0)...(4,3); j = 10..14: 1/D_k
-//   lfac[(k*8  + j) * lstride + lid]   j = 0..3: B_k(0, m), m = 1..4; j = 4..7: B_k(m, m)
-//   vec [(k*5  + r) * lstride + lid]   rhs -> w -> x in place
+// Storage: one record per (block k, line lid) of a colour class with `nlines` lines,
+// block-major so that a line's consecutive blocks are `nlines` records apart and the
+// lines of a wave sit next to each other:
+//   fac [(k*nlines + lid)*15 + j]   j = 0..9: C_k strictly lower, row-major
+//                                   (1,0),(2,0),(2,1),(3,0)...(4,3); j = 10..14: 1/D_k
+//   lfac[(k*nlines + lid)*8  + j]   j = 0..3: B_k(0, m), m = 1..4; j = 4..7: B_k(m, m)
+//   vec [(k*nlines + lid)*5  + r]   rhs -> w -> x in place
+// The forward/backward kernels stream these records with FOUR lanes per line (each lane
+// loads a quarter of a record, the quad exchanges it through DPP), because a wave that
+// serves 64 lines cannot keep enough bytes in flight to hide HBM latency along the
+// sequential block recurrence.
 // ---------------------------------------------------------------------------------------
 EMG_HD constexpr int tri(int r, int m) { return r * (r - 1) / 2 + m; }   // index of C(r,m), m<r
 
@@ -594,7 +599,7 @@ template <class T> EMG_HD void ldlt5_solve(const T (&C)[10], const T (&dinv)[5],
 
 // Setup of one line: block factorisation, stored in (fac, lfac). Sequential along the line.
 template <class T, int DIR>
-EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int lstride)
+EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int nlines, int lid)
 {
     const Axes<T, DIR> A(L);
     const int n0 = A.n0();
@@ -636,131 +641,107 @@ EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, 
             }
         }
         ldlt5<T>(S, (k == n0 - 1) ? 1 : 5, C, dinv);
+        T *f = fac + ((size_t)k * nlines + lid) * 15;
+        double *lf = lfac + ((size_t)k * nlines + lid) * 8;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) fac[(size_t)(k * 15 + j) * lstride] = C[j];
+        for (int j = 0; j < 10; ++j) f[j] = C[j];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) fac[(size_t)(k * 15 + 10 + j) * lstride] = dinv[j];
+        for (int j = 0; j < 5; ++j) f[10 + j] = dinv[j];
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
-            lfac[(size_t)(k * 8 + m - 1) * lstride] = (k > 0) ? left0[m] : 0.0;
+            lf[m - 1] = (k > 0) ? left0[m] : 0.0;
             // the last block has a single row: its B has a first row only
-            lfac[(size_t)(k * 8 + 3 + m) * lstride] = (k > 0 && k < n0 - 1) ? leftd[m] : 0.0;
+            lf[3 + m] = (k > 0 && k < n0 - 1) ? leftd[m] : 0.0;
         }
     }
 }
 
-template <class T> struct BlockFac {
-    T C[10], dinv[5];
-    double l0[4], ld[4];
-    EMG_HD void load(const T *fac, const double *lfac, int k, int lstride)
-    {
-#pragma unroll
-        for (int j = 0; j < 10; ++j) C[j] = fac[(size_t)(k * 15 + j) * lstride];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) dinv[j] = fac[(size_t)(k * 15 + 10 + j) * lstride];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            l0[j] = lfac[(size_t)(k * 8 + j) * lstride];
-            ld[j] = lfac[(size_t)(k * 8 + 4 + j) * lstride];
-        }
-    }
-};
-
-// Forward substitution of one line: vec holds rhs on entry, w on exit.
+// One block of the forward substitution: c holds rhs_k on entry and w_k = S_k^{-1}(rhs_k -
+// B_k w_{k-1}) on exit; w is w_{k-1} on entry and w_k on exit.
 template <class T>
-EMG_HD void line_forward(int n0, const T *fac, const double *lfac, T *vec, int lstride)
+EMG_HD void line_forward_step(const T (&C)[10], const T (&dinv)[5], const double (&l0)[4],
+                              const double (&ld)[4], T (&c)[5], T (&w)[5])
+{
+    T v0 = zero<T>();
+#pragma unroll
+    for (int m = 1; m < 5; ++m) v0 += l0[m - 1] * w[m];
+    c[0] -= v0;
+#pragma unroll
+    for (int m = 1; m < 5; ++m) c[m] -= ld[m - 1] * w[m];
+    ldlt5_solve<T>(C, dinv, c);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) w[r] = c[r];
+}
+
+// One block of the backward substitution: x is x_{k+1} on entry and
+// x_k = w_k - S_k^{-1} B_{k+1}^T x_{k+1} on exit; (up0, upd) are B_{k+1}.
+template <class T>
+EMG_HD void line_backward_step(const T (&C)[10], const T (&dinv)[5], const double (&up0)[4],
+                               const double (&upd)[4], const T (&wk)[5], T (&x)[5])
+{
+    T h[5];
+    h[0] = zero<T>();
+#pragma unroll
+    for (int m = 1; m < 5; ++m) h[m] = up0[m - 1] * x[0] + upd[m - 1] * x[m];
+    ldlt5_solve<T>(C, dinv, h);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) x[r] = wk[r] - h[r];
+}
+
+// Reference walk of one line (one thread per line): used by the CPU emulation of the
+// unit tests and as the specification of what the quad kernels in kernels.hip compute.
+template <class T>
+EMG_HD void line_forward_ref(int n0, int nlines, int lid, const T *fac, const double *lfac, T *vec)
 {
     T w[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) w[r] = zero<T>();
-    BlockFac<T> cur, nxt;
-    T c[5], cn[5];
-    cur.load(fac, lfac, 0, lstride);
-#pragma unroll
-    for (int r = 0; r < 5; ++r) c[r] = vec[(size_t)r * lstride];
     for (int k = 0; k < n0; ++k) {
-        if (k + 1 < n0) {   // prefetch the next block while this one is being solved
-            nxt.load(fac, lfac, k + 1, lstride);
-#pragma unroll
-            for (int r = 0; r < 5; ++r) cn[r] = vec[(size_t)((k + 1) * 5 + r) * lstride];
-        }
-        // c = rhs - B_k w_{k-1}
-        T v0 = zero<T>();
-#pragma unroll
-        for (int m = 1; m < 5; ++m) v0 += cur.l0[m - 1] * w[m];
-        c[0] -= v0;
-#pragma unroll
-        for (int m = 1; m < 5; ++m) c[m] -= cur.ld[m - 1] * w[m];
-        ldlt5_solve<T>(cur.C, cur.dinv, c);
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            w[r] = c[r];
-            vec[(size_t)(k * 5 + r) * lstride] = c[r];
-        }
-        cur = nxt;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) c[r] = cn[r];
+        const size_t rec = (size_t)k * nlines + lid;
+        T C[10], dinv[5], c[5];
+        double l0[4], ld[4];
+        for (int j = 0; j < 10; ++j) C[j] = fac[rec * 15 + j];
+        for (int j = 0; j < 5; ++j) dinv[j] = fac[rec * 15 + 10 + j];
+        for (int j = 0; j < 4; ++j) { l0[j] = lfac[rec * 8 + j]; ld[j] = lfac[rec * 8 + 4 + j]; }
+        for (int r = 0; r < 5; ++r) c[r] = vec[rec * 5 + r];
+        line_forward_step<T>(C, dinv, l0, ld, c, w);
+        for (int r = 0; r < 5; ++r) vec[rec * 5 + r] = w[r];
     }
 }
 
-// Backward substitution of one line: vec holds w on entry, the solution x on exit.
 template <class T>
-EMG_HD void line_backward(int n0, const T *fac, const double *lfac, T *vec, int lstride)
+EMG_HD void line_backward_ref(int n0, int nlines, int lid, const T *fac, const double *lfac, T *vec)
 {
-    // last block: x = w (single row), nothing to do; walk down from block n0-2
     T x[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) x[r] = vec[(size_t)((n0 - 1) * 5 + r) * lstride];
-    BlockFac<T> cur, nxt;           // cur: factors of S_k; up: B_{k+1}
     double up0[4], upd[4];
     {
-        BlockFac<T> last;
-        last.load(fac, lfac, n0 - 1, lstride);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { up0[j] = last.l0[j]; upd[j] = last.ld[j]; }
-    }
-    T wv[5], wn[5];
-    if (n0 >= 2) {
-        cur.load(fac, lfac, n0 - 2, lstride);
-#pragma unroll
-        for (int r = 0; r < 5; ++r) wv[r] = vec[(size_t)((n0 - 2) * 5 + r) * lstride];
+        const size_t rec = (size_t)(n0 - 1) * nlines + lid;
+        for (int r = 0; r < 5; ++r) x[r] = vec[rec * 5 + r];          // x_{n0-1} = w_{n0-1}
+        for (int j = 0; j < 4; ++j) { up0[j] = lfac[rec * 8 + j]; upd[j] = lfac[rec * 8 + 4 + j]; }
     }
     for (int k = n0 - 2; k >= 0; --k) {
-        if (k > 0) {
-            nxt.load(fac, lfac, k - 1, lstride);
-#pragma unroll
-            for (int r = 0; r < 5; ++r) wn[r] = vec[(size_t)((k - 1) * 5 + r) * lstride];
-        }
-        // h = B_{k+1}^T x_{k+1}:  h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
-        T h[5];
-        h[0] = zero<T>();
-#pragma unroll
-        for (int m = 1; m < 5; ++m) h[m] = up0[m - 1] * x[0] + upd[m - 1] * x[m];
-        ldlt5_solve<T>(cur.C, cur.dinv, h);
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            x[r] = wv[r] - h[r];
-            vec[(size_t)(k * 5 + r) * lstride] = x[r];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { up0[j] = cur.l0[j]; upd[j] = cur.ld[j]; }
-        cur = nxt;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) wv[r] = wn[r];
+        const size_t rec = (size_t)k * nlines + lid;
+        T C[10], dinv[5], wk[5];
+        for (int j = 0; j < 10; ++j) C[j] = fac[rec * 15 + j];
+        for (int j = 0; j < 5; ++j) dinv[j] = fac[rec * 15 + 10 + j];
+        for (int r = 0; r < 5; ++r) wk[r] = vec[rec * 5 + r];
+        line_backward_step<T>(C, dinv, up0, upd, wk, x);
+        for (int r = 0; r < 5; ++r) vec[rec * 5 + r] = x[r];
+        for (int j = 0; j < 4; ++j) { up0[j] = lfac[rec * 8 + j]; upd[j] = lfac[rec * 8 + 4 + j]; }
     }
 }
 
 // Scatter block k of the solution into the field (core.py:775-783).
 template <class T, int DIR>
-EMG_HD void line_scatter(const Axes<T, DIR> &A, int k, int i1, int i2, const T *vec, int lstride)
+EMG_HD void line_scatter(const Axes<T, DIR> &A, int k, int i1, int i2, const T *rec)
 {
     const int n0 = A.n0();
-    A.E(0)[A.idx(0, k, i1, i2)] = vec[(size_t)(k * 5 + 0) * lstride];
+    A.E(0)[A.idx(0, k, i1, i2)] = rec[0];
     if (k < n0 - 1) {
-        A.E(1)[A.idx(1, k + 1, i1 - 1, i2)] = vec[(size_t)(k * 5 + 1) * lstride];
-        A.E(1)[A.idx(1, k + 1, i1, i2)] = vec[(size_t)(k * 5 + 2) * lstride];
-        A.E(2)[A.idx(2, k + 1, i1, i2 - 1)] = vec[(size_t)(k * 5 + 3) * lstride];
-        A.E(2)[A.idx(2, k + 1, i1, i2)] = vec[(size_t)(k * 5 + 4) * lstride];
+        A.E(1)[A.idx(1, k + 1, i1 - 1, i2)] = rec[1];
+        A.E(1)[A.idx(1, k + 1, i1, i2)] = rec[2];
+        A.E(2)[A.idx(2, k + 1, i1, i2 - 1)] = rec[3];
+        A.E(2)[A.idx(2, k + 1, i1, i2)] = rec[4];
     }
 }
 

@@ -60,12 +60,10 @@ void line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac
     for_threads(emg::lineblk_grid(lc), emg::lineblk_block(), [&](int gx, int gy, int gz) {
         emg::line_rhs_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, vec);
     });
-    for_threads(emg::line_grid(lc), emg::line_block(), [&](int gx, int gy, int) {
-        emg::line_forward_thread<T>(lc.n0, lc.cntp, lc.cntq, gx, gy, f, lf, vec);
-    });
-    for_threads(emg::line_grid(lc), emg::line_block(), [&](int gx, int gy, int) {
-        emg::line_backward_thread<T>(lc.n0, lc.cntp, lc.cntq, gx, gy, f, lf, vec);
-    });
+    // the GPU runs these two with four lanes per line (kernels.hip); the arithmetic per
+    // line is that of the reference walks below
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_forward_ref<T>(lc.n0, lc.lines, lid, f, lf, vec);
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_backward_ref<T>(lc.n0, lc.lines, lid, f, lf, vec);
     for_threads(emg::lineblk_grid(lc), emg::lineblk_block(), [&](int gx, int gy, int gz) {
         emg::line_scatter_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, (const T *)vec);
     });
