@@ -117,17 +117,22 @@ __device__ __forceinline__ cplx quad_bcast(cplx x, int ln)
     return cplx(quad_bcast(x.re, ln), quad_bcast(x.im, ln));
 }
 
+// Lane j's share of a block record. Every slot is loaded from ONE array by all lanes (a
+// per-lane choice between `fac` and `vec` would be compiled into divergent branches):
+//   slots 0..2: fac[4s + j]; slot 3: fac[12 + min(j,2)]; slot 4: vec[j]; slot 5: vec[4].
 template <class T> struct QuadRec {
-    T u[5];
+    T u[6];
     double l0, ld;
     __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, int j)
     {
-#pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            const int unit = 4 * s + j;
-            const T *p = unit < 15 ? fac + rec * 15 + unit : vec + rec * 5 + (unit - 15);
-            u[s] = *p;
-        }
+        const T *f = fac + rec * 15;
+        const T *v = vec + rec * 5;
+        u[0] = f[j];
+        u[1] = f[4 + j];
+        u[2] = f[8 + j];
+        u[3] = f[12 + min(j, 2)];
+        u[4] = v[j];
+        u[5] = v[4];
         l0 = lfac[rec * 8 + j];
         ld = lfac[rec * 8 + 4 + j];
     }
@@ -136,12 +141,14 @@ template <class T> struct QuadRec {
                                            double (&bd)[4]) const
     {
 #pragma unroll
-        for (int unit = 0; unit < 20; ++unit) {
+        for (int unit = 0; unit < 15; ++unit) {
             const T val = quad_bcast(u[unit >> 2], unit & 3);
             if (unit < 10) C[unit] = val;
-            else if (unit < 15) dinv[unit - 10] = val;
-            else v[unit - 15] = val;
+            else dinv[unit - 10] = val;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = quad_bcast(u[4], r);
+        v[4] = u[5];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             b0[m] = quad_bcast(l0, m);
@@ -150,86 +157,100 @@ template <class T> struct QuadRec {
     }
 };
 
-constexpr int QD = 4;   // blocks in flight per line
+constexpr int QD = emg::LINE_PAD;   // blocks in flight per line = padding granule
 
+// quad_pick(v0..v3): lane j of every quad gets v_j. Done with bank-masked DPP moves
+// (bank = lane & 3), because a select chain on j is compiled into divergent branches.
+template <int BANK> __device__ __forceinline__ double bank_move(double old, double src)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0xE4, 0xf, 1 << BANK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0xE4, 0xf, 1 << BANK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_pick(double v0, double v1, double v2, double v3)
+{
+    double t = v0;
+    t = bank_move<1>(t, v1);
+    t = bank_move<2>(t, v2);
+    t = bank_move<3>(t, v3);
+    return t;
+}
+__device__ __forceinline__ cplx quad_pick(cplx v0, cplx v1, cplx v2, cplx v3)
+{
+    return cplx(quad_pick(v0.re, v1.re, v2.re, v3.re), quad_pick(v0.im, v1.im, v2.im, v3.im));
+}
+
+// Lane j of a quad stores entry j of a block's solution, and every lane stores entry 4 (the
+// same value to the same address): no predicate, no branch.
+template <class T> __device__ __forceinline__ void quad_store(T *o, const T (&v)[5], int j)
+{
+    o[j] = quad_pick(v[0], v[1], v[2], v[3]);
+    o[4] = v[4];
+}
+
+// The loops below are branch-free inside: loads and stores are unconditional (the records
+// are padded to a multiple of QD blocks with identity blocks, launch.h), because with
+// branches around memory operations the compiler's s_waitcnt insertion falls back to
+// vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
+// last line replicate the last line (same loads, same values stored to the same addresses).
 template <class T>
-__global__ __launch_bounds__(64) void k_line_forward(int n0, int nlines, const T *fac, const double *lfac,
+__global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const T *fac, const double *lfac,
                                                      T *vec)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const int j = gt & 3;
-    int line = gt >> 2;
-    const bool active = line < nlines;
-    if (!active) line = nlines - 1;   // keep every quad complete for the DPP exchange
+    const int line = min(gt >> 2, nlines - 1);
     QuadRec<T> ring[QD];
 #pragma unroll
-    for (int d = 0; d < QD; ++d)
-        if (d < n0) ring[d].load(fac, lfac, vec, (size_t)d * nlines + line, j);
+    for (int d = 0; d < QD; ++d) ring[d].load(fac, lfac, vec, (size_t)d * nlines + line, j);
     T w[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) w[r] = emg::zero<T>();
-    for (int k0 = 0; k0 < n0; k0 += QD) {
+    for (int k0 = 0; k0 < n0p; k0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = k0 + d;
-            if (k < n0) {
-                T C[10], dinv[5], c[5];
-                double b0[4], bd[4];
-                ring[d].gather(C, dinv, c, b0, bd);
-                if (k + QD < n0) ring[d].load(fac, lfac, vec, (size_t)(k + QD) * nlines + line, j);
-                emg::line_forward_step<T>(C, dinv, b0, bd, c, w);
-                if (active) {
-                    T *o = vec + ((size_t)k * nlines + line) * 5;
-#pragma unroll
-                    for (int r = 0; r < 5; ++r)
-                        if (((15 + r) & 3) == j) o[r] = w[r];
-                }
-            }
+            T C[10], dinv[5], c[5];
+            double b0[4], bd[4];
+            ring[d].gather(C, dinv, c, b0, bd);
+            emg::line_forward_step<T>(C, dinv, b0, bd, c, w);
+            quad_store<T>(vec + ((size_t)k * nlines + line) * 5, w, j);
+            ring[d].load(fac, lfac, vec, (size_t)min(k + QD, n0p - 1) * nlines + line, j);
         }
     }
 }
 
 template <class T>
-__global__ __launch_bounds__(64) void k_line_backward(int n0, int nlines, const T *fac, const double *lfac,
+__global__ __launch_bounds__(64) void k_line_backward(int n0p, int nlines, const T *fac, const double *lfac,
                                                       T *vec)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const int j = gt & 3;
-    int line = gt >> 2;
-    const bool active = line < nlines;
-    if (!active) line = nlines - 1;
+    const int line = min(gt >> 2, nlines - 1);
+    const int last = n0p - 1;
     QuadRec<T> ring[QD];
-    // walk kk = 0..n0-1 over the blocks k = n0-1-kk
 #pragma unroll
-    for (int d = 0; d < QD; ++d)
-        if (d < n0) ring[d].load(fac, lfac, vec, (size_t)(n0 - 1 - d) * nlines + line, j);
+    for (int d = 0; d < QD; ++d) ring[d].load(fac, lfac, vec, (size_t)(last - d) * nlines + line, j);
+    // x = 0 and B = 0: the identity padding keeps x = 0 until the first real block, where
+    // the step yields x_{n0-1} = w_{n0-1}
     T x[5];
     double up0[4], upd[4];
-    for (int k0 = 0; k0 < n0; k0 += QD) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) x[r] = emg::zero<T>();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { up0[m] = 0.0; upd[m] = 0.0; }
+    for (int k0 = 0; k0 < n0p; k0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
-            const int kk = k0 + d;
-            if (kk < n0) {
-                const int k = n0 - 1 - kk;
-                T C[10], dinv[5], wk[5];
-                double b0[4], bd[4];
-                ring[d].gather(C, dinv, wk, b0, bd);
-                if (kk + QD < n0) ring[d].load(fac, lfac, vec, (size_t)(k - QD) * nlines + line, j);
-                if (kk == 0) {
+            const int k = last - (k0 + d);
+            T C[10], dinv[5], wk[5];
+            double b0[4], bd[4];
+            ring[d].gather(C, dinv, wk, b0, bd);
+            emg::line_backward_step<T>(C, dinv, up0, upd, wk, x);
 #pragma unroll
-                    for (int r = 0; r < 5; ++r) x[r] = wk[r];          // x_{n0-1} = w_{n0-1}
-                } else {
-                    emg::line_backward_step<T>(C, dinv, up0, upd, wk, x);
-                    if (active) {
-                        T *o = vec + ((size_t)k * nlines + line) * 5;
-#pragma unroll
-                        for (int r = 0; r < 5; ++r)
-                            if (((15 + r) & 3) == j) o[r] = x[r];
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { up0[m] = b0[m]; upd[m] = bd[m]; }
-            }
+            for (int m = 0; m < 4; ++m) { up0[m] = b0[m]; upd[m] = bd[m]; }
+            quad_store<T>(vec + ((size_t)k * nlines + line) * 5, x, j);
+            ring[d].load(fac, lfac, vec, (size_t)max(k - QD, 0) * nlines + line, j);
         }
     }
 }
@@ -342,13 +363,14 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
 {
     const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
     if (lc.lines <= 0) return;
-    const dim3 bb = d3(emg::lineblk_block()), bg = d3(emg::lineblk_grid(lc));
+    const dim3 bb = d3(emg::lineblk_block());
+    const dim3 bgp = d3(emg::lineblk_grid(lc, true)), bg = d3(emg::lineblk_grid(lc, false));
     const T *f = fac + lc.fac_off;
     const double *lf = lfac + lc.lfac_off;
     const dim3 qb = d3(emg::linequad_block()), qg = d3(emg::linequad_grid(lc));
-    hipLaunchKernelGGL((k_line_rhs<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
-    hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0, lc.lines, f, lf, vec);
-    hipLaunchKernelGGL(k_line_backward<T>, qg, qb, 0, st, lc.n0, lc.lines, f, lf, vec);
+    hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
+    hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec);
+    hipLaunchKernelGGL(k_line_backward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec);
     hipLaunchKernelGGL((k_line_scatter<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, (const T *)vec);
 }
 

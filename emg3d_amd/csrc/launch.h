@@ -82,10 +82,16 @@ inline int line_np(int dir, int nx, int ny, int nz) { (void)nz; return dir == 0 
 inline int line_nq(int dir, int nx, int ny, int nz) { (void)nx; return dir == 2 ? ny : nz; }
 inline int line_n0(int dir, int nx, int ny, int nz) { return dir == 0 ? nx : dir == 1 ? ny : nz; }
 
+// The factor / rhs records of a line are padded to a multiple of LINE_PAD blocks with
+// "identity" blocks (C = 0, 1/D = 1, B = 0, rhs = 0), so that the forward / backward
+// kernels can run a LINE_PAD-times unrolled, branch-free software pipeline.
+constexpr int LINE_PAD = 4;
+EMG_HD int line_padded(int n0) { return (n0 + LINE_PAD - 1) / LINE_PAD * LINE_PAD; }
+
 // Geometry of one colour class of one direction on one level.
 struct LineClass {
-    int n0, cntp, cntq, lines;     // blocks per line, lines along p / q, total
-    size_t fac_off, lfac_off;      // element offsets of the class in the factor buffers
+    int n0, n0p, cntp, cntq, lines;   // blocks per line (real, padded), lines along p / q, total
+    size_t fac_off, lfac_off;         // element offsets of the class in the factor buffers
 };
 inline LineClass line_class(int dir, int nx, int ny, int nz, int colour)
 {
@@ -98,8 +104,9 @@ inline LineClass line_class(int dir, int nx, int ny, int nz, int colour)
         if (cc == colour) { c.cntp = cp; c.cntq = cq; c.lines = cp * cq; }
         else before += (size_t)cp * cq;
     }
-    c.fac_off = (size_t)15 * c.n0 * before;
-    c.lfac_off = (size_t)8 * c.n0 * before;
+    c.n0p = line_padded(c.n0);
+    c.fac_off = (size_t)15 * c.n0p * before;
+    c.lfac_off = (size_t)8 * c.n0p * before;
     return c;
 }
 // all lines of a direction: (np-1)(nq-1)
@@ -110,16 +117,16 @@ inline size_t line_total(int dir, int nx, int ny, int nz)
 // elements of the factor buffers and of the rhs/solution scratch of one direction
 inline size_t line_fac_elems(int dir, int nx, int ny, int nz)
 {
-    return (size_t)15 * line_n0(dir, nx, ny, nz) * line_total(dir, nx, ny, nz);
+    return (size_t)15 * line_padded(line_n0(dir, nx, ny, nz)) * line_total(dir, nx, ny, nz);
 }
 inline size_t line_lfac_elems(int dir, int nx, int ny, int nz)
 {
-    return (size_t)8 * line_n0(dir, nx, ny, nz) * line_total(dir, nx, ny, nz);
+    return (size_t)8 * line_padded(line_n0(dir, nx, ny, nz)) * line_total(dir, nx, ny, nz);
 }
 inline size_t line_vec_elems(int dir, int nx, int ny, int nz)
 {   // largest colour class (odd,odd)
     const size_t lines = (size_t)cnt_par(line_np(dir, nx, ny, nz), 1) * cnt_par(line_nq(dir, nx, ny, nz), 1);
-    return (size_t)5 * line_n0(dir, nx, ny, nz) * lines;
+    return (size_t)5 * line_padded(line_n0(dir, nx, ny, nz)) * lines;
 }
 
 // per-line kernels (setup, forward, backward): one thread per line
@@ -127,7 +134,7 @@ inline Dim3 line_block() { return Dim3{64, 1, 1}; }
 inline Dim3 line_grid(const LineClass &c) { return Dim3{cdiv(c.cntp, 64), c.cntq, 1}; }
 // per-(line, block) kernels (rhs, scatter): thread (tp, tq, k)
 inline Dim3 lineblk_block() { return Dim3{64, 1, 1}; }
-inline Dim3 lineblk_grid(const LineClass &c) { return Dim3{cdiv(c.cntp, 64), c.cntq, c.n0}; }
+inline Dim3 lineblk_grid(const LineClass &c, bool padded) { return Dim3{cdiv(c.cntp, 64), c.cntq, padded ? c.n0p : c.n0}; }
 
 // (i1, i2, lid) of thread (tp, tq) in colour class `colour`; false if out of range
 template <int DIR>
@@ -149,7 +156,7 @@ EMG_HD void line_setup_thread(const Level<T> &L, int colour, int cntp, int cntq,
 {
     int i1, i2, lid;
     if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
-    line_setup<T, DIR>(L, i1, i2, fac, lfac, cntp * cntq, lid);
+    line_setup<T, DIR>(L, i1, i2, fac, lfac, cntp * cntq, lid, line_padded(Axes<T, DIR>(L).n0()));
 }
 
 template <class T, int DIR>
@@ -159,7 +166,12 @@ EMG_HD void line_rhs_thread(const Level<T> &L, int colour, int cntp, int cntq, i
     if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
     const Axes<T, DIR> A(L);
     T rhs[5];
-    line_rhs<T, DIR>(A, k, i1, i2, rhs);
+    if (k < A.n0()) {
+        line_rhs<T, DIR>(A, k, i1, i2, rhs);
+    } else {   // padding block
+#pragma unroll
+        for (int r = 0; r < 5; ++r) rhs[r] = zero<T>();
+    }
     T *o = vec + ((size_t)k * (cntp * cntq) + lid) * 5;
 #pragma unroll
     for (int r = 0; r < 5; ++r) o[r] = rhs[r];

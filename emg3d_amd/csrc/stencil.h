@@ -599,7 +599,7 @@ template <class T> EMG_HD void ldlt5_solve(const T (&C)[10], const T (&dinv)[5],
 
 // Setup of one line: block factorisation, stored in (fac, lfac). Sequential along the line.
 template <class T, int DIR>
-EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int nlines, int lid)
+EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int nlines, int lid, int n0p)
 {
     const Axes<T, DIR> A(L);
     const int n0 = A.n0();
@@ -653,6 +653,14 @@ EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, 
             // the last block has a single row: its B has a first row only
             lf[3 + m] = (k > 0 && k < n0 - 1) ? leftd[m] : 0.0;
         }
+    }
+    // identity padding blocks (launch.h: LINE_PAD)
+    for (int k = n0; k < n0p; ++k) {
+        T *f = fac + ((size_t)k * nlines + lid) * 15;
+        double *lf = lfac + ((size_t)k * nlines + lid) * 8;
+        for (int j = 0; j < 10; ++j) f[j] = zero<T>();
+        for (int j = 0; j < 5; ++j) f[10 + j] = T(1.0);
+        for (int j = 0; j < 8; ++j) lf[j] = 0.0;
     }
 }
 
