@@ -90,77 +90,34 @@ __global__ __launch_bounds__(64) void k_line_rhs(emg::Level<T> L, int colour, in
 }
 
 // ---- forward / backward substitution along the lines: four lanes per line -------------
-// Lane j of a quad loads the units u = 4s + j (s = 0..4) of a block record (15 factor
-// entries + 5 rhs/solution entries) and the coupling pair (B(0,j+1), B(j+1,j+1)); the quad
-// then all-gathers the record through DPP quad_perm broadcasts and every lane evaluates
-// the (tiny) 5x5 step redundantly. Records of the next QD blocks are kept in flight in a
-// register ring, so that a wave has 16 lines x QD blocks x 464 B outstanding instead of
-// 64 lines x 1 block: the block recurrence is bound by HBM latency, not by arithmetic.
-template <int LN> __device__ __forceinline__ double quad_bcast_lane(double x)
+// The recurrence along a line is sequential and latency-bound; its per-block critical
+// path is what sets the kernel time. Lane j of a quad owns ROW j of the block: it loads
+// row j of T_k (5 entries, straight from the packed symmetric record), computes entry j of
+// the 5-vectors, and the quad exchanges the 4+1 entries with DPP quad_perm moves; entry 4
+// is formed from the partial products T(j,4) c_j that the lanes already hold (quad sum).
+// Records of the next QD blocks are kept in flight in a register ring, so that a wave has
+// 16 lines x QD blocks outstanding instead of 64 lines x 1 block.
+template <int CTRL> __device__ __forceinline__ double dpp_move(double x)
 {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_mov_dpp(lo, LN * 0x55, 0xf, 0xf, true);   // quad_perm:[LN,LN,LN,LN]
-    hi = __builtin_amdgcn_mov_dpp(hi, LN * 0x55, 0xf, 0xf, true);
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double quad_bcast(double x, int ln)
+template <int CTRL> __device__ __forceinline__ cplx dpp_move(cplx x)
 {
-    switch (ln) {   // ln is a compile-time constant after unrolling
-        case 0: return quad_bcast_lane<0>(x);
-        case 1: return quad_bcast_lane<1>(x);
-        case 2: return quad_bcast_lane<2>(x);
-        default: return quad_bcast_lane<3>(x);
-    }
+    return cplx(dpp_move<CTRL>(x.re), dpp_move<CTRL>(x.im));
 }
-__device__ __forceinline__ cplx quad_bcast(cplx x, int ln)
+// broadcast lane LN of every quad
+template <int LN, class T> __device__ __forceinline__ T quad_bcast(T x) { return dpp_move<LN * 0x55>(x); }
+// sum over the four lanes of every quad (result in all lanes)
+template <class T> __device__ __forceinline__ T quad_sum(T x)
 {
-    return cplx(quad_bcast(x.re, ln), quad_bcast(x.im, ln));
+    x = x + dpp_move<0xB1>(x);   // quad_perm:[1,0,3,2]
+    x = x + dpp_move<0x4E>(x);   // quad_perm:[2,3,0,1]
+    return x;
 }
-
-// Lane j's share of a block record. Every slot is loaded from ONE array by all lanes (a
-// per-lane choice between `fac` and `vec` would be compiled into divergent branches):
-//   slots 0..2: fac[4s + j]; slot 3: fac[12 + min(j,2)]; slot 4: vec[j]; slot 5: vec[4].
-template <class T> struct QuadRec {
-    T u[6];
-    double l0, ld;
-    __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, int j)
-    {
-        const T *f = fac + rec * 15;
-        const T *v = vec + rec * 5;
-        u[0] = f[j];
-        u[1] = f[4 + j];
-        u[2] = f[8 + j];
-        u[3] = f[12 + min(j, 2)];
-        u[4] = v[j];
-        u[5] = v[4];
-        l0 = lfac[rec * 8 + j];
-        ld = lfac[rec * 8 + 4 + j];
-    }
-    // all-gather inside the quad
-    __device__ __forceinline__ void gather(T (&C)[10], T (&dinv)[5], T (&v)[5], double (&b0)[4],
-                                           double (&bd)[4]) const
-    {
-#pragma unroll
-        for (int unit = 0; unit < 15; ++unit) {
-            const T val = quad_bcast(u[unit >> 2], unit & 3);
-            if (unit < 10) C[unit] = val;
-            else dinv[unit - 10] = val;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = quad_bcast(u[4], r);
-        v[4] = u[5];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            b0[m] = quad_bcast(l0, m);
-            bd[m] = quad_bcast(ld, m);
-        }
-    }
-};
-
-constexpr int QD = emg::LINE_PAD;   // blocks in flight per line = padding granule
-
-// quad_pick(v0..v3): lane j of every quad gets v_j. Done with bank-masked DPP moves
-// (bank = lane & 3), because a select chain on j is compiled into divergent branches.
+// quad_pick(v0..v3): lane j of every quad gets v_j. Bank-masked DPP moves (bank = lane & 3):
+// a select chain on j would be compiled into divergent branches.
 template <int BANK> __device__ __forceinline__ double bank_move(double old, double src)
 {
     int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0xE4, 0xf, 1 << BANK, false);
@@ -180,27 +137,46 @@ __device__ __forceinline__ cplx quad_pick(cplx v0, cplx v1, cplx v2, cplx v3)
     return cplx(quad_pick(v0.re, v1.re, v2.re, v3.re), quad_pick(v0.im, v1.im, v2.im, v3.im));
 }
 
-// Lane j of a quad stores entry j of a block's solution, and every lane stores entry 4 (the
-// same value to the same address): no predicate, no branch.
-template <class T> __device__ __forceinline__ void quad_store(T *o, const T (&v)[5], int j)
-{
-    o[j] = quad_pick(v[0], v[1], v[2], v[3]);
-    o[4] = v[4];
-}
+// Lane j's share of one block record (all loads unconditional, addresses per lane).
+template <class T> struct QuadRow {
+    T t[5];        // T_k(j, 0..4)
+    T t44;         // T_k(4,4)
+    T v, v4;       // vec[j], vec[4]
+    double b[8];   // B_k: B(0,m) m=1..4, then B(m,m) m=1..4
+    __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, int j)
+    {
+        const T *f = fac + rec * 15;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int idx = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
+            t[m] = f[idx];
+        }
+        t44 = f[14];
+        v = vec[rec * 5 + j];
+        v4 = vec[rec * 5 + 4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) b[m] = lfac[rec * 8 + m];
+    }
+};
+
+constexpr int QD = emg::LINE_PAD;   // blocks in flight per line = padding granule
 
 // The loops below are branch-free inside: loads and stores are unconditional (the records
 // are padded to a multiple of QD blocks with identity blocks, launch.h), because with
 // branches around memory operations the compiler's s_waitcnt insertion falls back to
 // vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
-// last line replicate the last line (same loads, same values stored to the same addresses).
+// last line walk the last line again but store into a dummy area behind the records.
 template <class T>
 __global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const T *fac, const double *lfac,
-                                                     T *vec)
+                                                     T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const int j = gt & 3;
+    const bool active = (gt >> 2) < nlines;
     const int line = min(gt >> 2, nlines - 1);
-    QuadRec<T> ring[QD];
+    T *const obase = active ? vec + (size_t)line * 5 : dummy + (threadIdx.x >> 2) * 5;
+    const size_t ostride = active ? (size_t)nlines * 5 : 0;
+    QuadRow<T> ring[QD];
 #pragma unroll
     for (int d = 0; d < QD; ++d) ring[d].load(fac, lfac, vec, (size_t)d * nlines + line, j);
     T w[5];
@@ -210,11 +186,25 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const 
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = k0 + d;
-            T C[10], dinv[5], c[5];
-            double b0[4], bd[4];
-            ring[d].gather(C, dinv, c, b0, bd);
-            emg::line_forward_step<T>(C, dinv, b0, bd, c, w);
-            quad_store<T>(vec + ((size_t)k * nlines + line) * 5, w, j);
+            const QuadRow<T> &q = ring[d];
+            // c_j = rhs_j - (B w_prev)_j ; row 0: sum_m B(0,m) w_m ; row m: B(m,m) w_m
+            T bw0 = emg::zero<T>();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bw0 += q.b[m] * w[m + 1];
+            const double dj = quad_pick(0.0, q.b[4], q.b[5], q.b[6]);
+            const T wj = quad_pick(w[0], w[1], w[2], w[3]);
+            const T bwj = dj * wj;
+            const T cj = q.v - quad_pick(bw0, bwj, bwj, bwj);
+            const T c4 = q.v4 - q.b[7] * w[4];
+            const T c0 = quad_bcast<0>(cj), c1 = quad_bcast<1>(cj), c2 = quad_bcast<2>(cj), c3 = quad_bcast<3>(cj);
+            // w_j = sum_m T(j,m) c_m ; w_4 from the partial products T(j,4) c_j
+            const T wn = q.t[0] * c0 + q.t[1] * c1 + (q.t[2] * c2 + q.t[3] * c3) + q.t[4] * c4;
+            const T w4 = quad_sum(q.t[4] * cj) + q.t44 * c4;
+            w[0] = quad_bcast<0>(wn); w[1] = quad_bcast<1>(wn); w[2] = quad_bcast<2>(wn); w[3] = quad_bcast<3>(wn);
+            w[4] = w4;
+            T *o = obase + (size_t)k * ostride;
+            o[j] = wn;
+            o[4] = w4;
             ring[d].load(fac, lfac, vec, (size_t)min(k + QD, n0p - 1) * nlines + line, j);
         }
     }
@@ -222,34 +212,47 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const 
 
 template <class T>
 __global__ __launch_bounds__(64) void k_line_backward(int n0p, int nlines, const T *fac, const double *lfac,
-                                                      T *vec)
+                                                      T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const int j = gt & 3;
+    const bool active = (gt >> 2) < nlines;
     const int line = min(gt >> 2, nlines - 1);
+    T *const obase = active ? vec + (size_t)line * 5 : dummy + (threadIdx.x >> 2) * 5;
+    const size_t ostride = active ? (size_t)nlines * 5 : 0;
     const int last = n0p - 1;
-    QuadRec<T> ring[QD];
+    QuadRow<T> ring[QD];
 #pragma unroll
     for (int d = 0; d < QD; ++d) ring[d].load(fac, lfac, vec, (size_t)(last - d) * nlines + line, j);
     // x = 0 and B = 0: the identity padding keeps x = 0 until the first real block, where
     // the step yields x_{n0-1} = w_{n0-1}
     T x[5];
-    double up0[4], upd[4];
+    double up[8];
 #pragma unroll
     for (int r = 0; r < 5; ++r) x[r] = emg::zero<T>();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { up0[m] = 0.0; upd[m] = 0.0; }
+    for (int m = 0; m < 8; ++m) up[m] = 0.0;
     for (int k0 = 0; k0 < n0p; k0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = last - (k0 + d);
-            T C[10], dinv[5], wk[5];
-            double b0[4], bd[4];
-            ring[d].gather(C, dinv, wk, b0, bd);
-            emg::line_backward_step<T>(C, dinv, up0, upd, wk, x);
+            const QuadRow<T> &q = ring[d];
+            // h = B_{k+1}^T x_{k+1}: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
+            const double aj = quad_pick(0.0, up[0], up[1], up[2]);
+            const double dj = quad_pick(0.0, up[4], up[5], up[6]);
+            const T xj = quad_pick(x[0], x[1], x[2], x[3]);
+            const T hj = aj * x[0] + dj * xj;
+            const T h4 = up[3] * x[0] + up[7] * x[4];
+            const T h0 = quad_bcast<0>(hj), h1 = quad_bcast<1>(hj), h2 = quad_bcast<2>(hj), h3 = quad_bcast<3>(hj);
+            const T xn = q.v - (q.t[0] * h0 + q.t[1] * h1 + (q.t[2] * h2 + q.t[3] * h3) + q.t[4] * h4);
+            const T x4 = q.v4 - (quad_sum(q.t[4] * hj) + q.t44 * h4);
+            x[0] = quad_bcast<0>(xn); x[1] = quad_bcast<1>(xn); x[2] = quad_bcast<2>(xn); x[3] = quad_bcast<3>(xn);
+            x[4] = x4;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { up0[m] = b0[m]; upd[m] = bd[m]; }
-            quad_store<T>(vec + ((size_t)k * nlines + line) * 5, x, j);
+            for (int m = 0; m < 8; ++m) up[m] = q.b[m];
+            T *o = obase + (size_t)k * ostride;
+            o[j] = xn;
+            o[4] = x4;
             ring[d].load(fac, lfac, vec, (size_t)max(k - QD, 0) * nlines + line, j);
         }
     }
@@ -368,9 +371,10 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const T *f = fac + lc.fac_off;
     const double *lf = lfac + lc.lfac_off;
     const dim3 qb = d3(emg::linequad_block()), qg = d3(emg::linequad_grid(lc));
+    const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
     hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
-    hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec);
-    hipLaunchKernelGGL(k_line_backward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec);
+    hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
+    hipLaunchKernelGGL(k_line_backward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
     hipLaunchKernelGGL((k_line_scatter<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, (const T *)vec);
 }
 

@@ -86,6 +86,9 @@ inline int line_n0(int dir, int nx, int ny, int nz) { return dir == 0 ? nx : dir
 // "identity" blocks (C = 0, 1/D = 1, B = 0, rhs = 0), so that the forward / backward
 // kernels can run a LINE_PAD-times unrolled, branch-free software pipeline.
 constexpr int LINE_PAD = 4;
+// elements at the tail of the rhs/solution scratch that absorb the stores of the surplus
+// quads of the last wave of the forward / backward kernels (16 quads x 5 entries)
+constexpr int LINE_DUMMY = 80;
 EMG_HD int line_padded(int n0) { return (n0 + LINE_PAD - 1) / LINE_PAD * LINE_PAD; }
 
 // Geometry of one colour class of one direction on one level.
@@ -126,7 +129,7 @@ inline size_t line_lfac_elems(int dir, int nx, int ny, int nz)
 inline size_t line_vec_elems(int dir, int nx, int ny, int nz)
 {   // largest colour class (odd,odd)
     const size_t lines = (size_t)cnt_par(line_np(dir, nx, ny, nz), 1) * cnt_par(line_nq(dir, nx, ny, nz), 1);
-    return (size_t)5 * line_padded(line_n0(dir, nx, ny, nz)) * lines;
+    return (size_t)5 * line_padded(line_n0(dir, nx, ny, nz)) * lines + LINE_DUMMY;
 }
 
 // per-line kernels (setup, forward, backward): one thread per line

@@ -397,19 +397,24 @@ template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, 
 // It depends on eta, zeta and h only -- NOT on the field -- so its block factorisation
 //     S_0 = M_0,   S_k = M_k - B_k S_{k-1}^{-1} B_k^T,   S_k = C_k D_k C_k^T  (LDL^T, no pivoting)
 // is computed ONCE per level and direction (line_setup) and kept in HBM (MI355X has the
-// capacity: 304 B per cell and direction); it is the factorisation core.solve
-// (core.py:1481-1616) performs on every call, in block form. A smoothing sweep then is
+// capacity: 304 B per cell and direction) in the form of the explicit inverses
+// T_k = S_k^{-1} (obtained from the LDL^T factors by five triangular solves); it is the
+// factorisation core.solve (core.py:1481-1616) performs on every call, in block form.
+// Storing T_k instead of (C_k, D_k) turns the two dependent triangular solves per block
+// into five independent dot products -- the sequential recurrence along the line is
+// latency-bound, so the depth of the dependency chain per block is what matters.
+// A smoothing sweep then is
 //     (1) rhs_k  : source + terms of edges NOT on the line          (parallel, line_rhs)
-//     (2) forward: c_k = rhs_k - B_k w_{k-1},  w_k = S_k^{-1} c_k    (per line, line_forward)
-//     (3) backward: x_k = w_k - S_k^{-1} B_{k+1}^T x_{k+1}           (per line, line_backward)
+//     (2) forward: c_k = rhs_k - B_k w_{k-1},  w_k = T_k c_k         (per line)
+//     (3) backward: x_k = w_k - T_k B_{k+1}^T x_{k+1}                (per line)
 //     (4) scatter x into the field                                   (parallel, line_scatter)
 // The reference's `amat`/`bvec`/`middle`/`left` arrays (core.py:586-593) never exist.
 //
 // Storage: one record per (block k, line lid) of a colour class with `nlines` lines,
 // block-major so that a line's consecutive blocks are `nlines` records apart and the
 // lines of a wave sit next to each other:
-//   fac [(k*nlines + lid)*15 + j]   j = 0..9: C_k strictly lower, row-major
-//                                   (1,0),(2,0),(2,1),(3,0)...(4,3); j = 10..14: 1/D_k
+//   fac [(k*nlines + lid)*15 + j]   T_k = S_k^{-1}, symmetric, lower triangle packed
+//                                   row-major: T(r,m), m <= r, at j = r(r+1)/2 + m
 //   lfac[(k*nlines + lid)*8  + j]   j = 0..3: B_k(0, m), m = 1..4; j = 4..7: B_k(m, m)
 //   vec [(k*nlines + lid)*5  + r]   rhs -> w -> x in place
 // The forward/backward kernels stream these records with FOUR lanes per line (each lane
@@ -643,10 +648,16 @@ EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, 
         ldlt5<T>(S, (k == n0 - 1) ? 1 : 5, C, dinv);
         T *f = fac + ((size_t)k * nlines + lid) * 15;
         double *lf = lfac + ((size_t)k * nlines + lid) * 8;
+        // T_k = S_k^{-1}: column m from the solve with e_m; lower triangle packed
 #pragma unroll
-        for (int j = 0; j < 10; ++j) f[j] = C[j];
+        for (int m = 0; m < 5; ++m) {
+            T col[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) f[10 + j] = dinv[j];
+            for (int r = 0; r < 5; ++r) col[r] = (r == m) ? T(1.0) : zero<T>();
+            ldlt5_solve<T>(C, dinv, col);
+#pragma unroll
+            for (int r = m; r < 5; ++r) f[tri(r + 1, m)] = col[r];
+        }
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
             lf[m - 1] = (k > 0) ? left0[m] : 0.0;
@@ -658,17 +669,20 @@ EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, 
     for (int k = n0; k < n0p; ++k) {
         T *f = fac + ((size_t)k * nlines + lid) * 15;
         double *lf = lfac + ((size_t)k * nlines + lid) * 8;
-        for (int j = 0; j < 10; ++j) f[j] = zero<T>();
-        for (int j = 0; j < 5; ++j) f[10 + j] = T(1.0);
+        for (int r = 0; r < 5; ++r)
+            for (int m = 0; m <= r; ++m) f[tri(r + 1, m)] = (r == m) ? T(1.0) : zero<T>();
         for (int j = 0; j < 8; ++j) lf[j] = 0.0;
     }
 }
 
-// One block of the forward substitution: c holds rhs_k on entry and w_k = S_k^{-1}(rhs_k -
-// B_k w_{k-1}) on exit; w is w_{k-1} on entry and w_k on exit.
+// packed index of T(r,m) = T(m,r)
+EMG_HD constexpr int sym(int r, int m) { return r >= m ? r * (r + 1) / 2 + m : m * (m + 1) / 2 + r; }
+
+// One block of the forward substitution: c holds rhs_k on entry; w is w_{k-1} on entry
+// and w_k = T_k (rhs_k - B_k w_{k-1}) on exit.
 template <class T>
-EMG_HD void line_forward_step(const T (&C)[10], const T (&dinv)[5], const double (&l0)[4],
-                              const double (&ld)[4], T (&c)[5], T (&w)[5])
+EMG_HD void line_forward_step(const T (&Tk)[15], const double (&l0)[4], const double (&ld)[4], T (&c)[5],
+                              T (&w)[5])
 {
     T v0 = zero<T>();
 #pragma unroll
@@ -676,24 +690,32 @@ EMG_HD void line_forward_step(const T (&C)[10], const T (&dinv)[5], const double
     c[0] -= v0;
 #pragma unroll
     for (int m = 1; m < 5; ++m) c[m] -= ld[m - 1] * w[m];
-    ldlt5_solve<T>(C, dinv, c);
 #pragma unroll
-    for (int r = 0; r < 5; ++r) w[r] = c[r];
+    for (int r = 0; r < 5; ++r) {
+        T acc = zero<T>();
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc += Tk[sym(r, m)] * c[m];
+        w[r] = acc;
+    }
 }
 
 // One block of the backward substitution: x is x_{k+1} on entry and
-// x_k = w_k - S_k^{-1} B_{k+1}^T x_{k+1} on exit; (up0, upd) are B_{k+1}.
+// x_k = w_k - T_k B_{k+1}^T x_{k+1} on exit; (up0, upd) are B_{k+1}.
 template <class T>
-EMG_HD void line_backward_step(const T (&C)[10], const T (&dinv)[5], const double (&up0)[4],
-                               const double (&upd)[4], const T (&wk)[5], T (&x)[5])
+EMG_HD void line_backward_step(const T (&Tk)[15], const double (&up0)[4], const double (&upd)[4],
+                               const T (&wk)[5], T (&x)[5])
 {
     T h[5];
     h[0] = zero<T>();
 #pragma unroll
     for (int m = 1; m < 5; ++m) h[m] = up0[m - 1] * x[0] + upd[m - 1] * x[m];
-    ldlt5_solve<T>(C, dinv, h);
 #pragma unroll
-    for (int r = 0; r < 5; ++r) x[r] = wk[r] - h[r];
+    for (int r = 0; r < 5; ++r) {
+        T acc = zero<T>();
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc += Tk[sym(r, m)] * h[m];
+        x[r] = wk[r] - acc;
+    }
 }
 
 // Reference walk of one line (one thread per line): used by the CPU emulation of the
@@ -706,13 +728,12 @@ EMG_HD void line_forward_ref(int n0, int nlines, int lid, const T *fac, const do
     for (int r = 0; r < 5; ++r) w[r] = zero<T>();
     for (int k = 0; k < n0; ++k) {
         const size_t rec = (size_t)k * nlines + lid;
-        T C[10], dinv[5], c[5];
+        T Tk[15], c[5];
         double l0[4], ld[4];
-        for (int j = 0; j < 10; ++j) C[j] = fac[rec * 15 + j];
-        for (int j = 0; j < 5; ++j) dinv[j] = fac[rec * 15 + 10 + j];
+        for (int j = 0; j < 15; ++j) Tk[j] = fac[rec * 15 + j];
         for (int j = 0; j < 4; ++j) { l0[j] = lfac[rec * 8 + j]; ld[j] = lfac[rec * 8 + 4 + j]; }
         for (int r = 0; r < 5; ++r) c[r] = vec[rec * 5 + r];
-        line_forward_step<T>(C, dinv, l0, ld, c, w);
+        line_forward_step<T>(Tk, l0, ld, c, w);
         for (int r = 0; r < 5; ++r) vec[rec * 5 + r] = w[r];
     }
 }
@@ -722,18 +743,14 @@ EMG_HD void line_backward_ref(int n0, int nlines, int lid, const T *fac, const d
 {
     T x[5];
     double up0[4], upd[4];
-    {
-        const size_t rec = (size_t)(n0 - 1) * nlines + lid;
-        for (int r = 0; r < 5; ++r) x[r] = vec[rec * 5 + r];          // x_{n0-1} = w_{n0-1}
-        for (int j = 0; j < 4; ++j) { up0[j] = lfac[rec * 8 + j]; upd[j] = lfac[rec * 8 + 4 + j]; }
-    }
-    for (int k = n0 - 2; k >= 0; --k) {
+    for (int r = 0; r < 5; ++r) x[r] = zero<T>();
+    for (int j = 0; j < 4; ++j) { up0[j] = 0.0; upd[j] = 0.0; }
+    for (int k = n0 - 1; k >= 0; --k) {
         const size_t rec = (size_t)k * nlines + lid;
-        T C[10], dinv[5], wk[5];
-        for (int j = 0; j < 10; ++j) C[j] = fac[rec * 15 + j];
-        for (int j = 0; j < 5; ++j) dinv[j] = fac[rec * 15 + 10 + j];
+        T Tk[15], wk[5];
+        for (int j = 0; j < 15; ++j) Tk[j] = fac[rec * 15 + j];
         for (int r = 0; r < 5; ++r) wk[r] = vec[rec * 5 + r];
-        line_backward_step<T>(C, dinv, up0, upd, wk, x);
+        line_backward_step<T>(Tk, up0, upd, wk, x);
         for (int r = 0; r < 5; ++r) vec[rec * 5 + r] = x[r];
         for (int j = 0; j < 4; ++j) { up0[j] = lfac[rec * 8 + j]; upd[j] = lfac[rec * 8 + 4 + j]; }
     }
