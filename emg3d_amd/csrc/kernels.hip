@@ -116,33 +116,14 @@ template <class T> __device__ __forceinline__ T quad_sum(T x)
     x = x + dpp_move<0x4E>(x);   // quad_perm:[2,3,0,1]
     return x;
 }
-// quad_pick(v0..v3): lane j of every quad gets v_j. Bank-masked DPP moves (bank = lane & 3):
-// a select chain on j would be compiled into divergent branches.
-template <int BANK> __device__ __forceinline__ double bank_move(double old, double src)
-{
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0xE4, 0xf, 1 << BANK, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0xE4, 0xf, 1 << BANK, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_pick(double v0, double v1, double v2, double v3)
-{
-    double t = v0;
-    t = bank_move<1>(t, v1);
-    t = bank_move<2>(t, v2);
-    t = bank_move<3>(t, v3);
-    return t;
-}
-__device__ __forceinline__ cplx quad_pick(cplx v0, cplx v1, cplx v2, cplx v3)
-{
-    return cplx(quad_pick(v0.re, v1.re, v2.re, v3.re), quad_pick(v0.im, v1.im, v2.im, v3.im));
-}
-
 // Lane j's share of one block record (all loads unconditional, addresses per lane).
 template <class T> struct QuadRow {
-    T t[5];        // T_k(j, 0..4)
-    T t44;         // T_k(4,4)
-    T v, v4;       // vec[j], vec[4]
-    double b[8];   // B_k: B(0,m) m=1..4, then B(m,m) m=1..4
+    T t[5];          // T_k(j, 0..4)
+    T t44;           // T_k(4,4)
+    T v, v4;         // vec[j], vec[4]
+    double l0[4];    // B_k(0, m), m = 1..4           (row 0 of B_k; used by lane 0 / entry 4)
+    double bA, bD;   // B_k(0, j), B_k(j, j) for lane j >= 1 (lane 0: entries of m = 1, masked out)
+    double d4;       // B_k(4, 4)
     __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, int j)
     {
         const T *f = fac + rec * 15;
@@ -154,8 +135,13 @@ template <class T> struct QuadRow {
         t44 = f[14];
         v = vec[rec * 5 + j];
         v4 = vec[rec * 5 + 4];
+        const double *lf = lfac + rec * 8;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) b[m] = lfac[rec * 8 + m];
+        for (int m = 0; m < 4; ++m) l0[m] = lf[m];
+        const int jm = max(j, 1) - 1;
+        bA = lf[jm];
+        bD = lf[4 + jm];
+        d4 = lf[7];
     }
 };
 
@@ -182,26 +168,26 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const 
     T w[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) w[r] = emg::zero<T>();
+    T wmine = emg::zero<T>();                    // this lane's own entry of w
+    const double nz = j != 0 ? 1.0 : 0.0, is0 = 1.0 - nz;
     for (int k0 = 0; k0 < n0p; k0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = k0 + d;
             const QuadRow<T> &q = ring[d];
-            // c_j = rhs_j - (B w_prev)_j ; row 0: sum_m B(0,m) w_m ; row m: B(m,m) w_m
+            // c_j = rhs_j - (B w_prev)_j ; row 0: sum_m B(0,m) w_m (lane 0) ; row j: B(j,j) w_j
             T bw0 = emg::zero<T>();
 #pragma unroll
-            for (int m = 0; m < 4; ++m) bw0 += q.b[m] * w[m + 1];
-            const double dj = quad_pick(0.0, q.b[4], q.b[5], q.b[6]);
-            const T wj = quad_pick(w[0], w[1], w[2], w[3]);
-            const T bwj = dj * wj;
-            const T cj = q.v - quad_pick(bw0, bwj, bwj, bwj);
-            const T c4 = q.v4 - q.b[7] * w[4];
+            for (int m = 0; m < 4; ++m) bw0 += q.l0[m] * w[m + 1];
+            const T cj = q.v - ((q.bD * nz) * wmine + is0 * bw0);
+            const T c4 = q.v4 - q.d4 * w[4];
             const T c0 = quad_bcast<0>(cj), c1 = quad_bcast<1>(cj), c2 = quad_bcast<2>(cj), c3 = quad_bcast<3>(cj);
             // w_j = sum_m T(j,m) c_m ; w_4 from the partial products T(j,4) c_j
             const T wn = q.t[0] * c0 + q.t[1] * c1 + (q.t[2] * c2 + q.t[3] * c3) + q.t[4] * c4;
             const T w4 = quad_sum(q.t[4] * cj) + q.t44 * c4;
             w[0] = quad_bcast<0>(wn); w[1] = quad_bcast<1>(wn); w[2] = quad_bcast<2>(wn); w[3] = quad_bcast<3>(wn);
             w[4] = w4;
+            wmine = wn;
             T *o = obase + (size_t)k * ostride;
             o[j] = wn;
             o[4] = w4;
@@ -227,29 +213,26 @@ __global__ __launch_bounds__(64) void k_line_backward(int n0p, int nlines, const
     // x = 0 and B = 0: the identity padding keeps x = 0 until the first real block, where
     // the step yields x_{n0-1} = w_{n0-1}
     T x[5];
-    double up[8];
 #pragma unroll
     for (int r = 0; r < 5; ++r) x[r] = emg::zero<T>();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) up[m] = 0.0;
+    T xmine = emg::zero<T>();                    // this lane's own entry of x
+    double upA = 0.0, upD = 0.0, up03 = 0.0, up44 = 0.0;   // entries of B_{k+1}
+    const double nz = j != 0 ? 1.0 : 0.0;
     for (int k0 = 0; k0 < n0p; k0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = last - (k0 + d);
             const QuadRow<T> &q = ring[d];
             // h = B_{k+1}^T x_{k+1}: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
-            const double aj = quad_pick(0.0, up[0], up[1], up[2]);
-            const double dj = quad_pick(0.0, up[4], up[5], up[6]);
-            const T xj = quad_pick(x[0], x[1], x[2], x[3]);
-            const T hj = aj * x[0] + dj * xj;
-            const T h4 = up[3] * x[0] + up[7] * x[4];
+            const T hj = (upA * nz) * x[0] + (upD * nz) * xmine;
+            const T h4 = up03 * x[0] + up44 * x[4];
             const T h0 = quad_bcast<0>(hj), h1 = quad_bcast<1>(hj), h2 = quad_bcast<2>(hj), h3 = quad_bcast<3>(hj);
             const T xn = q.v - (q.t[0] * h0 + q.t[1] * h1 + (q.t[2] * h2 + q.t[3] * h3) + q.t[4] * h4);
             const T x4 = q.v4 - (quad_sum(q.t[4] * hj) + q.t44 * h4);
             x[0] = quad_bcast<0>(xn); x[1] = quad_bcast<1>(xn); x[2] = quad_bcast<2>(xn); x[3] = quad_bcast<3>(xn);
             x[4] = x4;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) up[m] = q.b[m];
+            xmine = xn;
+            upA = q.bA; upD = q.bD; up03 = q.l0[3]; up44 = q.d4;
             T *o = obase + (size_t)k * ostride;
             o[j] = xn;
             o[4] = x4;
