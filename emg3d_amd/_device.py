@@ -60,6 +60,9 @@ class Workspace:
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
 
     def need_gs(self, nbytes):
+        """Line-smoother scratch. Sized once for the largest request of the hierarchy
+        (DeviceLevel.from_host reserves the top level's maximum over the three directions):
+        captured HIP graphs hold its address, so it must never be re-allocated later."""
         if nbytes > self.gs_bytes:
             self.gs_scratch = None   # release before growing
             self.gs_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -115,9 +118,13 @@ class DeviceLevel:
             if key not in up:      # preserves aliasing of eta_x/eta_y/eta_z
                 up[key] = torch.from_numpy(np.asfortranarray(a, dtype=dt).ravel('F').copy()).to(device)
             return up[key]
-        return cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case,
-                   upload(vmodel.eta_x, ndt), upload(vmodel.eta_y, ndt), upload(vmodel.eta_z, ndt),
-                   upload(vmodel.zeta, np.float64), dtype, work, device)
+        top = cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case,
+                  upload(vmodel.eta_x, ndt), upload(vmodel.eta_y, ndt), upload(vmodel.eta_z, ndt),
+                  upload(vmodel.zeta, np.float64), dtype, work, device)
+        nx, ny, nz = top.grid.shape_cells
+        work.need_gs(max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
+                         for lr in (1, 2, 3)))
+        return top
 
     @property
     def r(self):

@@ -15,6 +15,7 @@ Differences from the reference that are intended:
 * coarse grids / models / weights are built once per (level, sc_dir) and reused.
 """
 import itertools
+import os
 import time
 from dataclasses import dataclass
 from datetime import datetime, timedelta
@@ -251,6 +252,37 @@ def _smooth(lv, nu, lr_dir, var):
     var.smoother_cell_sweeps += nu * ndir * lv.n_cells
 
 
+# The coarse-grid correction (everything below level 0) consists of hundreds of short,
+# launch-bound kernels whose sequence depends only on (sc_dir, lr_dir): it is captured once
+# per variant into a HIP graph and replayed (MI355X_MICROARCH.md: a dependent kernel
+# boundary costs ~1.5 us inside a graph against ~5-10 us of host time per eager launch).
+_USE_GRAPHS = os.environ.get('EMG3D_AMD_GRAPHS', '1') != '0'
+
+
+def _coarse_correction_graphed(clv, var, new_cycmax):
+    """_multigrid(clv, var, 1, new_cycmax) through a HIP graph, captured at its second
+    occurrence (the first, eager one builds all levels, factors and scratch it touches)."""
+    cache = clv.__dict__.setdefault('_graphs', {})
+    key = (int(var.sc_dir), int(var.lr_dir), new_cycmax, var.cycle, var.nu_pre, var.nu_post,
+           var.nu_coarse, tuple(int(c) for c in var.clevel))
+    entry = cache.get(key)
+    if entry is None:                       # first time: eager, remember the work it does
+        w0 = var.smoother_cell_sweeps
+        _multigrid(clv, var, 1, new_cycmax)
+        cache[key] = {'work': var.smoother_cell_sweeps - w0, 'graph': None}
+        return
+    if entry['graph'] is None:
+        w0 = var.smoother_cell_sweeps
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            _multigrid(clv, var, 1, new_cycmax)
+        var.smoother_cell_sweeps = w0       # capturing does not execute
+        entry['graph'] = g
+    entry['graph'].replay()
+    var.smoother_cell_sweeps += entry['work']
+
+
 def _multigrid(lv, var, level, new_cycmax):
     """Recursive cycle on device levels; mirrors emg3d/solver.py:512-649."""
     it = 0
@@ -299,7 +331,10 @@ def _multigrid(lv, var, level, new_cycmax):
             sc_dir = _current_sc_dir(var.sc_dir, lv.grid)
             lv.residual(store=True, norm=False)
             clv = lv.restrict_to(sc_dir)
-            _multigrid(clv, var, level + 1, cycmax - cyc)
+            if level == 0 and var.verb < 5 and _USE_GRAPHS:
+                _coarse_correction_graphed(clv, var, cycmax - cyc)
+            else:
+                _multigrid(clv, var, level + 1, cycmax - cyc)
             lv.prolong_from(sc_dir)
             if var.first_cycle and var.verb > 3:
                 var.level_all.append(level)
