@@ -89,6 +89,41 @@ __global__ __launch_bounds__(64) void k_line_rhs(emg::Level<T> L, int colour, in
                                  blockIdx.z, vec);
 }
 
+// x-lines: the field is contiguous ALONG the line, the records are contiguous ACROSS the
+// lines. A 16 (blocks) x 16 (lines) tile is assembled with the threads running along the
+// line (256-B segments of ex/ey/ez/s per row), transposed through LDS, and written with the
+// threads running across the lines (16 records = 1280 contiguous bytes per block).
+template <class T>
+__global__ __launch_bounds__(256) void k_line_rhs_xt(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                     T *vec)
+{
+    __shared__ T tile[16][16][5];
+    const int a = threadIdx.x & 15, b = threadIdx.x >> 4;
+    const int tq = blockIdx.y;
+    {   // phase 1: a -> block, b -> line
+        const int k = blockIdx.z * 16 + a, tp = blockIdx.x * 16 + b;
+        int i1, i2, lid;
+        T rhs[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) rhs[r] = emg::zero<T>();
+        if (k < L.nx && emg::line_of_thread<0>(colour, cntp, cntq, tp, tq, i1, i2, lid)) {
+            const emg::Axes<T, 0> A(L);
+            emg::line_rhs<T, 0>(A, k, i1, i2, rhs);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) tile[b][a][r] = rhs[r];
+    }
+    __syncthreads();
+    {   // phase 2: a -> line, b -> block
+        const int k = blockIdx.z * 16 + b, tp = blockIdx.x * 16 + a;
+        if (k < n0p && tp < cntp) {
+            T *o = vec + ((size_t)k * (cntp * cntq) + (tp + cntp * tq)) * 5;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) o[r] = tile[a][b][r];
+        }
+    }
+}
+
 // ---- forward / backward substitution along the lines: four lanes per line -------------
 // The recurrence along a line is sequential and latency-bound; its per-block critical
 // path is what sets the kernel time. Lane j of a quad owns ROW j of the block: it loads
@@ -196,16 +231,33 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const 
     }
 }
 
-template <class T>
-__global__ __launch_bounds__(64) void k_line_backward(int n0p, int nlines, const T *fac, const double *lfac,
-                                                      T *vec, T *dummy)
+// Backward substitution fused with the scatter into the field (core.py:775-783): lane j
+// writes entry j of block k straight to its edge, every lane writes entry 4. Entries that
+// do not exist (padding blocks, entries 1..4 of the last block, surplus quads) go to the
+// dummy area through an address select -- no predicate, no branch.
+template <class T, int DIR>
+__global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                      const T *fac, const double *lfac, const T *vec, T *dummy)
 {
+    const emg::Axes<T, DIR> A(L);
+    const int n0 = A.n0();
+    const int nlines = cntp * cntq;
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const int j = gt & 3;
     const bool active = (gt >> 2) < nlines;
     const int line = min(gt >> 2, nlines - 1);
-    T *const obase = active ? vec + (size_t)line * 5 : dummy + (threadIdx.x >> 2) * 5;
-    const size_t ostride = active ? (size_t)nlines * 5 : 0;
+    int i1, i2, lid;
+    emg::line_of_thread<DIR>(colour, cntp, cntq, line % cntp, line / cntp, i1, i2, lid);
+    // entry j lives on component cj at (k + dk, i1 - d1, i2 - d2); entry 4 on component 2
+    const int cj = j == 0 ? 0 : (j <= 2 ? 1 : 2), dk = j == 0 ? 0 : 1;
+    const int d1 = j == 1 ? 1 : 0, d2 = j == 3 ? 1 : 0;
+    T *const ej = A.E(cj) + A.idx(cj, dk, i1 - d1, i2 - d2);
+    const long sj = (long)A.idx(cj, dk + 1, i1 - d1, i2 - d2) - (long)A.idx(cj, dk, i1 - d1, i2 - d2);
+    T *const e4 = A.E(2) + A.idx(2, 1, i1, i2);
+    const long s4 = (long)A.idx(2, 2, i1, i2) - (long)A.idx(2, 1, i1, i2);
+    T *const dj = dummy + (threadIdx.x >> 2) * 5 + j, *const d4 = dummy + (threadIdx.x >> 2) * 5 + 4;
+    const int lastj = j == 0 ? n0 - 1 : n0 - 2;     // last block in which entry j exists
+
     const int last = n0p - 1;
     QuadRow<T> ring[QD];
 #pragma unroll
@@ -233,20 +285,13 @@ __global__ __launch_bounds__(64) void k_line_backward(int n0p, int nlines, const
             x[4] = x4;
             xmine = xn;
             upA = q.bA; upD = q.bD; up03 = q.l0[3]; up44 = q.d4;
-            T *o = obase + (size_t)k * ostride;
-            o[j] = xn;
-            o[4] = x4;
+            T *const oj = (active && k <= lastj) ? ej + (long)k * sj : dj;
+            T *const o4 = (active && k <= n0 - 2) ? e4 + (long)k * s4 : d4;
+            *oj = xn;
+            *o4 = x4;
             ring[d].load(fac, lfac, vec, (size_t)max(k - QD, 0) * nlines + line, j);
         }
     }
-}
-
-template <class T, int DIR>
-__global__ __launch_bounds__(64) void k_line_scatter(emg::Level<T> L, int colour, int cntp, int cntq,
-                                                     const T *vec)
-{
-    emg::line_scatter_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
-                                     blockIdx.z, vec);
 }
 
 // Residual + per-block partial sums of |r|^2.
@@ -350,15 +395,19 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
     if (lc.lines <= 0) return;
     const dim3 bb = d3(emg::lineblk_block());
-    const dim3 bgp = d3(emg::lineblk_grid(lc, true)), bg = d3(emg::lineblk_grid(lc, false));
+    const dim3 bgp = d3(emg::lineblk_grid(lc, true));
     const T *f = fac + lc.fac_off;
     const double *lf = lfac + lc.lfac_off;
     const dim3 qb = d3(emg::linequad_block()), qg = d3(emg::linequad_grid(lc));
     const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
-    hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
+    if (DIR == 0)
+        hipLaunchKernelGGL(k_line_rhs_xt<T>, dim3(cdiv(lc.cntp, 16), lc.cntq, cdiv(lc.n0p, 16)), dim3(256), 0, st,
+                           L, c, lc.cntp, lc.cntq, lc.n0p, vec);
+    else
+        hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
     hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
-    hipLaunchKernelGGL(k_line_backward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
-    hipLaunchKernelGGL((k_line_scatter<T, DIR>), bg, bb, 0, st, L, c, lc.cntp, lc.cntq, (const T *)vec);
+    hipLaunchKernelGGL((k_line_backward<T, DIR>), qg, qb, 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f, lf,
+                       (const T *)vec, vec + dummy_off);
 }
 
 template <class T>
