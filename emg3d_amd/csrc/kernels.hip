@@ -61,6 +61,10 @@ inline dim3 d3(emg::Dim3 d) { return dim3(d.x, d.y, d.z); }
 // gs_point_schedule). 0 = plain four launches per sweep. Tunable at run time through
 // emg3d_set_option("point_slab", T); the result does not depend on it.
 int g_point_slab = 0;
+// Line smoothers: 0 = three launches per colour (rhs, forward, backward), 1 = one fused
+// launch per colour, 2 = fused when the colour class has at most g_line_fuse_max lines.
+int g_line_fuse = 2;
+int g_line_fuse_max = 1024;
 
 // ----------------------------------------------------------------------------- kernels --
 
@@ -188,13 +192,11 @@ constexpr int QD = emg::LINE_PAD;   // blocks in flight per line = padding granu
 // vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
 // last line walk the last line again but store into a dummy area behind the records.
 template <class T>
-__global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const T *fac, const double *lfac,
-                                                     T *vec, T *dummy)
+__device__ __forceinline__ void quad_forward(int n0p, int nlines, int qline, int j, const T *fac,
+                                             const double *lfac, T *vec, T *dummy)
 {
-    const int gt = blockIdx.x * 64 + threadIdx.x;
-    const int j = gt & 3;
-    const bool active = (gt >> 2) < nlines;
-    const int line = min(gt >> 2, nlines - 1);
+    const bool active = qline < nlines;
+    const int line = min(qline, nlines - 1);
     T *const obase = active ? vec + (size_t)line * 5 : dummy + (threadIdx.x >> 2) * 5;
     const size_t ostride = active ? (size_t)nlines * 5 : 0;
     QuadRow<T> ring[QD];
@@ -231,21 +233,28 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const 
     }
 }
 
+template <class T>
+__global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const T *fac, const double *lfac,
+                                                     T *vec, T *dummy)
+{
+    const int gt = blockIdx.x * 64 + threadIdx.x;
+    quad_forward<T>(n0p, nlines, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+}
+
 // Backward substitution fused with the scatter into the field (core.py:775-783): lane j
 // writes entry j of block k straight to its edge, every lane writes entry 4. Entries that
 // do not exist (padding blocks, entries 1..4 of the last block, surplus quads) go to the
 // dummy area through an address select -- no predicate, no branch.
 template <class T, int DIR>
-__global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                      const T *fac, const double *lfac, const T *vec, T *dummy)
+__device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
+                                              int qline, int j, const T *fac, const double *lfac, const T *vec,
+                                              T *dummy)
 {
     const emg::Axes<T, DIR> A(L);
     const int n0 = A.n0();
     const int nlines = cntp * cntq;
-    const int gt = blockIdx.x * 64 + threadIdx.x;
-    const int j = gt & 3;
-    const bool active = (gt >> 2) < nlines;
-    const int line = min(gt >> 2, nlines - 1);
+    const bool active = qline < nlines;
+    const int line = min(qline, nlines - 1);
     int i1, i2, lid;
     emg::line_of_thread<DIR>(colour, cntp, cntq, line % cntp, line / cntp, i1, i2, lid);
     // entry j lives on component cj at (k + dk, i1 - d1, i2 - d2); entry 4 on component 2
@@ -292,6 +301,40 @@ __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colou
             ring[d].load(fac, lfac, vec, (size_t)max(k - QD, 0) * nlines + line, j);
         }
     }
+}
+
+template <class T, int DIR>
+__global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                      const T *fac, const double *lfac, const T *vec, T *dummy)
+{
+    const int gt = blockIdx.x * 64 + threadIdx.x;
+    quad_backward<T, DIR>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+}
+
+// One launch per colour for small levels: every wave owns 16 lines and runs rhs assembly,
+// forward and backward substitution for them back to back. Lines of one colour class are
+// independent, so only the wave's own rhs records have to be complete before its forward
+// pass starts (workgroup barrier of a one-wave workgroup). On the coarse levels the three
+// separate launches are bound by launch latency, not by work.
+template <class T, int DIR>
+__global__ __launch_bounds__(64) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                    const T *fac, const double *lfac, T *vec, T *dummy)
+{
+    const emg::Axes<T, DIR> A(L);
+    const int nlines = cntp * cntq;
+    const int line0 = blockIdx.x * 16;
+    const int nl = min(16, nlines - line0);
+    // (1) right-hand sides of the wave's lines; x-lines run the lanes along the line
+    for (int i = threadIdx.x; i < nl * n0p; i += 64) {
+        const int ll = DIR == 0 ? i / n0p : i % nl;
+        const int k = DIR == 0 ? i % n0p : i / nl;
+        const int lid = line0 + ll;
+        emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, lid % cntp, lid / cntp, k, vec);
+    }
+    __syncthreads();
+    const int qline = line0 + (threadIdx.x >> 2), j = threadIdx.x & 3;
+    quad_forward<T>(n0p, nlines, qline, j, fac, lfac, vec, dummy);
+    quad_backward<T, DIR>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, vec, dummy);
 }
 
 // Residual + per-block partial sums of |r|^2.
@@ -400,6 +443,11 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const double *lf = lfac + lc.lfac_off;
     const dim3 qb = d3(emg::linequad_block()), qg = d3(emg::linequad_grid(lc));
     const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
+    if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
+        hipLaunchKernelGGL((k_line_colour<T, DIR>), qg, qb, 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f, lf, vec,
+                           vec + dummy_off);
+        return;
+    }
     if (DIR == 0)
         hipLaunchKernelGGL(k_line_rhs_xt<T>, dim3(cdiv(lc.cntp, 16), lc.cntq, cdiv(lc.n0p, 16)), dim3(256), 0, st,
                            L, c, lc.cntp, lc.cntq, lc.n0p, vec);
@@ -595,12 +643,16 @@ int emg3d_set_option(const char *name, int value)
 {
     if (!name) return fail(EMG3D_ERR_BADARG, "set_option: null name");
     if (!std::strcmp(name, "point_slab")) { g_point_slab = value; return 0; }
+    if (!std::strcmp(name, "line_fuse")) { g_line_fuse = value; return 0; }
+    if (!std::strcmp(name, "line_fuse_max")) { g_line_fuse_max = value; return 0; }
     return fail(EMG3D_ERR_BADARG, "set_option: unknown option");
 }
 
 int emg3d_get_option(const char *name)
 {
     if (name && !std::strcmp(name, "point_slab")) return g_point_slab;
+    if (name && !std::strcmp(name, "line_fuse")) return g_line_fuse;
+    if (name && !std::strcmp(name, "line_fuse_max")) return g_line_fuse_max;
     return -1;
 }
 

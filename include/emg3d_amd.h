@@ -66,7 +66,9 @@ const char *emg3d_last_error(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int emg3d_device_count(void);
 /* Tuning knobs that never change results. "point_slab": plane-slab thickness of the point
- * smoother's launch schedule (0 = one launch per colour over all planes). */
+ * smoother's launch schedule (0 = one launch per colour over all planes). "line_fuse":
+ * 0 three launches per colour and line direction (rhs, forward, backward), 1 one fused
+ * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines. */
 int emg3d_set_option(const char *name, int value);
 int emg3d_get_option(const char *name);
 

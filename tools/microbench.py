@@ -86,9 +86,12 @@ def main():
             report(f"gauss_seidel (point) slab={slab}", med, nc, args.nu, args.case)
         lib.emg3d_set_option(b'point_slab', 0)
     if args.what in ('lines', 'all'):
-        for lr in (1, 2, 3):
-            med, mn = timeit(lambda: lv.smooth(lr, args.nu), reps=5, warm=1)
-            report(f"gauss_seidel_{'xyz'[lr - 1]} (line)", med, nc, args.nu, args.case)
+        for fuse in (0, 1):
+            lib.emg3d_set_option(b'line_fuse', fuse)
+            for lr in (1, 2, 3):
+                med, mn = timeit(lambda: lv.smooth(lr, args.nu), reps=5, warm=1)
+                report(f"gauss_seidel_{'xyz'[lr - 1]} (line) fuse={fuse}", med, nc, args.nu, args.case)
+        lib.emg3d_set_option(b'line_fuse', 2)
     if args.what in ('residual', 'all'):
         med, mn = timeit(lambda: lv.residual(store=True, norm=False))
         report("residual (store)", med, nc, 1, args.case)
