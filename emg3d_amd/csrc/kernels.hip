@@ -68,30 +68,12 @@ int g_line_fuse_max = 1024;
 
 // ----------------------------------------------------------------------------- kernels --
 
-// XCD-aware block mapping. The hardware hands consecutive workgroup ids to the 8 XCDs
-// round-robin, each with its own 4 MiB L2; for a 3-D stencil that puts every tile's
-// x/y/z neighbours on other XCDs, and each L2 fetches its own copy of the shared halo
-// planes. The 3-D kernels are therefore launched on a 1-D grid and map hardware block
-// b -> logical block so that each XCD owns one contiguous chunk of the logical (x,y,z)
-// order (bijective for any block count). Performance only; results do not depend on it.
-struct LBlock { int x, y, z; };
-__device__ __forceinline__ LBlock logical_block(int gx, int gy, int gz)
-{
-    const int n = gx * gy * gz, b = blockIdx.x;
-    const int q = n >> 3, r = n & 7, xcd = b & 7, i = b >> 3;
-    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-    const int gxy = gx * gy;
-    const int z = lb / gxy, rem = lb - z * gxy;
-    return LBlock{rem % gx, rem / gx, z};
-}
-inline dim3 flat(emg::Dim3 g) { return dim3((unsigned)(g.x * g.y * g.z), 1, 1); }
-
 // Point smoother, one colour. colour = ((ix+iz)&1) | (((iy+iz)&1)<<1).
 template <class T>
-__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, int colour, int iz0, int gx, int gy, int gz)
+__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, int colour, int iz0)
 {
-    const LBlock lb = logical_block(gx, gy, gz);
-    emg::gs_point_thread<T>(L, colour, iz0, lb.x * blockDim.x + threadIdx.x, lb.y * blockDim.y + threadIdx.y, lb.z);
+    emg::gs_point_thread<T>(L, colour, iz0, blockIdx.x * blockDim.x + threadIdx.x,
+                            blockIdx.y * blockDim.y + threadIdx.y, blockIdx.z);
 }
 
 // Line smoothers (stencil.h: line_setup / line_rhs / line_forward / line_backward /
@@ -105,11 +87,10 @@ __global__ __launch_bounds__(64) void k_line_setup(emg::Level<T> L, int colour, 
 }
 
 template <class T, int DIR>
-__global__ __launch_bounds__(64) void k_line_rhs(emg::Level<T> L, int colour, int cntp, int cntq, T *vec, int gx,
-                                                 int gy, int gz)
+__global__ __launch_bounds__(64) void k_line_rhs(emg::Level<T> L, int colour, int cntp, int cntq, T *vec)
 {
-    const LBlock lb = logical_block(gx, gy, gz);
-    emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, lb.x * blockDim.x + threadIdx.x, lb.y, lb.z, vec);
+    emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
+                                 blockIdx.z, vec);
 }
 
 // x-lines: the field is contiguous ALONG the line, the records are contiguous ACROSS the
@@ -118,14 +99,13 @@ __global__ __launch_bounds__(64) void k_line_rhs(emg::Level<T> L, int colour, in
 // threads running across the lines (16 records = 1280 contiguous bytes per block).
 template <class T>
 __global__ __launch_bounds__(256) void k_line_rhs_xt(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                     T *vec, int gx, int gy, int gz)
+                                                     T *vec)
 {
     __shared__ T tile[16][16][5];
-    const LBlock lb = logical_block(gx, gy, gz);
     const int a = threadIdx.x & 15, b = threadIdx.x >> 4;
-    const int tq = lb.y;
+    const int tq = blockIdx.y;
     {   // phase 1: a -> block, b -> line
-        const int k = lb.x * 16 + a, tp = lb.z * 16 + b;
+        const int k = blockIdx.z * 16 + a, tp = blockIdx.x * 16 + b;
         int i1, i2, lid;
         T rhs[5];
 #pragma unroll
@@ -139,7 +119,7 @@ __global__ __launch_bounds__(256) void k_line_rhs_xt(emg::Level<T> L, int colour
     }
     __syncthreads();
     {   // phase 2: a -> line, b -> block
-        const int k = lb.x * 16 + b, tp = lb.z * 16 + a;
+        const int k = blockIdx.z * 16 + b, tp = blockIdx.x * 16 + a;
         if (k < n0p && tp < cntp) {
             T *o = vec + ((size_t)k * (cntp * cntq) + (tp + cntp * tq)) * 5;
 #pragma unroll
@@ -359,13 +339,11 @@ __global__ __launch_bounds__(64) void k_line_colour(emg::Level<T> L, int colour,
 
 // Residual + per-block partial sums of |r|^2.
 template <class T>
-__global__ __launch_bounds__(256) void k_residual(emg::Level<T> L, T *rx, T *ry, T *rz, double *partial, int gx,
-                                                  int gy, int gz)
+__global__ __launch_bounds__(256) void k_residual(emg::Level<T> L, T *rx, T *ry, T *rz, double *partial)
 {
-    const LBlock lb = logical_block(gx, gy, gz);
-    const int ix = lb.x * blockDim.x + threadIdx.x;
-    const int iy = lb.y * blockDim.y + threadIdx.y;
-    const int iz = lb.z;
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int iz = blockIdx.z;
     double acc = 0.0;
     if (ix <= L.nx && iy <= L.ny) acc = emg::residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
     if (partial) {
@@ -376,7 +354,8 @@ __global__ __launch_bounds__(256) void k_residual(emg::Level<T> L, T *rx, T *ry,
         if ((tid & 63) == 0) wsum[tid >> 6] = acc;
         __syncthreads();
         if (tid == 0) {
-            partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+            const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            partial[bid] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
         }
     }
 }
@@ -396,22 +375,20 @@ __global__ __launch_bounds__(256) void k_reduce_sum(const double *partial, int n
     if (threadIdx.x == 0) *out = sm[0];
 }
 
-template <class T> __global__ __launch_bounds__(256) void k_restrict(emg::Restrict<T> R, int gx, int gy, int gz)
+template <class T> __global__ __launch_bounds__(256) void k_restrict(emg::Restrict<T> R)
 {
-    const LBlock lb = logical_block(gx, gy, gz);
-    const int cix = lb.x * blockDim.x + threadIdx.x;
-    const int ciy = lb.y * blockDim.y + threadIdx.y;
-    const int ciz = lb.z;
+    const int cix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ciy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int ciz = blockIdx.z;
     if (cix >= R.cnxn || ciy >= R.cnyn) return;
     emg::restrict_node<T>(R, cix, ciy, ciz);
 }
 
-template <class T> __global__ __launch_bounds__(256) void k_prolong(emg::Prolong<T> P, int gx, int gy, int gz)
+template <class T> __global__ __launch_bounds__(256) void k_prolong(emg::Prolong<T> P)
 {
-    const LBlock lb = logical_block(gx, gy, gz);
-    const int ix = lb.x * blockDim.x + threadIdx.x;
-    const int iy = lb.y * blockDim.y + threadIdx.y;
-    const int iz = lb.z;
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int iz = blockIdx.z;
     if (ix > P.nx || iy > P.ny) return;
     emg::prolong_cell<T>(P, ix, iy, iz);
 }
@@ -472,14 +449,10 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         return;
     }
     if (DIR == 0)
-    {   // logical grid: x -> block tiles along the line (fastest), y -> tq, z -> line tiles
-        const int tgx = cdiv(lc.n0p, 16), tgy = lc.cntq, tgz = cdiv(lc.cntp, 16);
-        hipLaunchKernelGGL(k_line_rhs_xt<T>, dim3((unsigned)(tgx * tgy * tgz)), dim3(256), 0, st, L, c, lc.cntp,
-                           lc.cntq, lc.n0p, vec, tgx, tgy, tgz);
-    }
+        hipLaunchKernelGGL(k_line_rhs_xt<T>, dim3(cdiv(lc.cntp, 16), lc.cntq, cdiv(lc.n0p, 16)), dim3(256), 0, st,
+                           L, c, lc.cntp, lc.cntq, lc.n0p, vec);
     else
-        hipLaunchKernelGGL((k_line_rhs<T, DIR>), flat(emg::lineblk_grid(lc, true)), bb, 0, st, L, c, lc.cntp, lc.cntq,
-                           vec, (int)bgp.x, (int)bgp.y, (int)bgp.z);
+        hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
     hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
     hipLaunchKernelGGL((k_line_backward<T, DIR>), qg, qb, 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f, lf,
                        (const T *)vec, vec + dummy_off);
@@ -504,8 +477,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
                 const emg::Dim3 g = emg::gs_point_grid(nx, ny, izn);
                 if (g.x > 0 && g.y > 0 && g.z > 0)
-                    hipLaunchKernelGGL(k_gs_point<T>, flat(g), d3(emg::gs_point_block()), 0, st, L, c, iz0, g.x, g.y,
-                                       g.z);
+                    hipLaunchKernelGGL(k_gs_point<T>, d3(g), d3(emg::gs_point_block()), 0, st, L, c, iz0);
             });
             continue;
         }
@@ -552,8 +524,7 @@ int launch_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double 
     const dim3 grid = d3(emg::cell_grid(L.nx + 1, L.ny + 1, L.nz + 1));
     const size_t nblk = (size_t)grid.x * grid.y * grid.z;
     if (sumsq && (ws == nullptr || ws_len < nblk)) return fail(EMG3D_ERR_SCRATCH, "residual: workspace too small");
-    hipLaunchKernelGGL(k_residual<T>, dim3((unsigned)nblk), block, 0, st, L, (T *)rx, (T *)ry, (T *)rz,
-                       sumsq ? ws : nullptr, (int)grid.x, (int)grid.y, (int)grid.z);
+    hipLaunchKernelGGL(k_residual<T>, grid, block, 0, st, L, (T *)rx, (T *)ry, (T *)rz, sumsq ? ws : nullptr);
     if (sumsq) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, ws, (int)nblk, sumsq);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -567,8 +538,7 @@ int launch_restrict(void *crx, void *cry, void *crz, const void *rx, const void 
     if ((f.cx && nx % 2) || (f.cy && ny % 2) || (f.cz && nz % 2))
         return fail(EMG3D_ERR_BADARG, "restrict: odd cell count in a coarsened direction");
     const emg::Restrict<T> R = emg::make_restrict<T>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir);
-    const emg::Dim3 g = emg::cell_grid(R.cnxn, R.cnyn, R.cnzn);
-    hipLaunchKernelGGL(k_restrict<T>, flat(g), d3(emg::cell_block()), 0, st, R, g.x, g.y, g.z);
+    hipLaunchKernelGGL(k_restrict<T>, d3(emg::cell_grid(R.cnxn, R.cnyn, R.cnzn)), d3(emg::cell_block()), 0, st, R);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -580,8 +550,7 @@ int launch_prolong(void *ex, void *ey, void *ez, const void *cex, const void *ce
 {
     const emg::Prolong<T> P =
         emg::make_prolong<T>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz, sc_dir);
-    const emg::Dim3 g = emg::cell_grid(nx + 1, ny + 1, nz + 1);
-    hipLaunchKernelGGL(k_prolong<T>, flat(g), d3(emg::cell_block()), 0, st, P, g.x, g.y, g.z);
+    hipLaunchKernelGGL(k_prolong<T>, d3(emg::cell_grid(nx + 1, ny + 1, nz + 1)), d3(emg::cell_block()), 0, st, P);
     HIP_TRY(hipGetLastError());
     return 0;
 }
