@@ -179,6 +179,21 @@ class DeviceLevel:
             return float(np.sqrt(w.sumsq.item()))
         return None
 
+    def apply_A(self, x, out):
+        """out = A x for a vector x laid out like a field (the Krylov operator of
+        emg3d/solver.py:686-702: core.amat_x into a zero field, negated)."""
+        lib = _lib.lib()
+        if getattr(self, '_zero', None) is None:
+            self._zero = torch.zeros(self.grid.n_edges, dtype=self.dtype, device=self.device)
+        nx, ny, nz = self.grid.shape_cells
+        c = _lib.Level(nx, ny, nz, self.is_complex, *self.parts(x), *self.parts(self._zero),
+                       _ptr(self.eta_x), _ptr(self.eta_y), _ptr(self.eta_z), _ptr(self.zeta),
+                       _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]))
+        _lib.check(lib.emg3d_dev_residual(ctypes.byref(c), *self.parts(out), None, 0, None,
+                                          _stream()), 'emg3d_dev_residual')
+        out.neg_()
+        return out
+
     def pec_zero(self):
         nx, ny, nz = self.grid.shape_cells
         _lib.check(_lib.lib().emg3d_dev_pec_zero(*self.parts(self.e), nx, ny, nz,

@@ -370,62 +370,17 @@ def _multigrid(lv, var, level, new_cycmax):
 def krylov(model, sfield, efield, var):
     """Krylov subspace solver with multigrid preconditioner (emg3d/solver.py:652-784).
 
-    The Krylov iteration itself is SciPy's (host), as in the reference; operator and
-    preconditioner applications run on the device with the vectors crossing PCIe per call.
-    (A device-resident BiCGSTAB is the next step)
+    ``bicgstab`` (the default of ``solve``) runs entirely on the device: vectors stay in
+    HBM, the operator is the residual kernel with a zero source, the preconditioner is the
+    multigrid cycle on the same hierarchy, and only scalars (inner products, norms) cross
+    PCIe. ``cgs`` and ``gcrotmk`` use SciPy on the host, as the reference does, with device
+    operator / preconditioner applications (vectors cross PCIe per call).
     """
-    import scipy.sparse.linalg as ssl
-
     hier = Hierarchy(model)
-    top = hier.top
-    frequency = sfield._frequency
-    grid = sfield.grid
-    zero = fields.Field(grid, dtype=sfield.field.dtype, frequency=frequency)
-
-    def amatvec(x):
-        # A x = -(0 - A x): residual with zero source (emg3d/solver.py:686-702)
-        hier.upload(zero, fields.Field(grid, np.asarray(x, dtype=sfield.field.dtype)))
-        top.residual(store=True, norm=False)
-        return -top.r.cpu().numpy()
-
-    A = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=sfield.field.dtype,
-                           matvec=amatvec)
-
-    def mg_matvec(b):
-        s = fields.Field(grid, np.asarray(b, dtype=sfield.field.dtype), frequency=frequency)
-        e = fields.Field(grid, dtype=sfield.field.dtype, frequency=frequency)
-        multigrid(model, s, e, var, hierarchy=hier)
-        return e.field
-
-    M = None
-    if var.cycle:
-        M = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=sfield.field.dtype,
-                               matvec=mg_matvec)
-
-    def callback(x):
-        var.ssl_it += 1
-        var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
-        hier.upload(sfield, fields.Field(grid, np.asarray(x, dtype=sfield.field.dtype)))
-        var.l2 = top.residual(store=False, norm=True)
-        var.error_at_cycle = np.r_[var.error_at_cycle, var.l2]
-        if var.verb > 3:
-            log = f"   [{var.time.now}]   {var.l2/var.l2_refe:.3e} "
-            log += f" after {var.ssl_it:3} {var.sslsolver}-cycles"
-            if var.ssl_it == 1 and var.it == 0 and var.cycle is not None:
-                log += "\n"
-            var.cprint(log, 3)
-        elif var.verb in [2, 3]:
-            _print_one_liner(var, var.l2)
-
-    try:
-        x, i = getattr(ssl, var.sslsolver)(
-            A=A, b=sfield.field, x0=efield.field.copy(), rtol=var.tol, maxiter=var.ssl_maxit,
-            atol=1e-30, M=M, callback=callback)
-        efield.field[:] = x
-    except _ConvergenceError:
-        i = -1
-        efield.field[:] = 0
-        var.exit_message += " (returned field is zero)"
+    if var.sslsolver == 'bicgstab':
+        i = _bicgstab_device(hier, sfield, efield, var)
+    else:
+        i = _scipy_krylov(hier, model, sfield, efield, var)
 
     pre = (50 * " " + "\r" if var.verb == 3 else "\n") + "   > "
     if i < 0:
@@ -437,6 +392,151 @@ def krylov(model, sfield, efield, var):
     else:
         var.exit_message = "CONVERGED"
     var.cprint(pre + var.exit_message, 2)
+
+
+def _krylov_callback(var, l2):
+    """Bookkeeping after a Krylov iteration (emg3d/solver.py:731-757)."""
+    var.ssl_it += 1
+    var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
+    var.l2 = l2
+    var.error_at_cycle = np.r_[var.error_at_cycle, var.l2]
+    if var.verb > 3:
+        log = f"   [{var.time.now}]   {var.l2/var.l2_refe:.3e} "
+        log += f" after {var.ssl_it:3} {var.sslsolver}-cycles"
+        if var.ssl_it == 1 and var.it == 0 and var.cycle is not None:
+            log += "\n"
+        var.cprint(log, 3)
+    elif var.verb in [2, 3]:
+        _print_one_liner(var, var.l2)
+
+
+def _bicgstab_device(hier, sfield, efield, var):
+    """Preconditioned BiCGSTAB (van der Vorst 1992) with the iteration, breakdown checks,
+    stopping rule ``|r| <= max(atol, rtol |b|)`` and return codes of
+    ``scipy.sparse.linalg.bicgstab`` (SciPy >= 1.12, which the reference calls at
+    emg3d/solver.py:763-765 with ``rtol=tol, atol=1e-30, maxiter=maxit``), on device
+    tensors. Returns 0 (converged), >0 (maxiter), <0 (breakdown / aborted)."""
+    top = hier.top
+    dev = hier.device
+    dtype = top.dtype
+    b = torch.from_numpy(np.ascontiguousarray(sfield.field)).to(dev)
+    x = torch.from_numpy(np.ascontiguousarray(efield.field)).to(dev)
+    new = lambda: torch.empty_like(b)   # noqa: E731
+
+    def norm(t):
+        return float(torch.linalg.vector_norm(t).item())
+
+    def dot(u, w):                      # conj(u) . w, like np.vdot
+        return complex(torch.vdot(u, w).item()) if top.is_complex else float(torch.dot(u, w).item())
+
+    def psolve(vec, out):
+        if not var.cycle:
+            out.copy_(vec)
+            return out
+        top.s.copy_(vec)
+        top.e.zero_()
+        _multigrid(top, var, 0, 0)      # maxit = maxcycle cycles (emg3d/solver.py:1376-1381)
+        out.copy_(top.e)
+        return out
+
+    def true_residual_norm():
+        top.s.copy_(b)
+        top.e.copy_(x)
+        return top.residual(store=False, norm=True)
+
+    atol = max(1e-30, var.tol * norm(b))
+    eps = np.finfo(np.float64).eps
+    rhotol = omegatol = eps ** 2
+    r, v, t, p, phat, shat = new(), new(), new(), new(), new(), new()
+    top.apply_A(x, r)
+    torch.sub(b, r, out=r)              # r = b - A x
+    rtilde = r.clone()
+    rho_prev = omega = alpha = 1.0
+    code = var.ssl_maxit
+    try:
+        for iteration in range(var.ssl_maxit):
+            if norm(r) < atol:
+                code = 0
+                break
+            rho = dot(rtilde, r)
+            if abs(rho) < rhotol:
+                code = -10
+                break
+            if iteration > 0:
+                if abs(omega) < omegatol:
+                    code = -11
+                    break
+                beta = (rho / rho_prev) * (alpha / omega)
+                p.sub_(v, alpha=omega).mul_(beta).add_(r)
+            else:
+                p.copy_(r)
+            psolve(p, phat)
+            top.apply_A(phat, v)
+            rv = dot(rtilde, v)
+            if rv == 0:
+                code = -11
+                break
+            alpha = rho / rv
+            r.sub_(v, alpha=alpha)      # s = r - alpha v (in place)
+            if norm(r) < atol:
+                x.add_(phat, alpha=alpha)
+                code = 0
+                break
+            psolve(r, shat)
+            top.apply_A(shat, t)
+            omega = dot(t, r) / dot(t, t)
+            x.add_(phat, alpha=alpha).add_(shat, alpha=omega)
+            r.sub_(t, alpha=omega)
+            rho_prev = rho
+            _krylov_callback(var, true_residual_norm())
+        efield.field[:] = x.cpu().numpy()
+    except _ConvergenceError:
+        code = -1
+        efield.field[:] = 0
+        var.exit_message += " (returned field is zero)"
+    del dtype
+    return code
+
+
+def _scipy_krylov(hier, model, sfield, efield, var):
+    """cgs / gcrotmk through SciPy on the host (emg3d/solver.py:685-768)."""
+    import scipy.sparse.linalg as ssl
+
+    top = hier.top
+    frequency = sfield._frequency
+    grid = sfield.grid
+    dt = sfield.field.dtype
+
+    def amatvec(x):
+        xt = torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).to(hier.device)
+        return top.apply_A(xt, torch.empty_like(xt)).cpu().numpy()
+
+    A = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=dt, matvec=amatvec)
+
+    def mg_matvec(b):
+        s = fields.Field(grid, np.asarray(b, dtype=dt), frequency=frequency)
+        e = fields.Field(grid, dtype=dt, frequency=frequency)
+        multigrid(model, s, e, var, hierarchy=hier)
+        return e.field
+
+    M = None
+    if var.cycle:
+        M = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=dt, matvec=mg_matvec)
+
+    def callback(x):
+        hier.upload(sfield, fields.Field(grid, np.asarray(x, dtype=dt)))
+        _krylov_callback(var, top.residual(store=False, norm=True))
+
+    try:
+        x, i = getattr(ssl, var.sslsolver)(
+            A=A, b=sfield.field, x0=efield.field.copy(), rtol=var.tol, maxiter=var.ssl_maxit,
+            atol=1e-30, M=M, callback=callback)
+        efield.field[:] = x
+    except _ConvergenceError:
+        i = -1
+        efield.field[:] = 0
+        var.exit_message += " (returned field is zero)"
+    return i
 
 
 # ----------------------------------------- host-object wrappers (reference signatures) ---

@@ -342,6 +342,14 @@ def test_krylov_with_multigrid_preconditioner(golden_regression):
     e, info = emg3d.solve(model, sfield, sslsolver='bicgstab', plain=True, return_info=True)
     assert info['exit'] == 0 and info['it_ssl'] > 0 and info['it_mg'] > 0
     assert relerr(e.field, g['res_bicresult']) < 2e-6
+    # host-SciPy variants (cgs, gcrotmk) with device operator and preconditioner
+    ec, ic = emg3d.solve(model, sfield, sslsolver='cgs', plain=True, return_info=True)
+    assert ic['exit'] == 0 and relerr(ec.field, g['res_bicresult']) < 5e-6
+    eg = emg3d.solve(model, sfield, sslsolver='gcrotmk', plain=True, maxit=20)
+    assert relerr(eg.field, g['res_bicresult']) < 5e-6
+    # Krylov alone (no multigrid) and iteration limit
+    _, info = emg3d.solve(model, sfield, sslsolver='bicgstab', cycle=None, maxit=3, return_info=True)
+    assert info['exit'] == 1 and info['it_ssl'] == 3 and info['it_mg'] == 0
     e2 = emg3d.solve(model, sfield, tol=1e-9)          # all defaults: bicgstab + sc + lr
     e3 = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10)
     assert relerr(e2.field, e3.field) < 1e-7
@@ -432,3 +440,55 @@ def test_full_size_smoother_fixed_point_and_reduction(shape, case):
         lv.smooth(lr, 1)
         r1 = lv.residual(store=False, norm=True)
         assert np.isfinite(r1) and r1 < r0, (lr, r1, r0)
+
+
+def test_tuning_options_do_not_change_results(golden_kernels):
+    """emg3d_set_option knobs (launch schedules) must be result-neutral on the GPU too."""
+    lib = _lib.lib()
+    g = golden_kernels
+    p = 'c_tri_'
+    grid, vm = _case(g, 'c_tri')
+    s = mg_ref.Field(grid, g[p + 'gs_s'].copy())
+    args = (s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 2)
+    ref = {}
+    try:
+        for fn in SMOOTHERS:
+            a = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
+            lib.emg3d_set_option(b'point_slab', 0)
+            lib.emg3d_set_option(b'line_fuse', 0)
+            getattr(core, fn)(a.fx, a.fy, a.fz, *args)
+            ref[fn] = a.field.copy()
+        for slab, fuse in ((2, 1), (3, 2), (5, 1)):
+            lib.emg3d_set_option(b'point_slab', slab)
+            lib.emg3d_set_option(b'line_fuse', fuse)
+            for fn in SMOOTHERS:
+                b = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
+                getattr(core, fn)(b.fx, b.fy, b.fz, *args)
+                assert np.array_equal(b.field, ref[fn]), (fn, slab, fuse)
+    finally:
+        lib.emg3d_set_option(b'point_slab', 0)
+        lib.emg3d_set_option(b'line_fuse', 2)
+
+
+@pytest.mark.parametrize('shape,kw', [
+    ((48, 32, 24), dict(cycle='W', semicoarsening=True, linerelaxation=True)),
+    ((24, 40, 16), dict(cycle='V', semicoarsening=2, linerelaxation=0)),
+    ((20, 12, 36), dict(cycle='F', semicoarsening=False, linerelaxation=7, clevel=1)),
+])
+def test_solve_ragged_grids_vs_oracle(shape, kw):
+    """Non-cubic grids whose coarsest levels are odd (3, 5, 9 cells) or stop early: GPU
+    vs oracle (lexicographic) converged fields, tri-axial random model."""
+    rng = np.random.default_rng(sum(shape))
+    h = [widths(n // 2, n // 4, 20., 1.15) for n in shape]
+    grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
+    assert grid.shape_cells == shape
+    rho = 10 ** rng.uniform(-0.5, 1.0, shape)
+    model = emg3d.Model(grid, rho, 1.5 * rho, 2.5 * rho)
+    sfield = emg3d.get_source_field(grid, (3., -2., 1., 20., 30.), 0.8)
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **kw)
+    assert info['exit'] == 0, info['exit_message']
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    vm = mg_ref.volume_model(ogrid, 0.8, 1 / rho, 1 / (1.5 * rho), 1 / (2.5 * rho))
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **kw)
+    assert io['exit'] == 0
+    assert relerr(e.field, eo.field) < 1e-8
