@@ -152,12 +152,26 @@ class DeviceLevel:
             self._factors[lr] = (fac, lfac)
         return self._factors[lr]
 
+    def point_factors(self):
+        """Eta edge sums of the point smoother (emg3d_dev_point_setup), built on first use."""
+        if 0 not in self._factors:
+            lib = _lib.lib()
+            nx, ny, nz = self.grid.shape_cells
+            fac = torch.empty(lib.emg3d_point_fac_bytes(nx, ny, nz, self.is_complex),
+                              dtype=torch.uint8, device=self.device)
+            _lib.check(lib.emg3d_dev_point_setup(self._cref, _ptr(fac), _stream()),
+                       'emg3d_dev_point_setup')
+            self._factors[0] = (fac, None)
+        return self._factors[0][0]
+
     def smooth(self, lr, nu):
         """nu sweeps of smoother lr (0 point, 1/2/3 x/y/z line) on (e, s)."""
         lib = _lib.lib()
         nx, ny, nz = self.grid.shape_cells
         fac = lfac = scr = None
         nbytes = 0
+        if lr == 0:
+            fac = _ptr(self.point_factors())
         if lr:
             f, lf = self.line_factors(lr)
             fac, lfac = _ptr(f), _ptr(lf)

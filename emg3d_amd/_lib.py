@@ -64,6 +64,8 @@ SIGNATURES = {
     'emg3d_line_fac_bytes': (_sz, [_ci] * 5),
     'emg3d_line_lfac_bytes': (_sz, [_ci] * 4),
     'emg3d_dev_line_setup': (_ci, [ctypes.POINTER(Level), _ci, _vp, _vp, _vp]),
+    'emg3d_point_fac_bytes': (_sz, [_ci] * 4),
+    'emg3d_dev_point_setup': (_ci, [ctypes.POINTER(Level), _vp, _vp]),
     'emg3d_dev_gauss_seidel': (_ci, [ctypes.POINTER(Level), _ci, _ci, _vp, _vp, _vp, _sz, _vp]),
     'emg3d_residual_ws_len': (_sz, [_ci] * 3),
     'emg3d_dev_residual': (_ci, [ctypes.POINTER(Level), _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -61,6 +61,11 @@ inline dim3 d3(emg::Dim3 d) { return dim3(d.x, d.y, d.z); }
 // gs_point_schedule). 0 = plain four launches per sweep. Tunable at run time through
 // emg3d_set_option("point_slab", T); the result does not depend on it.
 int g_point_slab = 0;
+// Point smoother: levels with at least this many interior nodes use the tiled schedule
+// (launch.h) -- it changes the ORDER of the Gauss-Seidel sweep (documented in
+// include/emg3d_amd.h), so it is part of the algorithm, not a free tuning knob: the
+// oracle applies the same rule. <= 0 never, 1 always.
+int g_point_tile_min = 1 << 20;
 // Line smoothers: 0 = three launches per colour (rhs, forward, backward), 1 = one fused
 // launch per colour, 2 = fused when the colour class has at most g_line_fuse_max lines.
 int g_line_fuse = 2;
@@ -69,11 +74,55 @@ int g_line_fuse_max = 1024;
 // ----------------------------------------------------------------------------- kernels --
 
 // Point smoother, one colour. colour = ((ix+iz)&1) | (((iy+iz)&1)<<1).
+// pst: eta edge sums from k_point_setup, or nullptr (formed on the fly).
 template <class T>
-__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, int colour, int iz0)
+__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, const T *pst, int colour, int iz0)
 {
-    emg::gs_point_thread<T>(L, colour, iz0, blockIdx.x * blockDim.x + threadIdx.x,
+    emg::gs_point_thread<T>(L, pst, colour, iz0, blockIdx.x * blockDim.x + threadIdx.x,
                             blockIdx.y * blockDim.y + threadIdx.y, blockIdx.z);
+}
+
+// eta edge sums of a level (stencil.h: point_setup_cell), one thread per extended cell
+template <class T> __global__ __launch_bounds__(256) void k_point_setup(emg::Level<T> L, T *pst)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix <= L.nx && iy <= L.ny) emg::point_setup_cell<T>(L, pst, ix, iy, blockIdx.z);
+}
+
+// workgroup barrier that orders LDS traffic only: global loads issued before it (the
+// prefetch of the next node's inputs) stay in flight across it
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Point smoother, tiled schedule (launch.h): one workgroup = one tile of one tile colour;
+// the tile's edges live in LDS while the four node colours run on it. The model/source
+// inputs of the next colour's node are fetched while the current node is solved.
+template <class T, class TB, bool ST>
+__global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const T *pst, int tc, int colours)
+{
+    extern __shared__ double2 tile_smem[];
+    T *lds = reinterpret_cast<T *>(tile_smem);
+    using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+    const int x0 = 1 + ((tc & 1) + 2 * blockIdx.x) * TB::BX;
+    const int y0 = 1 + (((tc >> 1) & 1) + 2 * blockIdx.y) * TB::BY;
+    const int z0 = 1 + (((tc >> 2) & 1) + 2 * blockIdx.z) * TB::BZ;
+    const int t = threadIdx.x;
+    emg::tile_load<T, TB>(L, lds, x0, y0, z0, t);
+    lds_barrier();
+    // two workgroups per CU (launch bounds: <= 256 registers, 2 x 79 KB of LDS): while one
+    // waits for the inputs of its next node, the other one computes
+#pragma unroll 1
+    for (int cc = 0; cc < 4; ++cc) {
+        emg::PointIn<T> in;
+        int ix, iy, iz;
+        const bool ok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, (colours >> (2 * cc)) & 3, t, ix, iy, iz);
+        emg::point_load<T, ST>(L, pst, ix, iy, iz, in);
+        if (ok) emg::point_update<T, E>(L, in, E(lds, x0, y0, z0), ix, iy, iz);
+        lds_barrier();
+    }
+    emg::tile_store<T, TB>(L, lds, x0, y0, z0, t);
 }
 
 // Line smoothers (stencil.h: line_setup / line_rhs / line_forward / line_backward /
@@ -470,14 +519,42 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
         if (!scratch || scratch_bytes < emg3d_gs_scratch_bytes(lr, nx, ny, nz, lv->is_complex))
             return fail(EMG3D_ERR_SCRATCH, "gauss_seidel: scratch buffer too small");
     }
+    const bool tiled = emg::point_tiled(nx, ny, nz, g_point_tile_min);
+    const T *pst = lr == 0 ? (const T *)fac : nullptr;   // optional eta edge sums (emg3d_dev_point_setup)
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;   // first sweep backward (reference emg3d/core.py:301,311)
+        if (lr == 0 && tiled) {
+            using TB = emg::PointTile;
+            using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+            const size_t smem = sizeof(T) * E::LDS_ELEMS;
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr_set = true;
+            }
+            const int colours = emg::sweep_colours_packed(iback);
+            for (int t8 = 0; t8 < 8; ++t8) {
+                const int tc = emg::tile_colour_at(iback, t8);
+                const emg::Dim3 g = emg::tile_grid<TB>(nx, ny, nz, tc);
+                if (g.x <= 0 || g.y <= 0 || g.z <= 0) continue;
+                if (pst)
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true>), d3(g), dim3(TB::THREADS), smem, st, L, pst, tc,
+                                       colours);
+                else
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false>), d3(g), dim3(TB::THREADS), smem, st, L, pst, tc,
+                                       colours);
+            }
+            continue;
+        }
         if (lr == 0) {
             emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
                 const emg::Dim3 g = emg::gs_point_grid(nx, ny, izn);
                 if (g.x > 0 && g.y > 0 && g.z > 0)
-                    hipLaunchKernelGGL(k_gs_point<T>, d3(g), d3(emg::gs_point_block()), 0, st, L, c, iz0);
+                    hipLaunchKernelGGL(k_gs_point<T>, d3(g), d3(emg::gs_point_block()), 0, st, L, pst, c, iz0);
             });
             continue;
         }
@@ -643,6 +720,7 @@ int emg3d_set_option(const char *name, int value)
 {
     if (!name) return fail(EMG3D_ERR_BADARG, "set_option: null name");
     if (!std::strcmp(name, "point_slab")) { g_point_slab = value; return 0; }
+    if (!std::strcmp(name, "point_tile_min")) { g_point_tile_min = value; return 0; }
     if (!std::strcmp(name, "line_fuse")) { g_line_fuse = value; return 0; }
     if (!std::strcmp(name, "line_fuse_max")) { g_line_fuse_max = value; return 0; }
     return fail(EMG3D_ERR_BADARG, "set_option: unknown option");
@@ -651,6 +729,7 @@ int emg3d_set_option(const char *name, int value)
 int emg3d_get_option(const char *name)
 {
     if (name && !std::strcmp(name, "point_slab")) return g_point_slab;
+    if (name && !std::strcmp(name, "point_tile_min")) return g_point_tile_min;
     if (name && !std::strcmp(name, "line_fuse")) return g_line_fuse;
     if (name && !std::strcmp(name, "line_fuse_max")) return g_line_fuse_max;
     return -1;
@@ -686,6 +765,24 @@ int emg3d_dev_line_setup(const emg3d_level *lv, int lr, void *fac, double *lfac,
     if (!lv || lr < 1 || lr > 3 || !fac || !lfac) return fail(EMG3D_ERR_BADARG, "line_setup: bad argument");
     return lv->is_complex ? launch_line_setup<cplx>(lv, lr, fac, lfac, (hipStream_t)stream)
                           : launch_line_setup<double>(lv, lr, fac, lfac, (hipStream_t)stream);
+}
+
+size_t emg3d_point_fac_bytes(int nx, int ny, int nz, int is_complex)
+{
+    const Sizes S(nx, ny, nz, is_complex);
+    return (S.nex + S.ney + S.nez) * S.esz;
+}
+
+int emg3d_dev_point_setup(const emg3d_level *lv, void *fac, void *stream)
+{
+    if (!lv || !fac) return fail(EMG3D_ERR_BADARG, "point_setup: bad argument");
+    const hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(fac, 0, emg3d_point_fac_bytes(lv->nx, lv->ny, lv->nz, lv->is_complex), st));
+    const dim3 g = d3(emg::cell_grid(lv->nx + 1, lv->ny + 1, lv->nz + 1)), b = d3(emg::cell_block());
+    if (lv->is_complex) hipLaunchKernelGGL(k_point_setup<cplx>, g, b, 0, st, to_level<cplx>(lv), (cplx *)fac);
+    else hipLaunchKernelGGL(k_point_setup<double>, g, b, 0, st, to_level<double>(lv), (double *)fac);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, const void *fac, const double *lfac,
@@ -802,7 +899,8 @@ int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx
     const size_t sb = emg3d_gs_scratch_bytes(lr, nx, ny, nz, is_complex);
     HIP_TRY(scr.alloc(sb));
     DevBuf dfac, dlfac;
-    HIP_TRY(dfac.alloc(emg3d_line_fac_bytes(lr, nx, ny, nz, is_complex)));
+    HIP_TRY(dfac.alloc(lr ? emg3d_line_fac_bytes(lr, nx, ny, nz, is_complex)
+                          : emg3d_point_fac_bytes(nx, ny, nz, is_complex)));
     HIP_TRY(dlfac.alloc(emg3d_line_lfac_bytes(lr, nx, ny, nz)));
     emg3d_level lv;
     lv.nx = nx; lv.ny = ny; lv.nz = nz; lv.is_complex = is_complex;
@@ -813,6 +911,7 @@ int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx
     lv.ihx = (const double *)dhx.d; lv.ihy = (const double *)dhy.d; lv.ihz = (const double *)dhz.d;
     int rc = 0;
     if (lr != 0) rc = emg3d_dev_line_setup(&lv, lr, dfac.d, (double *)dlfac.d, nullptr);
+    else rc = emg3d_dev_point_setup(&lv, dfac.d, nullptr);
     if (rc) return rc;
     rc = emg3d_dev_gauss_seidel(&lv, lr, nu, dfac.d, (const double *)dlfac.d, scr.d, sb, nullptr);
     if (rc) return rc;

@@ -18,8 +18,9 @@ EMG_HD int first_par(int par) { return par ? 1 : 2; }
 // Colour class visited at position cc (0..3) of a sweep. A forward sweep visits the classes
 // in the sequence 0,2,3,1, a backward sweep in the reverse; the first sweep of a smoother
 // call is backward, like the reference's (emg3d/core.py:301,311). Of the distinct
-// sequences this one gives the best multigrid convergence factor (measured with the
-// oracle: 0.128 vs 0.156 for 0,1,2,3 on the point smoother; lexicographic 0.088).
+// sequences this one (and its x<->y mirror image 0,1,3,2) gives the best multigrid
+// convergence factor (measured with the oracle: 0.128 vs 0.156 for 0,1,2,3 on the point
+// smoother; lexicographic 0.088).
 inline int sweep_colour(int iback, int cc)
 {
     const int seq[4] = {0, 2, 3, 1};
@@ -34,7 +35,7 @@ inline Dim3 gs_point_grid(int nx, int ny, int izn)
     return Dim3{cdiv(cdiv(nx - 1, 2), 64), cdiv(cdiv(ny - 1, 2), 4), izn};
 }
 template <class T>
-EMG_HD void gs_point_thread(const Level<T> &L, int colour, int iz0, int gx, int gy, int gz)
+EMG_HD void gs_point_thread(const Level<T> &L, const T *pst, int colour, int iz0, int gx, int gy, int gz)
 {
     const int iz = iz0 + gz;
     const int parx = (colour & 1) ^ (iz & 1);
@@ -42,7 +43,7 @@ EMG_HD void gs_point_thread(const Level<T> &L, int colour, int iz0, int gx, int 
     const int ix = first_par(parx) + 2 * gx;
     const int iy = first_par(pary) + 2 * gy;
     if (ix > L.nx - 1 || iy > L.ny - 1 || iz > L.nz - 1) return;
-    gs_point_node<T>(L, ix, iy, iz);
+    gs_point_node<T>(L, pst, ix, iy, iz);
 }
 
 // Launch schedule of ONE four-colour sweep of the point smoother.
@@ -72,6 +73,160 @@ template <class F> inline void gs_point_schedule(int nz, int slab, int iback, F 
             if (b > nz) b = nz;
             if (b > a) launch(sweep_colour(iback, cc), a, b - a);
         }
+}
+
+// ---- point smoother, TILED schedule (large levels).
+//
+// The plain schedule streams the whole level through HBM once per colour class (4 passes
+// per sweep, each reading every field value although it updates a quarter of the nodes).
+// The tiled schedule cuts the interior nodes into tiles of TB::BX x BY x BZ nodes; one
+// workgroup stages a tile's edges (+ the one-edge halo) in LDS, runs the four colour
+// classes on it back to back, and writes the tile's edges out -- one pass over the field
+// per sweep. Tiles that run concurrently must not touch: the tiles are coloured
+// (tx&1)|((ty&1)<<1)|((tz&1)<<2) and a sweep is eight launches, one per tile colour (forward
+// 0..7, backward 7..0). The result is a Gauss-Seidel sweep in the order "tile colour, then
+// node colour inside every tile" -- a different, equally valid ordering than the plain
+// schedule's (the oracle restates it: oracle/core_generic.h, order 2).
+template <int BX_, int BY_, int BZ_> struct TileBox {
+    static constexpr int BX = BX_, BY = BY_, BZ = BZ_;
+    static constexpr int THREADS = BX * BY * BZ / 4;   // one thread per node of a colour class
+    static_assert(BX % 2 == 0 && BY % 2 == 0, "tile extents in x and y must be even");
+};
+using PointTile = TileBox<16, 8, 8>;
+
+struct TileCount { int x, y, z; };
+template <class TB> inline TileCount tile_count(int nx, int ny, int nz)
+{
+    return TileCount{cdiv(nx - 1, TB::BX), cdiv(ny - 1, TB::BY), cdiv(nz - 1, TB::BZ)};
+}
+// launch grid of one tile colour: tiles t = par + 2 b along every axis
+template <class TB> inline Dim3 tile_grid(int nx, int ny, int nz, int tc)
+{
+    const TileCount n = tile_count<TB>(nx, ny, nz);
+    return Dim3{(n.x - (tc & 1) + 1) / 2, (n.y - ((tc >> 1) & 1) + 1) / 2, (n.z - ((tc >> 2) & 1) + 1) / 2};
+}
+// the rule that selects the tiled schedule (and with it the sweep order) for a level
+inline bool point_tiled(int nx, int ny, int nz, int tile_min)
+{
+    return tile_min > 0 && (long long)(nx - 1) * (ny - 1) * (nz - 1) >= tile_min;
+}
+inline int tile_colour_at(int iback, int t8) { return iback ? 7 - t8 : t8; }
+// the four node colours of a sweep packed two bits each, first-visited in the low bits
+inline int sweep_colours_packed(int iback)
+{
+    int p = 0;
+    for (int cc = 0; cc < 4; ++cc) p |= sweep_colour(iback, cc) << (2 * cc);
+    return p;
+}
+
+// Phase 1 (thread t of THREADS): copy the tile's edges and halo into LDS. All loads are
+// issued before the first LDS store (fully unrolled, branch-free: clamped source address;
+// slots past the end of a box go to the spare LDS slot), so that a thread has its ~20
+// 16-byte loads in flight together. Box element e of each array is LDS element e.
+template <class T, class TB>
+EMG_HD void tile_load(const Level<T> &L, T *lds, int x0, int y0, int z0, int t)
+{
+    using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+    const EdgesGlobal<T> g(L);
+    const int ox = x0 - 1, oy = y0 - 1, oz = z0 - 1;
+    constexpr int TX = (E::NXE + TB::THREADS - 1) / TB::THREADS, TY = (E::NYE + TB::THREADS - 1) / TB::THREADS;
+    constexpr int TZ = (E::NZE + TB::THREADS - 1) / TB::THREADS;
+    T vx[TX], vy[TY], vz[TZ];
+#pragma unroll
+    for (int it = 0; it < TX; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int li = e % (TB::BX + 1), r = e / (TB::BX + 1), lj = r % (TB::BY + 2), lk = r / (TB::BY + 2);
+        const int i = ox + li, j = oy + lj, k = oz + lk;
+        const bool ok = e < E::NXE && i < L.nx && j <= L.ny && k <= L.nz;
+        vx[it] = g.x(ok ? i : 0, ok ? j : 0, ok ? k : 0);
+    }
+#pragma unroll
+    for (int it = 0; it < TY; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int li = e % (TB::BX + 2), r = e / (TB::BX + 2), lj = r % (TB::BY + 1), lk = r / (TB::BY + 1);
+        const int i = ox + li, j = oy + lj, k = oz + lk;
+        const bool ok = e < E::NYE && i <= L.nx && j < L.ny && k <= L.nz;
+        vy[it] = g.y(ok ? i : 0, ok ? j : 0, ok ? k : 0);
+    }
+#pragma unroll
+    for (int it = 0; it < TZ; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int li = e % (TB::BX + 2), r = e / (TB::BX + 2), lj = r % (TB::BY + 2), lk = r / (TB::BY + 2);
+        const int i = ox + li, j = oy + lj, k = oz + lk;
+        const bool ok = e < E::NZE && i <= L.nx && j <= L.ny && k < L.nz;
+        vz[it] = g.z(ok ? i : 0, ok ? j : 0, ok ? k : 0);
+    }
+#pragma unroll
+    for (int it = 0; it < TX; ++it) {
+        const int e = t + it * TB::THREADS;
+        lds[e < E::NXE ? e : E::ELEMS] = vx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < TY; ++it) {
+        const int e = t + it * TB::THREADS;
+        lds[e < E::NYE ? E::NXE + e : E::ELEMS] = vy[it];
+    }
+#pragma unroll
+    for (int it = 0; it < TZ; ++it) {
+        const int e = t + it * TB::THREADS;
+        lds[e < E::NZE ? E::NXE + E::NYE + e : E::ELEMS] = vz[it];
+    }
+}
+// Phase 2 (once per node colour): the node of colour class `colour` that thread t owns;
+// false if it lies outside the level (partial tile) -- the coordinates are then clamped to
+// a valid node so that its inputs can still be fetched unconditionally.
+template <class TB>
+EMG_HD bool tile_node(int nx, int ny, int nz, int x0, int y0, int z0, int colour, int t, int &ix, int &iy, int &iz)
+{
+    const int jx = t % (TB::BX / 2), r = t / (TB::BX / 2), jy = r % (TB::BY / 2), lz = r / (TB::BY / 2);
+    iz = z0 + lz;
+    ix = x0 + 2 * jx + (((colour & 1) ^ (x0 + iz)) & 1);
+    iy = y0 + 2 * jy + ((((colour >> 1) & 1) ^ (y0 + iz)) & 1);
+    const bool ok = ix <= nx - 1 && iy <= ny - 1 && iz <= nz - 1;
+    if (!ok) { ix = 1; iy = 1; iz = 1; }
+    return ok;
+}
+template <class T, class TB>
+EMG_HD void tile_colour(const Level<T> &L, const T *pst, T *lds, int x0, int y0, int z0, int colour, int t)
+{
+    int ix, iy, iz;
+    if (!tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, colour, t, ix, iy, iz)) return;
+    using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+    gs_point_node<T, E>(L, pst, E(lds, x0, y0, z0), ix, iy, iz);
+}
+// Phase 3: write the edges attached to the tile's nodes back (the halo is read-only).
+template <class T, class TB>
+EMG_HD void tile_store(const Level<T> &L, const T *lds, int x0, int y0, int z0, int t)
+{
+    using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+    const E ed(const_cast<T *>(lds), x0, y0, z0);
+    const EdgesGlobal<T> g(L);
+    const int x1 = x0 + TB::BX - 1 < L.nx - 1 ? x0 + TB::BX - 1 : L.nx - 1;   // last node of the tile
+    const int y1 = y0 + TB::BY - 1 < L.ny - 1 ? y0 + TB::BY - 1 : L.ny - 1;
+    const int z1 = z0 + TB::BZ - 1 < L.nz - 1 ? z0 + TB::BZ - 1 : L.nz - 1;
+    constexpr int MX = (TB::BX + 1) * TB::BY * TB::BZ, MY = TB::BX * (TB::BY + 1) * TB::BZ;
+    constexpr int MZ = TB::BX * TB::BY * (TB::BZ + 1);
+#pragma unroll
+    for (int it = 0; it < (MX + TB::THREADS - 1) / TB::THREADS; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int li = e % (TB::BX + 1), r = e / (TB::BX + 1);
+        const int i = x0 - 1 + li, j = y0 + r % TB::BY, k = z0 + r / TB::BY;
+        if (e < MX && i <= x1 && j <= y1 && k <= z1) g.x(i, j, k) = ed.x(i, j, k);
+    }
+#pragma unroll
+    for (int it = 0; it < (MY + TB::THREADS - 1) / TB::THREADS; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int li = e % TB::BX, r = e / TB::BX;
+        const int i = x0 + li, j = y0 - 1 + r % (TB::BY + 1), k = z0 + r / (TB::BY + 1);
+        if (e < MY && i <= x1 && j <= y1 && k <= z1) g.y(i, j, k) = ed.y(i, j, k);
+    }
+#pragma unroll
+    for (int it = 0; it < (MZ + TB::THREADS - 1) / TB::THREADS; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int li = e % TB::BX, r = e / TB::BX;
+        const int i = x0 + li, j = y0 + r % TB::BY, k = z0 - 1 + r / TB::BY;
+        if (e < MZ && i <= x1 && j <= y1 && k <= z1) g.z(i, j, k) = ed.z(i, j, k);
+    }
 }
 
 // ---- line smoothers: (p,q) = transverse PHYSICAL node indices in memory order (p faster):

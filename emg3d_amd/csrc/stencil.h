@@ -247,9 +247,110 @@ template <class T> EMG_HD void solve6(const T (&dg)[6], const double (&od)[6][6]
     }
 }
 
-template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, int iz)
+// Where the point smoother finds the field: directly in the global arrays ...
+template <class T> struct EdgesGlobal {
+    T *ex, *ey, *ez;
+    int nx, ny;
+    EMG_HD explicit EdgesGlobal(const Level<T> &L) : ex(L.ex), ey(L.ey), ez(L.ez), nx(L.nx), ny(L.ny) {}
+    EMG_HD T &x(int i, int j, int k) const { return ex[i + nx * (j + (ny + 1) * k)]; }
+    EMG_HD T &y(int i, int j, int k) const { return ey[i + (nx + 1) * (j + ny * k)]; }
+    EMG_HD T &z(int i, int j, int k) const { return ez[i + (nx + 1) * (j + (ny + 1) * k)]; }
+};
+// ... or in an LDS copy of one tile of BX x BY x BZ nodes starting at node (ox,oy,oz), with
+// the one-edge halo the 6x6 node systems read (launch.h: tiled schedule). Three dense
+// boxes, x fastest:  ex [BX+1][BY+2][BZ+2],  ey [BX+2][BY+1][BZ+2],  ez [BX+2][BY+2][BZ+1].
+template <class T, int BX, int BY, int BZ> struct EdgesTile {
+    static constexpr int NXE = (BX + 1) * (BY + 2) * (BZ + 2);
+    static constexpr int NYE = (BX + 2) * (BY + 1) * (BZ + 2);
+    static constexpr int NZE = (BX + 2) * (BY + 2) * (BZ + 1);
+    static constexpr int ELEMS = NXE + NYE + NZE;
+    static constexpr int LDS_ELEMS = ELEMS + 1;   // + one slot that absorbs out-of-range copies
+    T *lds;
+    int ox, oy, oz;
+    EMG_HD EdgesTile(T *l, int x0, int y0, int z0) : lds(l), ox(x0 - 1), oy(y0 - 1), oz(z0 - 1) {}
+    EMG_HD T &x(int i, int j, int k) const { return lds[(i - ox) + (BX + 1) * ((j - oy) + (BY + 2) * (k - oz))]; }
+    EMG_HD T &y(int i, int j, int k) const
+    {
+        return lds[NXE + (i - ox) + (BX + 2) * ((j - oy) + (BY + 1) * (k - oz))];
+    }
+    EMG_HD T &z(int i, int j, int k) const
+    {
+        return lds[NXE + NYE + (i - ox) + (BX + 2) * ((j - oy) + (BY + 2) * (k - oz))];
+    }
+};
+
+// The model- and source-dependent inputs of one node update: eta edge sums (core.py:377-390),
+// zeta of the 8 surrounding cells, source at the 6 edges. Loading them (point_load) is
+// separate from the update (point_update) so that a kernel can fetch the inputs of its next
+// node while it computes the current one.
+// `pst` (optional): precomputed eta edge sums [stx|sty|stz], shaped like ex/ey/ez
+// (point_setup_cell) -- 6 loads instead of 24; the sums are formed in the same order, so
+// both paths give identical bits.
+template <class T> struct PointIn {
+    T st[6];
+    double z[8];   // z000 z100 z010 z110 z001 z101 z011 z111  (x fastest)
+    T s[6];
+};
+
+template <class T, bool ST>
+EMG_HD void point_load(const Level<T> &L, const T *pst, int ix, int iy, int iz, PointIn<T> &in)
 {
     const Axes<T, 0> A(L);
+    const int ixm = ix - 1, iym = iy - 1, izm = iz - 1;
+    in.z[0] = L.zeta[A.icc(ixm, iym, izm)]; in.z[1] = L.zeta[A.icc(ix, iym, izm)];
+    in.z[2] = L.zeta[A.icc(ixm, iy, izm)];  in.z[3] = L.zeta[A.icc(ix, iy, izm)];
+    in.z[4] = L.zeta[A.icc(ixm, iym, iz)];  in.z[5] = L.zeta[A.icc(ix, iym, iz)];
+    in.z[6] = L.zeta[A.icc(ixm, iy, iz)];   in.z[7] = L.zeta[A.icc(ix, iy, iz)];
+    const int e0 = A.iex(ixm, iy, iz), e1 = A.iex(ix, iy, iz), e2 = A.iey(ix, iym, iz), e3 = A.iey(ix, iy, iz);
+    const int e4 = A.iez(ix, iy, izm), e5 = A.iez(ix, iy, iz);
+    in.s[0] = L.sx[e0]; in.s[1] = L.sx[e1]; in.s[2] = L.sy[e2]; in.s[3] = L.sy[e3];
+    in.s[4] = L.sz[e4]; in.s[5] = L.sz[e5];
+    if (ST) {
+        const T *sty = pst + (size_t)L.nx * (L.ny + 1) * (L.nz + 1);
+        const T *stz = sty + (size_t)(L.nx + 1) * L.ny * (L.nz + 1);
+        in.st[0] = pst[e0]; in.st[1] = pst[e1]; in.st[2] = sty[e2]; in.st[3] = sty[e3];
+        in.st[4] = stz[e4]; in.st[5] = stz[e5];
+    } else {
+#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
+        in.st[0] = ETv(L.eta_x, ixm, iy, iz) + ETv(L.eta_x, ixm, iy, izm) +
+                   ETv(L.eta_x, ixm, iym, iz) + ETv(L.eta_x, ixm, iym, izm);
+        in.st[1] = ETv(L.eta_x, ix, iy, iz) + ETv(L.eta_x, ix, iy, izm) +
+                   ETv(L.eta_x, ix, iym, iz) + ETv(L.eta_x, ix, iym, izm);
+        in.st[2] = ETv(L.eta_y, ix, iym, iz) + ETv(L.eta_y, ix, iym, izm) +
+                   ETv(L.eta_y, ixm, iym, iz) + ETv(L.eta_y, ixm, iym, izm);
+        in.st[3] = ETv(L.eta_y, ix, iy, iz) + ETv(L.eta_y, ix, iy, izm) +
+                   ETv(L.eta_y, ixm, iy, iz) + ETv(L.eta_y, ixm, iy, izm);
+        in.st[4] = ETv(L.eta_z, ix, iy, izm) + ETv(L.eta_z, ix, iym, izm) +
+                   ETv(L.eta_z, ixm, iy, izm) + ETv(L.eta_z, ixm, iym, izm);
+        in.st[5] = ETv(L.eta_z, ix, iy, iz) + ETv(L.eta_z, ix, iym, iz) +
+                   ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ixm, iym, iz);
+#undef ETv
+    }
+}
+
+// Eta edge sums of the three "lower" edges of extended cell (ix,iy,iz) (the ones attached
+// to interior nodes; all others stay 0), for the `pst` form of point_load.
+template <class T> EMG_HD void point_setup_cell(const Level<T> &L, T *pst, int ix, int iy, int iz)
+{
+    const Axes<T, 0> A(L);
+    T *sty = pst + (size_t)L.nx * (L.ny + 1) * (L.nz + 1);
+    T *stz = sty + (size_t)(L.nx + 1) * L.ny * (L.nz + 1);
+#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
+    if (ix < L.nx && iy >= 1 && iy < L.ny && iz >= 1 && iz < L.nz)
+        pst[A.iex(ix, iy, iz)] = ETv(L.eta_x, ix, iy, iz) + ETv(L.eta_x, ix, iy, iz - 1) +
+                                 ETv(L.eta_x, ix, iy - 1, iz) + ETv(L.eta_x, ix, iy - 1, iz - 1);
+    if (iy < L.ny && ix >= 1 && ix < L.nx && iz >= 1 && iz < L.nz)
+        sty[A.iey(ix, iy, iz)] = ETv(L.eta_y, ix, iy, iz) + ETv(L.eta_y, ix, iy, iz - 1) +
+                                 ETv(L.eta_y, ix - 1, iy, iz) + ETv(L.eta_y, ix - 1, iy, iz - 1);
+    if (iz < L.nz && ix >= 1 && ix < L.nx && iy >= 1 && iy < L.ny)
+        stz[A.iez(ix, iy, iz)] = ETv(L.eta_z, ix, iy, iz) + ETv(L.eta_z, ix, iy - 1, iz) +
+                                 ETv(L.eta_z, ix - 1, iy, iz) + ETv(L.eta_z, ix - 1, iy - 1, iz);
+#undef ETv
+}
+
+template <class T, class E>
+EMG_HD void point_update(const Level<T> &L, const PointIn<T> &in, const E &ed, int ix, int iy, int iz)
+{
     const int ixm = ix - 1, ixp = ix + 1, iym = iy - 1, iyp = iy + 1, izm = iz - 1, izp = iz + 1;
     const double hx0 = L.ihx[ixm], hx1 = L.ihx[ix];
     const double hy0 = L.ihy[iym], hy1 = L.ihy[iy];
@@ -258,10 +359,8 @@ template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, 
     const double kz0 = 0.5 * hz0, kz1 = 0.5 * hz1;
 
     // zeta of the 8 cells around the node: z[a][b][c], a/b/c = 0 (minus) or 1 (this)
-    const double z000 = L.zeta[A.icc(ixm, iym, izm)], z100 = L.zeta[A.icc(ix, iym, izm)];
-    const double z010 = L.zeta[A.icc(ixm, iy, izm)], z110 = L.zeta[A.icc(ix, iy, izm)];
-    const double z001 = L.zeta[A.icc(ixm, iym, iz)], z101 = L.zeta[A.icc(ix, iym, iz)];
-    const double z011 = L.zeta[A.icc(ixm, iy, iz)], z111 = L.zeta[A.icc(ix, iy, iz)];
+    const double z000 = in.z[0], z100 = in.z[1], z010 = in.z[2], z110 = in.z[3];
+    const double z001 = in.z[4], z101 = in.z[5], z011 = in.z[6], z111 = in.z[7];
 
     // the 24 face averages (core.py:351-374), names as in the reference
     const double mzyLxm = ky0 * (z001 + z000), mzyRxm = ky1 * (z011 + z010);
@@ -277,21 +376,7 @@ template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, 
     const double myxLzp = kx0 * (z011 + z001), myxRzp = kx1 * (z111 + z101);
     const double mxyLzp = ky0 * (z101 + z001), mxyRzp = ky1 * (z111 + z011);
 
-    // eta edge sums (core.py:377-390)
-#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
-    const T st0 = ETv(L.eta_x, ixm, iy, iz) + ETv(L.eta_x, ixm, iy, izm) +
-                  ETv(L.eta_x, ixm, iym, iz) + ETv(L.eta_x, ixm, iym, izm);
-    const T st1 = ETv(L.eta_x, ix, iy, iz) + ETv(L.eta_x, ix, iy, izm) +
-                  ETv(L.eta_x, ix, iym, iz) + ETv(L.eta_x, ix, iym, izm);
-    const T st2 = ETv(L.eta_y, ix, iym, iz) + ETv(L.eta_y, ix, iym, izm) +
-                  ETv(L.eta_y, ixm, iym, iz) + ETv(L.eta_y, ixm, iym, izm);
-    const T st3 = ETv(L.eta_y, ix, iy, iz) + ETv(L.eta_y, ix, iy, izm) +
-                  ETv(L.eta_y, ixm, iy, iz) + ETv(L.eta_y, ixm, iy, izm);
-    const T st4 = ETv(L.eta_z, ix, iy, izm) + ETv(L.eta_z, ix, iym, izm) +
-                  ETv(L.eta_z, ixm, iy, izm) + ETv(L.eta_z, ixm, iym, izm);
-    const T st5 = ETv(L.eta_z, ix, iy, iz) + ETv(L.eta_z, ix, iym, iz) +
-                  ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ixm, iym, iz);
-#undef ETv
+    const T st0 = in.st[0], st1 = in.st[1], st2 = in.st[2], st3 = in.st[3], st4 = in.st[4], st5 = in.st[5];
 
     // diagonal (core.py:396-412): -st/4 + real curl-curl part
     T dg[6];
@@ -313,16 +398,12 @@ template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, 
     od[5][4] = 0.0;
 
     // right-hand side: source + terms of the 24 neighbouring edges (core.py:436-492)
-#define EXv(i, j, k) L.ex[A.iex(i, j, k)]
-#define EYv(i, j, k) L.ey[A.iey(i, j, k)]
-#define EZv(i, j, k) L.ez[A.iez(i, j, k)]
+#define EXv(i, j, k) ed.x(i, j, k)
+#define EYv(i, j, k) ed.y(i, j, k)
+#define EZv(i, j, k) ed.z(i, j, k)
     T rhs[6];
-    rhs[0] = L.sx[A.iex(ixm, iy, iz)];
-    rhs[1] = L.sx[A.iex(ix, iy, iz)];
-    rhs[2] = L.sy[A.iey(ix, iym, iz)];
-    rhs[3] = L.sy[A.iey(ix, iy, iz)];
-    rhs[4] = L.sz[A.iez(ix, iy, izm)];
-    rhs[5] = L.sz[A.iez(ix, iy, iz)];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) rhs[r] = in.s[r];
 
     // the 24 neighbour edges, each used twice
     const T ex_mpc = EXv(ixm, iyp, iz), ex_mmc = EXv(ixm, iym, iz);   // ex[ixm, iy+-1, iz]
@@ -374,12 +455,25 @@ template <class T> EMG_HD void gs_point_node(const Level<T> &L, int ix, int iy, 
     solve6<T>(dg, od, rhs);
 
     // write the six edges (core.py:498-503)
-    L.ex[A.iex(ixm, iy, iz)] = rhs[0];
-    L.ex[A.iex(ix, iy, iz)] = rhs[1];
-    L.ey[A.iey(ix, iym, iz)] = rhs[2];
-    L.ey[A.iey(ix, iy, iz)] = rhs[3];
-    L.ez[A.iez(ix, iy, izm)] = rhs[4];
-    L.ez[A.iez(ix, iy, iz)] = rhs[5];
+    ed.x(ixm, iy, iz) = rhs[0];
+    ed.x(ix, iy, iz) = rhs[1];
+    ed.y(ix, iym, iz) = rhs[2];
+    ed.y(ix, iy, iz) = rhs[3];
+    ed.z(ix, iy, izm) = rhs[4];
+    ed.z(ix, iy, iz) = rhs[5];
+}
+// load + update in one go; pst = nullptr: eta edge sums formed on the fly
+template <class T, class E>
+EMG_HD void gs_point_node(const Level<T> &L, const T *pst, const E &ed, int ix, int iy, int iz)
+{
+    PointIn<T> in;
+    if (pst) point_load<T, true>(L, pst, ix, iy, iz, in);
+    else point_load<T, false>(L, pst, ix, iy, iz, in);
+    point_update<T, E>(L, in, ed, ix, iy, iz);
+}
+template <class T> EMG_HD void gs_point_node(const Level<T> &L, const T *pst, int ix, int iy, int iz)
+{
+    gs_point_node<T, EdgesGlobal<T>>(L, pst, EdgesGlobal<T>(L), ix, iy, iz);
 }
 
 // ---------------------------------------------------------------------------------------

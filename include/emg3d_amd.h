@@ -33,6 +33,14 @@
  *     point:  colour = ((ix+iz)&1) | (((iy+iz)&1)<<1);
  *     lines:  colour = (p&1) | ((q&1)<<1), (p,q) the transverse node indices in memory
  *             order: x-lines (iy,iz), y-lines (ix,iz), z-lines (ix,iy).
+ *     Point smoother on LARGE levels -- (nx-1)(ny-1)(nz-1) >= option "point_tile_min"
+ *     (default 2^20) -- the interior nodes are cut into tiles of 16 x 8 x 8 nodes (tile t
+ *     along an axis = nodes 1 + t*B .. (t+1)*B) which are coloured
+ *     (tx&1)|((ty&1)<<1)|((tz&1)<<2); a forward sweep visits the tile colours 0..7 (backward
+ *     7..0) and, inside every tile, the four node colours as above. This is the order in
+ *     which one workgroup can keep a tile in LDS for all four node colours (one pass over
+ *     the field per sweep instead of four); it is a Gauss-Seidel sweep like the others and
+ *     converges alike. The oracle restates all of these orders.
  */
 #ifndef EMG3D_AMD_H
 #define EMG3D_AMD_H
@@ -65,8 +73,9 @@ int emg3d_version(void);
 const char *emg3d_last_error(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int emg3d_device_count(void);
-/* Tuning knobs that never change results. "point_slab": plane-slab thickness of the point
- * smoother's launch schedule (0 = one launch per colour over all planes). "line_fuse":
+/* Tuning knobs; all but "point_tile_min" never change results. "point_slab": plane-slab thickness of the point
+ * smoother's launch schedule (0 = one launch per colour over all planes). "point_tile_min"
+ * DOES select the sweep order of the point smoother (see above; <= 0 never tiled). "line_fuse":
  * 0 three launches per colour and line direction (rhs, forward, backward), 1 one fused
  * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines. */
 int emg3d_set_option(const char *name, int value);
@@ -120,8 +129,16 @@ size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex); /
 /* Factorise all lines of direction lr (1/2/3 = x/y/z) of level lv into fac / lfac. */
 int emg3d_dev_line_setup(const emg3d_level *lv, int lr, void *fac, double *lfac, void *stream);
 
+/* Point smoother: the eta edge sums of emg3d/core.py:377-390 (one value per edge, arrays
+ * shaped like ex|ey|ez) depend on the model only; computed once per level they replace 24
+ * scattered eta loads per node by 6. Optional: emg3d_dev_gauss_seidel(lr = 0) forms the sums
+ * on the fly when fac == NULL; both give identical bits. */
+size_t emg3d_point_fac_bytes(int nx, int ny, int nz, int is_complex);
+int emg3d_dev_point_setup(const emg3d_level *lv, void *fac, void *stream);
+
 /* nu sweeps of the smoother lr (0 point, 1/2/3 line along x/y/z) on level lv.
- * fac/lfac: from emg3d_dev_line_setup for the same level and lr (NULL for lr = 0). */
+ * fac/lfac: from emg3d_dev_line_setup for the same level and lr; for lr = 0 fac is the
+ * buffer of emg3d_dev_point_setup or NULL, lfac is ignored. */
 int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, const void *fac, const double *lfac,
                            void *scratch, size_t scratch_bytes, void *stream);
 

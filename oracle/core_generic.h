@@ -348,7 +348,7 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
                     }
                 }
             }
-        } else {
+        } else if (order == 1) {
             for (cc = 0; cc < 4; cc++) {
                 c = oracle_colour_order[iback ? 3 - cc : cc];
                 for (izh = 1; izh < nz; izh++)
@@ -357,6 +357,29 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
                             if ((((ixh + izh) & 1) | (((iyh + izh) & 1) << 1)) == c)
                                 FN(gs_node)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx,
                                             hy, hz, kx, ky, kz, nx, ny, nz, ixh, iyh, izh);
+            }
+        } else {
+            /* order 2: tiles of oracle_tile[0..2] nodes, eight tile colours
+             * (tx&1)|((ty&1)<<1)|((tz&1)<<2) visited in oracle_tile_order (backward:
+             * reversed); inside a tile the four node colours of order 1. */
+            const int bx = oracle_tile[0], by = oracle_tile[1], bz = oracle_tile[2];
+            const int ntx = (nx - 2) / bx + 1, nty = (ny - 2) / by + 1, ntz = (nz - 2) / bz + 1;
+            int t8, tx, ty, tz;
+            for (t8 = 0; t8 < 8; t8++) {
+                const int tc = oracle_tile_order[iback ? 7 - t8 : t8];
+                for (tz = (tc >> 2) & 1; tz < ntz; tz += 2)
+                    for (ty = (tc >> 1) & 1; ty < nty; ty += 2)
+                        for (tx = tc & 1; tx < ntx; tx += 2)
+                            for (cc = 0; cc < 4; cc++) {
+                                c = oracle_colour_order[iback ? 3 - cc : cc];
+                                for (izh = 1 + tz * bz; izh < nz && izh < 1 + (tz + 1) * bz; izh++)
+                                    for (iyh = 1 + ty * by; iyh < ny && iyh < 1 + (ty + 1) * by; iyh++)
+                                        for (ixh = 1 + tx * bx; ixh < nx && ixh < 1 + (tx + 1) * bx; ixh++)
+                                            if ((((ixh + izh) & 1) | (((iyh + izh) & 1) << 1)) == c)
+                                                FN(gs_node)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z,
+                                                            zeta, hx, hy, hz, kx, ky, kz, nx, ny, nz,
+                                                            ixh, iyh, izh);
+                            }
             }
         }
     }

@@ -18,14 +18,21 @@
 
 /* Sequence in which a FORWARD four-colour sweep visits the colour classes (backward =
  * reversed). Default 0,2,3,1 = the order of the HIP kernels (emg3d_amd/csrc/launch.h; chosen
- * because it converges fastest of the 4!/4 distinct sequences); settable for
- * experiments. */
+ * because it converges fastest of the 4!/4 distinct sequences -- as does its mirror image
+ * under x <-> y, 0,1,3,2 --); settable for experiments. */
 int oracle_colour_order[4] = {0, 2, 3, 1};
 void oracle_set_colour_order(int a, int b, int c, int d)
 {
     oracle_colour_order[0] = a; oracle_colour_order[1] = b;
     oracle_colour_order[2] = c; oracle_colour_order[3] = d;
 }
+
+/* order 2 of the point smoother: tile extents in nodes and the sequence of the eight tile
+ * colours of a FORWARD sweep (backward = reversed). */
+int oracle_tile[3] = {16, 8, 8};
+int oracle_tile_order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+void oracle_set_tile(int bx, int by, int bz) { oracle_tile[0] = bx; oracle_tile[1] = by; oracle_tile[2] = bz; }
+void oracle_set_tile_order(const int *o) { int i; for (i = 0; i < 8; i++) oracle_tile_order[i] = o[i]; }
 
 #define PASTE_(a, b) a##b
 #define PASTE(a, b) PASTE_(a, b)

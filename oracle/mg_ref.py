@@ -175,14 +175,22 @@ def restriction_weights(grid, cgrid, sc_dir):
     return out
 
 
-def smoothing(model, sfield, efield, nu, lr_dir, order=0):
+# Levels with at least this many interior nodes run the point smoother in the tiled order
+# (order 2) when a coloured order is requested -- the rule of the HIP library
+# (include/emg3d_amd.h, option "point_tile_min").
+POINT_TILE_MIN = 1 << 20
+
+
+def smoothing(model, sfield, efield, nu, lr_dir, order=0, tile_min=POINT_TILE_MIN):
     """solver.py:788-846."""
     inp = (sfield.fx, sfield.fy, sfield.fz, model.eta_x, model.eta_y, model.eta_z,
            model.zeta, model.grid.h[0], model.grid.h[1], model.grid.h[2], nu)
     c = current_lr_dir(lr_dir, model.grid)
     e = (efield.fx, efield.fy, efield.fz)
     if c == 0:
-        core.gauss_seidel(*e, *inp, order=order)
+        n = model.grid.shape_cells
+        tiled = order == 1 and tile_min > 0 and (n[0] - 1) * (n[1] - 1) * (n[2] - 1) >= tile_min
+        core.gauss_seidel(*e, *inp, order=2 if tiled else order)
     if c in (1, 5, 6, 7):
         core.gauss_seidel_x(*e, *inp, order=order)
     if c in (2, 4, 6, 7):
@@ -277,10 +285,10 @@ class Params:
 
     def __init__(self, shape_cells, cycle='F', semicoarsening=False, linerelaxation=False,
                  tol=1e-6, maxit=50, nu_init=0, nu_pre=2, nu_coarse=1, nu_post=2,
-                 clevel=-1, order=0):
+                 clevel=-1, order=0, tile_min=POINT_TILE_MIN):
         self.cycle, self.tol, self.maxit = cycle, tol, maxit
         self.nu_init, self.nu_pre, self.nu_coarse, self.nu_post = nu_init, nu_pre, nu_coarse, nu_post
-        self.order = order
+        self.order, self.tile_min = order, tile_min
         self.it, self.l2, self.l2_refe = 0, 1.0, 1.0
         self.exit_message = ''
         self.error_at_cycle = [0.]
@@ -351,7 +359,7 @@ def multigrid(model, sfield, efield, var, level=0, new_cycmax=0):
         l2_last = residual(model, sfield, efield, True)
         l2_stag = np.ones(var.maxcycle) * l2_last
         if var.nu_init > 0:
-            c = smoothing(model, sfield, efield, var.nu_init, var.lr_dir, var.order)
+            c = smoothing(model, sfield, efield, var.nu_init, var.lr_dir, var.order, var.tile_min)
             var.smooth_work += var.nu_init * ncell * NDIR[c]
 
     while level == 0 or it < cycmax:
@@ -359,11 +367,11 @@ def multigrid(model, sfield, efield, var, level=0, new_cycmax=0):
             l2_prev = l2_last  # noqa: F841
             l2_stag[(it - 1) % var.maxcycle] = l2_last
         if level == var.clevel[var.sc_dir]:
-            c = smoothing(model, sfield, efield, var.nu_coarse, var.lr_dir, var.order)
+            c = smoothing(model, sfield, efield, var.nu_coarse, var.lr_dir, var.order, var.tile_min)
             var.smooth_work += var.nu_coarse * ncell * NDIR[c]
         else:
             if var.nu_pre > 0:
-                c = smoothing(model, sfield, efield, var.nu_pre, var.lr_dir, var.order)
+                c = smoothing(model, sfield, efield, var.nu_pre, var.lr_dir, var.order, var.tile_min)
                 var.smooth_work += var.nu_pre * ncell * NDIR[c]
             sc_dir = current_sc_dir(var.sc_dir, model.grid)
             res = residual(model, sfield, efield)
@@ -371,7 +379,7 @@ def multigrid(model, sfield, efield, var, level=0, new_cycmax=0):
             multigrid(cmodel, csfield, cefield, var, level + 1, cycmax - cyc)
             prolongation(efield, cefield, sc_dir)
             if var.nu_post > 0:
-                c = smoothing(model, sfield, efield, var.nu_post, var.lr_dir, var.order)
+                c = smoothing(model, sfield, efield, var.nu_post, var.lr_dir, var.order, var.tile_min)
                 var.smooth_work += var.nu_post * ncell * NDIR[c]
         it += 1
         if level == 0:

@@ -26,6 +26,34 @@ struct LevelArgs {
 };
 
 int g_point_slab = 0;
+int g_point_tile_min = 1 << 20;
+
+// one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
+// kernels.hip (k_gs_point_tile), each workgroup's phases separated like its barriers
+template <class T> void gs_point_tiled(const emg::Level<T> &L, const T *pst, int iback)
+{
+    using TB = emg::PointTile;
+    using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+    std::vector<T> lds(E::LDS_ELEMS);
+    const int colours = emg::sweep_colours_packed(iback);
+    for (int t8 = 0; t8 < 8; ++t8) {
+        const int tc = emg::tile_colour_at(iback, t8);
+        const emg::Dim3 g = emg::tile_grid<TB>(L.nx, L.ny, L.nz, tc);
+        for (int bz = 0; bz < g.z; ++bz)
+            for (int by = 0; by < g.y; ++by)
+                for (int bx = 0; bx < g.x; ++bx) {
+                    const int x0 = 1 + ((tc & 1) + 2 * bx) * TB::BX;
+                    const int y0 = 1 + (((tc >> 1) & 1) + 2 * by) * TB::BY;
+                    const int z0 = 1 + (((tc >> 2) & 1) + 2 * bz) * TB::BZ;
+                    for (auto &v : lds) v = T(1e300);   // LDS is not initialised on the GPU either
+                    for (int t = 0; t < TB::THREADS; ++t) emg::tile_load<T, TB>(L, lds.data(), x0, y0, z0, t);
+                    for (int cc = 0; cc < 4; ++cc)
+                        for (int t = 0; t < TB::THREADS; ++t)
+                            emg::tile_colour<T, TB>(L, pst, lds.data(), x0, y0, z0, (colours >> (2 * cc)) & 3, t);
+                    for (int t = 0; t < TB::THREADS; ++t) emg::tile_store<T, TB>(L, lds.data(), x0, y0, z0, t);
+                }
+    }
+}
 
 template <class T> emg::Level<T> to_level(const LevelArgs *lv)
 {
@@ -91,13 +119,29 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
     if (lr == 1) line_setup_all<T, 0>(L, fac.data(), lfac.data());
     if (lr == 2) line_setup_all<T, 1>(L, fac.data(), lfac.data());
     if (lr == 3) line_setup_all<T, 2>(L, fac.data(), lfac.data());
+    // point smoother: odd nu runs with the precomputed eta edge sums (k_point_setup), even
+    // nu forms them on the fly -- both forms of point_load get exercised
+    std::vector<T> pstv;
+    const T *pst = nullptr;
+    if (lr == 0 && (nu & 1)) {
+        pstv.assign((size_t)nx * (ny + 1) * (nz + 1) + (size_t)(nx + 1) * ny * (nz + 1) +
+                    (size_t)(nx + 1) * (ny + 1) * nz, T(0));
+        for_threads(emg::cell_grid(nx + 1, ny + 1, nz + 1), emg::cell_block(), [&](int ix, int iy, int iz) {
+            if (ix <= nx && iy <= ny) emg::point_setup_cell<T>(L, pstv.data(), ix, iy, iz);
+        });
+        pst = pstv.data();
+    }
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;
+        if (lr == 0 && emg::point_tiled(nx, ny, nz, g_point_tile_min)) {
+            gs_point_tiled<T>(L, pst, iback);
+            continue;
+        }
         if (lr == 0) {
             emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
                 for_threads(emg::gs_point_grid(nx, ny, izn), emg::gs_point_block(),
-                            [&](int gx, int gy, int gz) { emg::gs_point_thread<T>(L, c, iz0, gx, gy, gz); });
+                            [&](int gx, int gy, int gz) { emg::gs_point_thread<T>(L, pst, c, iz0, gx, gy, gz); });
             });
             continue;
         }
@@ -125,6 +169,7 @@ template <class T> double residual(const LevelArgs *lv, void *rx, void *ry, void
 extern "C" {
 
 void emu_set_point_slab(int t) { g_point_slab = t; }
+void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
 {

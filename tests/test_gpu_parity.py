@@ -495,3 +495,70 @@ def test_solve_ragged_grids_vs_oracle(shape, kw):
     eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **kw)
     assert io['exit'] == 0
     assert relerr(e.field, eo.field) < 1e-8
+
+
+@pytest.mark.parametrize('shape', [(36, 20, 18), (16, 8, 8), (18, 34, 10), (40, 24, 33)])
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_point_tiled_schedule_vs_oracle_tile_order(shape, dtype):
+    """Tiled point smoother (k_gs_point_tile: LDS tile, eight tile colours) forced on small
+    grids with several / partial tiles, against the oracle's order 2; with the precomputed
+    eta edge sums (host flavour) and with sums formed on the fly (device flavour, fac = NULL)."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(sum(shape))
+    h = [rng.uniform(0.5, 2.0, n) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, 1.3 if dtype is complex else -1.3, *sig)
+    s = mg_ref.Field(grid, dtype=dtype)
+    e0 = mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    lib.emg3d_set_option(b'point_tile_min', 1)
+    try:
+        for nu in (1, 2):
+            a, b = e0.copy(), e0.copy()
+            ocore.gauss_seidel(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                               vm.zeta, *grid.h, nu, order=2)
+            core.gauss_seidel(b.fx, b.fy, b.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                              vm.zeta, *grid.h, nu)
+            assert relerr(b.field, a.field) < 5e-10, (shape, nu)
+            # device flavour without the eta-sum buffer
+            lv = DeviceLevel.from_host(vm, torch.device('cuda'))
+            lv.s.copy_(torch.from_numpy(s.field))
+            lv.e.copy_(torch.from_numpy(e0.field))
+            _lib.check(lib.emg3d_dev_gauss_seidel(lv._cref, 0, nu, None, None, None, 0, None), 'gs')
+            torch.cuda.synchronize()
+            assert np.array_equal(lv.e.cpu().numpy(), b.field), (shape, nu)
+    finally:
+        lib.emg3d_set_option(b'point_tile_min', 1 << 20)
+
+
+def test_solve_with_tiled_point_smoother_vs_oracle():
+    """Whole solves with the tiled order forced on every level (point_tile_min = 1): same
+    cycle count and converged field as the oracle run with the same rule."""
+    lib = _lib.lib()
+    shape = (40, 24, 32)
+    rng = np.random.default_rng(11)
+    h = [widths(n // 2, n // 4, 20., 1.1) for n in shape]
+    grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
+    rho = 10 ** rng.uniform(-0.5, 1.0, shape)
+    model = emg3d.Model(grid, rho, 1.5 * rho, 2.5 * rho)
+    sfield = emg3d.get_source_field(grid, (3., -2., 1., 20., 30.), 0.8)
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    vm = mg_ref.volume_model(ogrid, 0.8, 1 / rho, 1 / (1.5 * rho), 1 / (2.5 * rho))
+    lib.emg3d_set_option(b'point_tile_min', 1)
+    try:
+        e, info = emg3d.solve(model, sfield, sslsolver=False, semicoarsening=False,
+                              linerelaxation=False, cycle='F', tol=1e-10, return_info=True)
+    finally:
+        lib.emg3d_set_option(b'point_tile_min', 1 << 20)
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, cycle='F',
+                          order=1, tile_min=1)
+    assert info['exit'] == 0 and io['exit'] == 0
+    assert info['it_mg'] == io['it_mg']
+    assert relerr(e.field, eo.field) < 1e-8

@@ -80,11 +80,16 @@ def main():
     nc = grid.n_cells
     print(f"# {args.n}^3 {args.case}, nu={args.nu}")
     if args.what in ('point', 'all'):
+        lib.emg3d_set_option(b'point_tile_min', 1)
+        med, mn = timeit(lambda: lv.smooth(0, args.nu))
+        report("gauss_seidel (point) tiled", med, nc, args.nu, args.case)
+        lib.emg3d_set_option(b'point_tile_min', 0)
         for slab in [int(x) for x in args.slabs.split(',')]:
             lib.emg3d_set_option(b'point_slab', slab)
             med, mn = timeit(lambda: lv.smooth(0, args.nu))
             report(f"gauss_seidel (point) slab={slab}", med, nc, args.nu, args.case)
         lib.emg3d_set_option(b'point_slab', 0)
+        lib.emg3d_set_option(b'point_tile_min', 1 << 20)
     if args.what in ('lines', 'all'):
         for fuse in (0, 1):
             lib.emg3d_set_option(b'line_fuse', fuse)
