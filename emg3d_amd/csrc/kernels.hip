@@ -205,6 +205,8 @@ template <class T> __device__ __forceinline__ T quad_sum(T x)
     return x;
 }
 // Lane j's share of one block record (all loads unconditional, addresses per lane).
+// rec: record of the block's factors; rvj / rv4: records holding this lane's vec slot j and
+// slot 4 (they differ from rec for the mirrored blocks of the bottom half, stencil.h).
 template <class T> struct QuadRow {
     T t[5];          // T_k(j, 0..4)
     T t44;           // T_k(4,4)
@@ -212,17 +214,8 @@ template <class T> struct QuadRow {
     double l0[4];    // B_k(0, m), m = 1..4           (row 0 of B_k; used by lane 0 / entry 4)
     double bA, bD;   // B_k(0, j), B_k(j, j) for lane j >= 1 (lane 0: entries of m = 1, masked out)
     double d4;       // B_k(4, 4)
-    __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, int j)
+    __device__ __forceinline__ void load_b(const double *lfac, size_t rec, int j)
     {
-        const T *f = fac + rec * 15;
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            const int idx = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
-            t[m] = f[idx];
-        }
-        t44 = f[14];
-        v = vec[rec * 5 + j];
-        v4 = vec[rec * 5 + 4];
         const double *lf = lfac + rec * 8;
 #pragma unroll
         for (int m = 0; m < 4; ++m) l0[m] = lf[m];
@@ -231,35 +224,76 @@ template <class T> struct QuadRow {
         bD = lf[4 + jm];
         d4 = lf[7];
     }
+    __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, size_t rvj,
+                                         size_t rv4, int j)
+    {
+        const T *f = fac + rec * 15;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int idx = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
+            t[m] = f[idx];
+        }
+        t44 = f[14];
+        v = vec[rvj * 5 + j];
+        v4 = vec[rv4 * 5 + 4];
+        load_b(lfac, rec, j);
+    }
 };
 
 constexpr int QD = emg::LINE_PAD;   // blocks in flight per line = padding granule
 
-// The loops below are branch-free inside: loads and stores are unconditional (the records
-// are padded to a multiple of QD blocks with identity blocks, launch.h), because with
+// One half-chain of the two-sided line solve (stencil.h). HALF 0: the top half, standard
+// blocks k = 0 .. m-1 walked upwards; HALF 1: the bottom half, mirrored blocks walked from
+// the padded far end n0p-1 down to m+2. A half has `steps` blocks (a multiple of QD,
+// possibly 0); step i works on block kof(i).
+template <int HALF> struct HalfWalk {
+    int mk, n0p, steps;
+    __device__ __forceinline__ HalfWalk(int n0, int n0p_) : mk(emg::line_mid(n0)), n0p(n0p_)
+    {
+        steps = HALF ? n0p - 2 - mk : mk;
+    }
+    // forward pass: towards the middle
+    __device__ __forceinline__ int fwd(int i) const { return HALF ? n0p - 1 - i : i; }
+    // backward pass: away from the middle
+    __device__ __forceinline__ int bwd(int i) const { return HALF ? mk + 2 + i : mk - 1 - i; }
+    __device__ __forceinline__ int clampi(int i) const { return max(min(i, steps - 1), 0); }
+};
+// records of the vec slots of lane j / of slot 4 for block k of line `line`
+template <int HALF> __device__ __forceinline__ size_t slot_rec(int k, int nlines, int line, bool first)
+{
+    return (size_t)((HALF && !first) ? k - 1 : k) * nlines + line;
+}
+
+// The loops below are branch-free inside: loads and stores are unconditional (the halves
+// are padded to a multiple of QD blocks with identity blocks, stencil.h), because with
 // branches around memory operations the compiler's s_waitcnt insertion falls back to
 // vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
 // last line walk the last line again but store into a dummy area behind the records.
-template <class T>
-__device__ __forceinline__ void quad_forward(int n0p, int nlines, int qline, int j, const T *fac,
+template <class T, int HALF>
+__device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int j, const T *fac,
                                              const double *lfac, T *vec, T *dummy)
 {
+    const HalfWalk<HALF> W(n0, n0p);
     const bool active = qline < nlines;
     const int line = min(qline, nlines - 1);
-    T *const obase = active ? vec + (size_t)line * 5 : dummy + (threadIdx.x >> 2) * 5;
-    const size_t ostride = active ? (size_t)nlines * 5 : 0;
+    T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
     QuadRow<T> ring[QD];
+    auto fetch = [&](QuadRow<T> &q, int i) {
+        const int k = W.fwd(W.clampi(i));
+        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, nlines, line, j == 0),
+               slot_rec<HALF>(k, nlines, line, false), j);
+    };
 #pragma unroll
-    for (int d = 0; d < QD; ++d) ring[d].load(fac, lfac, vec, (size_t)d * nlines + line, j);
+    for (int d = 0; d < QD; ++d) fetch(ring[d], d);
     T w[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) w[r] = emg::zero<T>();
     T wmine = emg::zero<T>();                    // this lane's own entry of w
     const double nz = j != 0 ? 1.0 : 0.0, is0 = 1.0 - nz;
-    for (int k0 = 0; k0 < n0p; k0 += QD) {
+    for (int i0 = 0; i0 < W.steps; i0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
-            const int k = k0 + d;
+            const int k = W.fwd(i0 + d);
             const QuadRow<T> &q = ring[d];
             // c_j = rhs_j - (B w_prev)_j ; row 0: sum_m B(0,m) w_m (lane 0) ; row j: B(j,j) w_j
             T bw0 = emg::zero<T>();
@@ -274,66 +308,146 @@ __device__ __forceinline__ void quad_forward(int n0p, int nlines, int qline, int
             w[0] = quad_bcast<0>(wn); w[1] = quad_bcast<1>(wn); w[2] = quad_bcast<2>(wn); w[3] = quad_bcast<3>(wn);
             w[4] = w4;
             wmine = wn;
-            T *o = obase + (size_t)k * ostride;
-            o[j] = wn;
-            o[4] = w4;
-            ring[d].load(fac, lfac, vec, (size_t)min(k + QD, n0p - 1) * nlines + line, j);
+            T *const oj = active ? vec + slot_rec<HALF>(k, nlines, line, j == 0) * 5 + j : dslot + j;
+            T *const o4 = active ? vec + slot_rec<HALF>(k, nlines, line, false) * 5 + 4 : dslot + 4;
+            *oj = wn;
+            *o4 = w4;
+            fetch(ring[d], i0 + d + QD);
         }
     }
 }
 
 template <class T>
-__global__ __launch_bounds__(64) void k_line_forward(int n0p, int nlines, const T *fac, const double *lfac,
+__global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines, const T *fac, const double *lfac,
                                                      T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
-    quad_forward<T>(n0p, nlines, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, vec, dummy);
 }
 
-// Backward substitution fused with the scatter into the field (core.py:775-783): lane j
-// writes entry j of block k straight to its edge, every lane writes entry 4. Entries that
-// do not exist (padding blocks, entries 1..4 of the last block, surplus quads) go to the
-// dummy area through an address select -- no predicate, no branch.
-template <class T, int DIR>
+// Middle block of the two-sided solve (stencil.h: line_middle), computed by every lane of
+// both half-waves redundantly: x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}]).
+template <class T>
+__device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int line, const T *fac, const double *lfac,
+                                            const T *vec, T (&xq)[6])
+{
+    const int mk = emg::line_mid(n0);
+    const size_t rm = (size_t)mk * nlines + line, rp = rm + nlines;
+    T z[6];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) z[r] = vec[rm * 5 + r];
+    z[5] = vec[rp * 5];
+    {   // top coupling B_m w_{m-1} (zero if there is no top half: B_0 = 0 is stored as zeros)
+        const size_t rt = mk > 0 ? rm - nlines : rm;
+        const double *lf = lfac + rm * 8;
+        T q0 = emg::zero<T>();
+#pragma unroll
+        for (int m = 1; m < 5; ++m) {
+            const T y = vec[rt * 5 + m];
+            q0 += lf[m - 1] * y;
+            z[m] -= lf[3 + m] * y;
+        }
+        z[0] -= q0;
+    }
+    {   // bottom coupling U_{m+1} w_{m+2}; w_{m+2} = slots (m+2, 0), (m+1, 1..4); U of an
+        // identity padding block is zero, so no guard is needed (m+2 <= n0p-1 always)
+        const double *lf = lfac + rp * 8;
+        T q0 = emg::zero<T>();
+#pragma unroll
+        for (int m = 1; m < 5; ++m) {
+            const T y = vec[rp * 5 + m];
+            q0 += lf[m - 1] * y;
+            z[m] -= lf[3 + m] * y;
+        }
+        z[5] -= q0;
+    }
+    T tq[21];
+#pragma unroll
+    for (int jj = 0; jj < 15; ++jj) tq[jj] = fac[rm * 15 + jj];
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) tq[15 + jj] = fac[rp * 15 + jj];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        T acc = emg::zero<T>();
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc += tq[emg::sym(r, m)] * z[m];
+        xq[r] = acc;
+    }
+}
+
+// Backward substitution of one half, outwards from the middle block, fused with the scatter
+// into the field (core.py:775-783): lane j writes entry j of block k straight to its edge,
+// every lane writes entry 4. Entries that do not exist (padding blocks, surplus quads) go to
+// the dummy area through an address select -- no predicate, no branch. The top half also
+// writes the middle block.
+template <class T, int DIR, int HALF>
 __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
                                               int qline, int j, const T *fac, const double *lfac, const T *vec,
                                               T *dummy)
 {
     const emg::Axes<T, DIR> A(L);
     const int n0 = A.n0();
+    const HalfWalk<HALF> W(n0, n0p);
+    const int mk = W.mk;
     const int nlines = cntp * cntq;
     const bool active = qline < nlines;
     const int line = min(qline, nlines - 1);
     int i1, i2, lid;
     emg::line_of_thread<DIR>(colour, cntp, cntq, line % cntp, line / cntp, i1, i2, lid);
-    // entry j lives on component cj at (k + dk, i1 - d1, i2 - d2); entry 4 on component 2
-    const int cj = j == 0 ? 0 : (j <= 2 ? 1 : 2), dk = j == 0 ? 0 : 1;
+    // entry j lives on component cj at (k + dk, i1 - d1, i2 - d2); entry 4 on component 2.
+    // standard blocks carry the transverse edges of node k+1, mirrored blocks those of node k
+    const int cj = j == 0 ? 0 : (j <= 2 ? 1 : 2), dk = (j == 0 || HALF) ? 0 : 1, dk4 = HALF ? 0 : 1;
     const int d1 = j == 1 ? 1 : 0, d2 = j == 3 ? 1 : 0;
     T *const ej = A.E(cj) + A.idx(cj, dk, i1 - d1, i2 - d2);
     const long sj = (long)A.idx(cj, dk + 1, i1 - d1, i2 - d2) - (long)A.idx(cj, dk, i1 - d1, i2 - d2);
-    T *const e4 = A.E(2) + A.idx(2, 1, i1, i2);
-    const long s4 = (long)A.idx(2, 2, i1, i2) - (long)A.idx(2, 1, i1, i2);
-    T *const dj = dummy + (threadIdx.x >> 2) * 5 + j, *const d4 = dummy + (threadIdx.x >> 2) * 5 + 4;
-    const int lastj = j == 0 ? n0 - 1 : n0 - 2;     // last block in which entry j exists
+    T *const e4 = A.E(2) + A.idx(2, dk4, i1, i2);
+    const long s4 = (long)A.idx(2, dk4 + 1, i1, i2) - (long)A.idx(2, dk4, i1, i2);
+    T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
+    T *const dj = dslot + j, *const d4 = dslot + 4;
 
-    const int last = n0p - 1;
     QuadRow<T> ring[QD];
+    auto fetch = [&](QuadRow<T> &q, int i) {
+        const int k = min(max(W.bwd(W.clampi(i)), HALF), n0p - 1);   // a half without blocks still prefetches
+        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, nlines, line, j == 0),
+               slot_rec<HALF>(k, nlines, line, false), j);
+    };
 #pragma unroll
-    for (int d = 0; d < QD; ++d) ring[d].load(fac, lfac, vec, (size_t)(last - d) * nlines + line, j);
-    // x = 0 and B = 0: the identity padding keeps x = 0 until the first real block, where
-    // the step yields x_{n0-1} = w_{n0-1}
+    for (int d = 0; d < QD; ++d) fetch(ring[d], d);
+    // coupling to the middle: B_m (top) / U_{m+1} (bottom)
+    QuadRow<T> qm;
+    qm.load_b(lfac, (size_t)(HALF ? mk + 1 : mk) * nlines + line, j);
+
+    T xq[6];
+    quad_middle<T>(n0, n0p, nlines, line, fac, lfac, vec, xq);
+    // per-lane selection by 0/1 weights: a select chain on the lane index would be compiled
+    // into a scratch-memory array lookup
+    const double xsel[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
+    if (HALF == 0) {
+        // lanes 0..3 write entries 0..3 of x_Q (E0(m), t(m+1)_1..3), lane 0 also entry 4,
+        // lane 1 entry 5 (E0(m+1)); the transverse edges of node m+1 are the entries of
+        // "standard block m"
+        const int dkm = j == 0 ? 0 : 1;
+        T *const pm = A.E(cj) + A.idx(cj, mk + dkm, i1 - d1, i2 - d2);
+        *(active ? pm : dj) = xsel[0] * xq[0] + xsel[1] * xq[1] + (xsel[2] * xq[2] + xsel[3] * xq[3]);
+        T *const p4 = A.E(2) + A.idx(2, mk + 1, i1, i2);
+        T *const p5 = A.E(0) + A.idx(0, mk + 1, i1, i2);
+        *((active && j == 0) ? p4 : ((active && j == 1) ? p5 : d4)) = xsel[1] * xq[5] + (1.0 - xsel[1]) * xq[4];
+    }
+    // x of the block next to the walk: standard block m / mirrored block m+1 of x_Q
     T x[5];
+    x[0] = HALF ? xq[5] : xq[0];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) x[r] = emg::zero<T>();
-    T xmine = emg::zero<T>();                    // this lane's own entry of x
-    double upA = 0.0, upD = 0.0, up03 = 0.0, up44 = 0.0;   // entries of B_{k+1}
+    for (int r = 1; r < 5; ++r) x[r] = xq[r];
+    T xmine = xsel[0] * x[0] + xsel[1] * x[1] + (xsel[2] * x[2] + xsel[3] * x[3]);   // this lane's own entry of x
+    double upA = qm.bA, upD = qm.bD, up03 = qm.l0[3], up44 = qm.d4;        // entries of the coupling block
     const double nz = j != 0 ? 1.0 : 0.0;
-    for (int k0 = 0; k0 < n0p; k0 += QD) {
+    for (int i0 = 0; i0 < W.steps; i0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
-            const int k = last - (k0 + d);
+            const int k = W.bwd(i0 + d);
             const QuadRow<T> &q = ring[d];
-            // h = B_{k+1}^T x_{k+1}: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
+            // h = B^T x_prev: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
             const T hj = (upA * nz) * x[0] + (upD * nz) * xmine;
             const T h4 = up03 * x[0] + up44 * x[4];
             const T h0 = quad_bcast<0>(hj), h1 = quad_bcast<1>(hj), h2 = quad_bcast<2>(hj), h3 = quad_bcast<3>(hj);
@@ -343,11 +457,12 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
             x[4] = x4;
             xmine = xn;
             upA = q.bA; upD = q.bD; up03 = q.l0[3]; up44 = q.d4;
-            T *const oj = (active && k <= lastj) ? ej + (long)k * sj : dj;
-            T *const o4 = (active && k <= n0 - 2) ? e4 + (long)k * s4 : d4;
+            const bool real_block = HALF ? k <= n0 - 1 : true;
+            T *const oj = (active && real_block) ? ej + (long)k * sj : dj;
+            T *const o4 = (active && real_block) ? e4 + (long)k * s4 : d4;
             *oj = xn;
             *o4 = x4;
-            ring[d].load(fac, lfac, vec, (size_t)max(k - QD, 0) * nlines + line, j);
+            fetch(ring[d], i0 + d + QD);
         }
     }
 }
@@ -357,33 +472,39 @@ __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colou
                                                       const T *fac, const double *lfac, const T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
-    quad_backward<T, DIR>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+    if (blockIdx.y == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, vec, dummy);
 }
 
-// One launch per colour for small levels: every wave owns 16 lines and runs rhs assembly,
-// forward and backward substitution for them back to back. Lines of one colour class are
-// independent, so only the wave's own rhs records have to be complete before its forward
-// pass starts (workgroup barrier of a one-wave workgroup). On the coarse levels the three
+// One launch per colour for small levels: a workgroup of two waves owns 16 lines -- wave 0
+// their top halves, wave 1 their bottom halves -- and runs rhs assembly, forward and
+// backward substitution for them back to back. Lines of one colour class are independent,
+// so only the workgroup's own records have to be complete between the phases (workgroup
+// barriers; both waves sit on one CU and share its L1). On the coarse levels the three
 // separate launches are bound by launch latency, not by work.
 template <class T, int DIR>
-__global__ __launch_bounds__(64) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                    const T *fac, const double *lfac, T *vec, T *dummy)
+__global__ __launch_bounds__(128) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                     const T *fac, const double *lfac, T *vec, T *dummy)
 {
     const emg::Axes<T, DIR> A(L);
     const int nlines = cntp * cntq;
     const int line0 = blockIdx.x * 16;
     const int nl = min(16, nlines - line0);
-    // (1) right-hand sides of the wave's lines; x-lines run the lanes along the line
-    for (int i = threadIdx.x; i < nl * n0p; i += 64) {
+    // (1) right-hand sides of the workgroup's lines; x-lines run the lanes along the line
+    for (int i = threadIdx.x; i < nl * n0p; i += 128) {
         const int ll = DIR == 0 ? i / n0p : i % nl;
         const int k = DIR == 0 ? i % n0p : i / nl;
         const int lid = line0 + ll;
         emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, lid % cntp, lid / cntp, k, vec);
     }
     __syncthreads();
-    const int qline = line0 + (threadIdx.x >> 2), j = threadIdx.x & 3;
-    quad_forward<T>(n0p, nlines, qline, j, fac, lfac, vec, dummy);
-    quad_backward<T, DIR>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, vec, dummy);
+    const int half = threadIdx.x >> 6;
+    const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
+    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, j, fac, lfac, vec, dummy);
+    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, j, fac, lfac, vec, dummy);
+    __syncthreads();
+    if (half == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, vec, dummy);
+    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, vec, dummy);
 }
 
 // Residual + per-block partial sums of |r|^2.
@@ -490,11 +611,13 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 bgp = d3(emg::lineblk_grid(lc, true));
     const T *f = fac + lc.fac_off;
     const double *lf = lfac + lc.lfac_off;
-    const dim3 qb = d3(emg::linequad_block()), qg = d3(emg::linequad_grid(lc));
+    const dim3 qb = d3(emg::linequad_block());
+    const emg::Dim3 q1 = emg::linequad_grid(lc);
+    const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
     const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
     if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
-        hipLaunchKernelGGL((k_line_colour<T, DIR>), qg, qb, 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f, lf, vec,
-                           vec + dummy_off);
+        hipLaunchKernelGGL((k_line_colour<T, DIR>), dim3(q1.x), dim3(128), 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f,
+                           lf, vec, vec + dummy_off);
         return;
     }
     if (DIR == 0)
@@ -502,8 +625,8 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                            L, c, lc.cntp, lc.cntq, lc.n0p, vec);
     else
         hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
-    hipLaunchKernelGGL(k_line_forward<T>, qg, qb, 0, st, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
-    hipLaunchKernelGGL((k_line_backward<T, DIR>), qg, qb, 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f, lf,
+    hipLaunchKernelGGL(k_line_forward<T>, qg2, qb, 0, st, lc.n0, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
+    hipLaunchKernelGGL((k_line_backward<T, DIR>), qg2, qb, 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f, lf,
                        (const T *)vec, vec + dummy_off);
 }
 

@@ -237,14 +237,10 @@ inline int line_np(int dir, int nx, int ny, int nz) { (void)nz; return dir == 0 
 inline int line_nq(int dir, int nx, int ny, int nz) { (void)nx; return dir == 2 ? ny : nz; }
 inline int line_n0(int dir, int nx, int ny, int nz) { return dir == 0 ? nx : dir == 1 ? ny : nz; }
 
-// The factor / rhs records of a line are padded to a multiple of LINE_PAD blocks with
-// "identity" blocks (C = 0, 1/D = 1, B = 0, rhs = 0), so that the forward / backward
-// kernels can run a LINE_PAD-times unrolled, branch-free software pipeline.
-constexpr int LINE_PAD = 4;
+// (LINE_PAD, line_mid, line_padded: stencil.h -- record layout of the two-sided factorisation)
 // elements at the tail of the rhs/solution scratch that absorb the stores of the surplus
 // quads of the last wave of the forward / backward kernels (16 quads x 5 entries)
 constexpr int LINE_DUMMY = 80;
-EMG_HD int line_padded(int n0) { return (n0 + LINE_PAD - 1) / LINE_PAD * LINE_PAD; }
 
 // Geometry of one colour class of one direction on one level.
 struct LineClass {

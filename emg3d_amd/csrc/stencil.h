@@ -696,70 +696,257 @@ template <class T> EMG_HD void ldlt5_solve(const T (&C)[10], const T (&dinv)[5],
     }
 }
 
-// Setup of one line: block factorisation, stored in (fac, lfac). Sequential along the line.
+// ---- two-sided ("twisted") block factorisation -----------------------------------------
+// The recurrence along a line is sequential, and on the GPU its length is what a sweep
+// costs: one wave serves 16 lines, a colour class has far fewer waves than the chip has
+// SIMDs, and every wave is bound by the issue rate / latency of its own chain. The line is
+// therefore eliminated from BOTH ends by two waves working at the same time.
+//
+// Unknowns along a line: E0(k), k = 0..n0-1 (the edges on the line) and t(k), k = 1..n0-1
+// (the four transverse edges at node k). The reference's block k is {E0(k), t(k+1)}
+// ("standard" grouping; the last block has E0 only). Eliminating standard blocks from the
+// far end is numerically poor -- the near-null (gradient) direction of such a trailing
+// Schur complement is spread over all five unknowns and products with its inverse cancel --
+// so the far half uses the MIRRORED grouping {E0(k), t(k)}, for which the elimination from
+// the far end is the exact mirror image of the reference's from the near end:
+//
+//   top     k = 0 .. m-1      standard blocks {E0(k), t(k+1)},  S_k = M_k - B_k T_{k-1} B_k^T
+//   bottom  k = n0-1 .. m+2   mirrored blocks {E0(k), t(k)},    S_k = M'_k - U_k T_{k+1} U_k^T
+//   middle  Q = {E0(m), t(m+1), E0(m+1)}  (standard block m merged with mirrored block m+1,
+//           which share t(m+1)), 6 x 6:  S_Q = M_Q - [B_m T_{m-1} B_m^T] - [U_{m+1} T_{m+2} U_{m+1}^T]
+// with T = S^{-1}; M'_k(0,0) = M_k(0,0), M'_k(0,j) = B_k(0,j), M'_k(a,b) = M_{k-1}(a,b) and
+// the coupling of mirrored block k to mirrored block k+1  U_k = e0 u^T + diag(0, d),
+// u_j = M_k(0,j), d_j = B_k(j,j) -- the same shape as B_k. A solve is
+//   forward:  top     w_k = T_k (r_k - B_k w_{k-1}),        k = 0 .. m-1
+//             bottom  w_k = T_k (r'_k - U_k w_{k+1}),       k = n0-1 .. m+2
+//   middle:   x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}])
+//   backward: top     x_k = w_k - T_k B_{k+1}^T x_{k+1},    k = m-1 .. 0
+//             bottom  x_k = w_k - T_k U_{k-1}^T x_{k-1},    k = m+2 .. n0-1
+// i.e. two chains of half the length per pass, both of the reference's top-down form. It
+// is the same direct solve of the line system as core.solve's LDL^T
+// (emg3d/core.py:1481-1616), in a different elimination order.
+//
+// Records (block-major, record k of line lid at k*nlines + lid):
+//   fac : k < m: T_k; k >= m+2: T_k of the mirrored block; records m and m+1 together hold
+//         the 21 packed entries of T_Q (15 + 6)
+//   lfac: k <= m: B_k; k >= m+1: U_k        (j = 0..3: first row, j = 4..7: diagonal)
+//   vec : slot (k, 0) belongs to E0(k), slot (k, j) to t(k+1)_j -- whatever the grouping
+// m = line_mid(n0) is a multiple of LINE_PAD; behind block n0-1 the bottom half is padded
+// with identity blocks (T = 1, U = 0, rhs = 0) to a multiple of LINE_PAD, so that both
+// half-walks run a LINE_PAD-times unrolled, branch-free software pipeline.
+constexpr int LINE_PAD = 4;
+EMG_HD int line_mid(int n0) { return (n0 / 2) / LINE_PAD * LINE_PAD; }
+EMG_HD int line_padded(int n0)
+{
+    const int m = line_mid(n0);
+    return m + 2 + (n0 - 2 - m + LINE_PAD - 1) / LINE_PAD * LINE_PAD;
+}
+
+// packed index of T(r,m) = T(m,r)
+EMG_HD constexpr int sym(int r, int m) { return r >= m ? r * (r + 1) / 2 + m : m * (m + 1) / 2 + r; }
+
+// S -= B T B^T, T = (C D C^T)^{-1}, B = e0 l0^T + diag(0, d1..d4)  (lower triangle of S)
+template <class T>
+EMG_HD void sub_lower_coupling(T (&S)[5][5], const T (&C)[10], const T (&dinv)[5], const double (&left0)[5],
+                               const double (&leftd)[5])
+{
+    // columns of T that are needed: T l0 and T e_m (m=1..4) -> 5 solves
+    T tl[5];                              // T l0
+    tl[0] = zero<T>();
+#pragma unroll
+    for (int m = 1; m < 5; ++m) tl[m] = T(left0[m]);
+    ldlt5_solve<T>(C, dinv, tl);
+    T s00 = zero<T>();
+#pragma unroll
+    for (int m = 1; m < 5; ++m) s00 += left0[m] * tl[m];
+    S[0][0] -= s00;
+#pragma unroll
+    for (int r = 1; r < 5; ++r) S[r][0] -= leftd[r] * tl[r];       // (D T l0)_r
+    // D T D, lower triangle: columns T e_m
+#pragma unroll
+    for (int m = 1; m < 5; ++m) {
+        T col[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) col[r] = (r == m) ? T(1.0) : zero<T>();
+        ldlt5_solve<T>(C, dinv, col);
+#pragma unroll
+        for (int r = m; r < 5; ++r) S[r][m] -= (leftd[r] * leftd[m]) * col[r];
+    }
+}
+// explicit inverse (packed symmetric) from the LDL^T factors: five solves
+template <class T> EMG_HD void invert5(const T (&C)[10], const T (&dinv)[5], T (&Tp)[15])
+{
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        T col[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) col[r] = (r == m) ? T(1.0) : zero<T>();
+        ldlt5_solve<T>(C, dinv, col);
+#pragma unroll
+        for (int r = m; r < 5; ++r) Tp[tri(r + 1, m)] = col[r];
+    }
+}
+// inverse of a dense complex-symmetric 6 x 6 (lower triangle of S given) by LDL^T without
+// pivoting, packed symmetric result Tq[sym(r,m)]
+template <class T> EMG_HD void invert6(const T (&S)[6][6], T (&Tq)[21])
+{
+    T Lm[6][6], dinv[6];
+    for (int i = 0; i < 6; ++i) {
+        T u[6];
+        for (int j = 0; j < i; ++j) {
+            T t = S[i][j];
+            for (int kk = 0; kk < j; ++kk) t -= u[kk] * Lm[j][kk];
+            u[j] = t;
+            Lm[i][j] = t * dinv[j];
+        }
+        T d = S[i][i];
+        for (int kk = 0; kk < i; ++kk) d -= u[kk] * Lm[i][kk];
+        dinv[i] = recip(d);
+    }
+    for (int m = 0; m < 6; ++m) {
+        T b[6];
+        for (int r = 0; r < 6; ++r) b[r] = (r == m) ? T(1.0) : zero<T>();
+        for (int i = 1; i < 6; ++i)
+            for (int kk = 0; kk < i; ++kk) b[i] -= Lm[i][kk] * b[kk];
+        for (int i = 0; i < 6; ++i) b[i] *= dinv[i];
+        for (int j = 4; j >= 0; --j)
+            for (int kk = j + 1; kk < 6; ++kk) b[j] -= Lm[kk][j] * b[kk];
+        for (int r = m; r < 6; ++r) Tq[sym(r, m)] = b[r];
+    }
+}
+
+// Matrix of the MIRRORED block k = {E0(k), t(k)} and its coupling U_k to mirrored block k+1,
+// from the standard quantities of blocks k and k-1 (see above). 1 <= k <= n0-1.
+template <class T, int DIR>
+EMG_HD void line_matrix_mirrored(const Axes<T, DIR> &A, int k, int i1, int i2, T (&S)[5][5], double (&u0)[5],
+                                 double (&ud)[5])
+{
+    T dg[5], dgp[5];
+    double mid[5][5], midp[5][5], left0[5], leftd[5], l0p[5], ldp[5];
+    line_matrix<T, DIR>(A, k, i1, i2, dg, mid, left0, leftd);
+    line_matrix<T, DIR>(A, k - 1, i1, i2, dgp, midp, l0p, ldp);
+    const bool last = k == A.n0() - 1;
+    S[0][0] = dg[0];
+#pragma unroll
+    for (int a = 1; a < 5; ++a) {
+        S[a][0] = T(left0[a]);
+        S[a][a] = dgp[a];
+#pragma unroll
+        for (int b = 1; b < a; ++b) S[a][b] = T(midp[a][b]);
+        u0[a] = last ? 0.0 : mid[a][0];
+        ud[a] = last ? 0.0 : leftd[a];
+    }
+    u0[0] = 0.0;
+    ud[0] = 0.0;
+}
+
+// Setup of one line: two-sided block factorisation, stored in (fac, lfac). Sequential
+// along the line (once per level and direction).
 template <class T, int DIR>
 EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int nlines, int lid, int n0p)
 {
     const Axes<T, DIR> A(L);
     const int n0 = A.n0();
-    T C[10], dinv[5];        // factors of the previous block's S
+    const int mk = line_mid(n0);
+    T C[10], dinv[5];        // factors of the previous block's S (top chain)
     T dg[5];
     double mid[5][5], left0[5], leftd[5];
-    for (int k = 0; k < n0; ++k) {
-        line_matrix<T, DIR>(A, k, i1, i2, dg, mid, left0, leftd);
-        T S[5][5];
+    auto put_T = [&](int k, const T (&Tp)[15]) {
+        T *f = fac + ((size_t)k * nlines + lid) * 15;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) f[j] = Tp[j];
+    };
+    auto put_B = [&](int k, const double (&b0)[5], const double (&bd)[5], bool any) {
+        double *lf = lfac + ((size_t)k * nlines + lid) * 8;
+#pragma unroll
+        for (int m = 1; m < 5; ++m) {
+            lf[m - 1] = any ? b0[m] : 0.0;
+            lf[3 + m] = any ? bd[m] : 0.0;
+        }
+    };
+    auto std_S = [&](T (&S)[5][5]) {
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
             S[r][r] = dg[r];
 #pragma unroll
             for (int m = 0; m < r; ++m) S[r][m] = T(mid[r][m]);
         }
-        if (k > 0) {
-            // S -= B T B^T with T = S_{k-1}^{-1} and B = e0 l0^T + diag(0, d1..d4):
-            // columns of T that are needed: T l0 and T e_m (m=1..4) -> 5 solves
-            T tl[5];                              // T l0
-            tl[0] = zero<T>();
+    };
+    // ---- top chain: standard blocks k = 0 .. m-1
+    for (int k = 0; k < mk; ++k) {
+        line_matrix<T, DIR>(A, k, i1, i2, dg, mid, left0, leftd);
+        T S[5][5];
+        std_S(S);
+        if (k > 0) sub_lower_coupling<T>(S, C, dinv, left0, leftd);
+        ldlt5<T>(S, 5, C, dinv);
+        T Tp[15];
+        invert5<T>(C, dinv, Tp);
+        put_T(k, Tp);
+        put_B(k, left0, leftd, k > 0);
+    }
+    // standard part of the middle: S_m = M_m - B_m T_{m-1} B_m^T  (rows/cols 0..4 of S_Q)
+    T SQ[6][6];
+    {
+        line_matrix<T, DIR>(A, mk, i1, i2, dg, mid, left0, leftd);
+        T S[5][5];
+        std_S(S);
+        if (mk > 0) sub_lower_coupling<T>(S, C, dinv, left0, leftd);
+        put_B(mk, left0, leftd, mk > 0);
 #pragma unroll
-            for (int m = 1; m < 5; ++m) tl[m] = T(left0[m]);
-            ldlt5_solve<T>(C, dinv, tl);
-            T s00 = zero<T>();
+        for (int r = 0; r < 5; ++r)
 #pragma unroll
-            for (int m = 1; m < 5; ++m) s00 += left0[m] * tl[m];
-            S[0][0] -= s00;
+            for (int m = 0; m <= r; ++m) SQ[r][m] = S[r][m];
+    }
+    // ---- bottom chain: mirrored blocks k = n0-1 .. m+2
+    T Cb[10], db[5];         // factors of the previous block's S (bottom chain)
+    double u0[5], ud[5];
+    for (int k = n0 - 1; k >= mk + 2; --k) {
+        T S[5][5];
+        line_matrix_mirrored<T, DIR>(A, k, i1, i2, S, u0, ud);
+        if (k < n0 - 1) sub_lower_coupling<T>(S, Cb, db, u0, ud);
+        ldlt5<T>(S, 5, Cb, db);
+        T Tp[15];
+        invert5<T>(Cb, db, Tp);
+        put_T(k, Tp);
+        put_B(k, u0, ud, true);
+    }
+    // mirrored part of the middle: block m+1 = {E0(m+1), t(m+1)} -> Q indices {5, 1..4}
+    {
+        T S[5][5];
+        line_matrix_mirrored<T, DIR>(A, mk + 1, i1, i2, S, u0, ud);
+        put_B(mk + 1, u0, ud, true);
+        // only what block m has not contributed: E0(m+1) row/column (t(m+1) x t(m+1) is M_m's)
+        T Sc[5][5];
 #pragma unroll
-            for (int r = 1; r < 5; ++r) S[r][0] -= leftd[r] * tl[r];       // (D T l0)_r
-            // D T D, lower triangle: columns T e_m
+        for (int r = 0; r < 5; ++r)
 #pragma unroll
-            for (int m = 1; m < 5; ++m) {
-                T col[5];
+            for (int m = 0; m <= r; ++m) Sc[r][m] = zero<T>();
+        Sc[0][0] = S[0][0];
 #pragma unroll
-                for (int r = 0; r < 5; ++r) col[r] = (r == m) ? T(1.0) : zero<T>();
-                ldlt5_solve<T>(C, dinv, col);
+        for (int a = 1; a < 5; ++a) Sc[a][0] = S[a][0];
+        if (mk + 1 < n0 - 1) sub_lower_coupling<T>(Sc, Cb, db, u0, ud);
+        SQ[5][5] = Sc[0][0];
+        SQ[5][0] = zero<T>();                    // E0(m+1) and E0(m) are not coupled
 #pragma unroll
-                for (int r = m; r < 5; ++r) S[r][m] -= (leftd[r] * leftd[m]) * col[r];
-            }
-        }
-        ldlt5<T>(S, (k == n0 - 1) ? 1 : 5, C, dinv);
-        T *f = fac + ((size_t)k * nlines + lid) * 15;
-        double *lf = lfac + ((size_t)k * nlines + lid) * 8;
-        // T_k = S_k^{-1}: column m from the solve with e_m; lower triangle packed
+        for (int a = 1; a < 5; ++a) {
+            SQ[5][a] = Sc[a][0];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            T col[5];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) col[r] = (r == m) ? T(1.0) : zero<T>();
-            ldlt5_solve<T>(C, dinv, col);
-#pragma unroll
-            for (int r = m; r < 5; ++r) f[tri(r + 1, m)] = col[r];
-        }
-#pragma unroll
-        for (int m = 1; m < 5; ++m) {
-            lf[m - 1] = (k > 0) ? left0[m] : 0.0;
-            // the last block has a single row: its B has a first row only
-            lf[3 + m] = (k > 0 && k < n0 - 1) ? leftd[m] : 0.0;
+            for (int b = 1; b <= a; ++b) SQ[a][b] += Sc[a][b];
         }
     }
-    // identity padding blocks (launch.h: LINE_PAD)
+    {
+        T Tq[21];
+        invert6<T>(SQ, Tq);
+        T *f = fac + ((size_t)mk * nlines + lid) * 15;
+        T *g = fac + ((size_t)(mk + 1) * nlines + lid) * 15;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) f[j] = Tq[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) g[j] = Tq[15 + j];
+#pragma unroll
+        for (int j = 6; j < 15; ++j) g[j] = zero<T>();
+    }
+    // identity padding blocks behind the last block
     for (int k = n0; k < n0p; ++k) {
         T *f = fac + ((size_t)k * nlines + lid) * 15;
         double *lf = lfac + ((size_t)k * nlines + lid) * 8;
@@ -769,85 +956,139 @@ EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, 
     }
 }
 
-// packed index of T(r,m) = T(m,r)
-EMG_HD constexpr int sym(int r, int m) { return r >= m ? r * (r + 1) / 2 + m : m * (m + 1) / 2 + r; }
-
-// One block of the forward substitution: c holds rhs_k on entry; w is w_{k-1} on entry
-// and w_k = T_k (rhs_k - B_k w_{k-1}) on exit.
-template <class T>
-EMG_HD void line_forward_step(const T (&Tk)[15], const double (&l0)[4], const double (&ld)[4], T (&c)[5],
-                              T (&w)[5])
+// q = B y  /  q = B^T y  for B = e0 l0^T + diag(0, ld)
+template <class T> EMG_HD void couple_lower(const double (&l0)[4], const double (&ld)[4], const T (&y)[5], T (&q)[5])
 {
     T v0 = zero<T>();
 #pragma unroll
-    for (int m = 1; m < 5; ++m) v0 += l0[m - 1] * w[m];
-    c[0] -= v0;
+    for (int m = 1; m < 5; ++m) v0 += l0[m - 1] * y[m];
+    q[0] = v0;
 #pragma unroll
-    for (int m = 1; m < 5; ++m) c[m] -= ld[m - 1] * w[m];
+    for (int m = 1; m < 5; ++m) q[m] = ld[m - 1] * y[m];
+}
+template <class T> EMG_HD void couple_upper(const double (&l0)[4], const double (&ld)[4], const T (&y)[5], T (&q)[5])
+{
+    q[0] = zero<T>();
+#pragma unroll
+    for (int m = 1; m < 5; ++m) q[m] = l0[m - 1] * y[0] + ld[m - 1] * y[m];
+}
+template <class T> EMG_HD void sym_matvec(const T (&Tk)[15], const T (&z)[5], T (&o)[5])
+{
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
         T acc = zero<T>();
 #pragma unroll
-        for (int m = 0; m < 5; ++m) acc += Tk[sym(r, m)] * c[m];
-        w[r] = acc;
+        for (int m = 0; m < 5; ++m) acc += Tk[sym(r, m)] * z[m];
+        o[r] = acc;
     }
 }
 
-// One block of the backward substitution: x is x_{k+1} on entry and
-// x_k = w_k - T_k B_{k+1}^T x_{k+1} on exit; (up0, upd) are B_{k+1}.
+// Reference walks of one line (one thread per line): used by the CPU emulation of the unit
+// tests and as the specification of what the quad kernels in kernels.hip compute.
+// vec slots of a block: standard block k -> (k,0..4); mirrored block k -> (k,0), (k-1,1..4).
+template <class T> struct LineRef {
+    int nlines, lid;
+    const T *fac;
+    const double *lfac;
+    T *vec;
+    EMG_HD size_t rec(int k) const { return (size_t)k * nlines + lid; }
+    EMG_HD T &slot(int k, int r, bool mirrored) const { return vec[rec(mirrored && r > 0 ? k - 1 : k) * 5 + r]; }
+    EMG_HD void get(int k, bool mirrored, T (&v)[5]) const
+    {
+        for (int r = 0; r < 5; ++r) v[r] = slot(k, r, mirrored);
+    }
+    EMG_HD void put(int k, bool mirrored, const T (&v)[5]) const
+    {
+        for (int r = 0; r < 5; ++r) slot(k, r, mirrored) = v[r];
+    }
+    EMG_HD void T15(int k, T (&Tk)[15]) const
+    {
+        for (int j = 0; j < 15; ++j) Tk[j] = fac[rec(k) * 15 + j];
+    }
+    EMG_HD void B(int k, double (&l0)[4], double (&ld)[4]) const
+    {
+        for (int j = 0; j < 4; ++j) { l0[j] = lfac[rec(k) * 8 + j]; ld[j] = lfac[rec(k) * 8 + 4 + j]; }
+    }
+};
+// forward: both half-chains; n0 = real blocks, n0p = padded records
 template <class T>
-EMG_HD void line_backward_step(const T (&Tk)[15], const double (&up0)[4], const double (&upd)[4],
-                               const T (&wk)[5], T (&x)[5])
+EMG_HD void line_forward_ref(int n0, int n0p, int nlines, int lid, const T *fac, const double *lfac, T *vec)
 {
-    T h[5];
-    h[0] = zero<T>();
-#pragma unroll
-    for (int m = 1; m < 5; ++m) h[m] = up0[m - 1] * x[0] + upd[m - 1] * x[m];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
+    const LineRef<T> R{nlines, lid, fac, lfac, vec};
+    const int mk = line_mid(n0);
+    T w[5], q[5], z[5], v[5], Tk[15];
+    double l0[4], ld[4];
+    for (int half = 0; half < 2; ++half) {
+        const bool mir = half == 1;
+        for (int r = 0; r < 5; ++r) w[r] = zero<T>();
+        // top: k = 0 .. m-1 (w_k = T_k (r_k - B_k w_{k-1})); bottom: k = n0p-1 .. m+2 with U_k
+        for (int i = 0; i < (mir ? n0p - 2 - mk : mk); ++i) {
+            const int k = mir ? n0p - 1 - i : i;
+            R.T15(k, Tk); R.B(k, l0, ld); R.get(k, mir, v);
+            couple_lower<T>(l0, ld, w, q);
+            for (int r = 0; r < 5; ++r) z[r] = v[r] - q[r];
+            sym_matvec<T>(Tk, z, w);
+            R.put(k, mir, w);
+        }
+    }
+}
+// middle: x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}]), Q = {E0(m), t(m+1), E0(m+1)}
+template <class T>
+EMG_HD void line_middle(int n0, int n0p, int nlines, int lid, const T *fac, const double *lfac, T *vec,
+                        T (&xq)[6])
+{
+    const LineRef<T> R{nlines, lid, fac, lfac, vec};
+    const int mk = line_mid(n0);
+    T z[6], q[5], y[5];
+    double l0[4], ld[4];
+    for (int r = 0; r < 5; ++r) z[r] = R.slot(mk, r, false);
+    z[5] = R.slot(mk + 1, 0, false);
+    if (mk > 0) {
+        R.B(mk, l0, ld); R.get(mk - 1, false, y);
+        couple_lower<T>(l0, ld, y, q);
+        for (int r = 0; r < 5; ++r) z[r] -= q[r];
+    }
+    if (mk + 2 < n0p) {
+        R.B(mk + 1, l0, ld); R.get(mk + 2, true, y);
+        couple_lower<T>(l0, ld, y, q);           // mirrored block m+1: q[0] -> E0(m+1), q[j] -> t(m+1)_j
+        z[5] -= q[0];
+        for (int r = 1; r < 5; ++r) z[r] -= q[r];
+    }
+    T Tq[21];
+    for (int j = 0; j < 15; ++j) Tq[j] = fac[R.rec(mk) * 15 + j];
+    for (int j = 0; j < 6; ++j) Tq[15 + j] = fac[R.rec(mk + 1) * 15 + j];
+    for (int r = 0; r < 6; ++r) {
         T acc = zero<T>();
-#pragma unroll
-        for (int m = 0; m < 5; ++m) acc += Tk[sym(r, m)] * h[m];
-        x[r] = wk[r] - acc;
+        for (int m = 0; m < 6; ++m) acc += Tq[sym(r, m)] * z[m];
+        xq[r] = acc;
     }
 }
-
-// Reference walk of one line (one thread per line): used by the CPU emulation of the
-// unit tests and as the specification of what the quad kernels in kernels.hip compute.
 template <class T>
-EMG_HD void line_forward_ref(int n0, int nlines, int lid, const T *fac, const double *lfac, T *vec)
+EMG_HD void line_backward_ref(int n0, int n0p, int nlines, int lid, const T *fac, const double *lfac, T *vec)
 {
-    T w[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) w[r] = zero<T>();
-    for (int k = 0; k < n0; ++k) {
-        const size_t rec = (size_t)k * nlines + lid;
-        T Tk[15], c[5];
-        double l0[4], ld[4];
-        for (int j = 0; j < 15; ++j) Tk[j] = fac[rec * 15 + j];
-        for (int j = 0; j < 4; ++j) { l0[j] = lfac[rec * 8 + j]; ld[j] = lfac[rec * 8 + 4 + j]; }
-        for (int r = 0; r < 5; ++r) c[r] = vec[rec * 5 + r];
-        line_forward_step<T>(Tk, l0, ld, c, w);
-        for (int r = 0; r < 5; ++r) vec[rec * 5 + r] = w[r];
+    const LineRef<T> R{nlines, lid, fac, lfac, vec};
+    const int mk = line_mid(n0);
+    T xq[6], x[5], q[5], tq[5], v[5], Tk[15];
+    double l0[4], ld[4];
+    line_middle<T>(n0, n0p, nlines, lid, fac, lfac, vec, xq);
+    for (int half = 0; half < 2; ++half) {
+        const bool mir = half == 1;
+        // the part of x_Q the half couples to: standard block m / mirrored block m+1
+        x[0] = mir ? xq[5] : xq[0];
+        for (int r = 1; r < 5; ++r) x[r] = xq[r];
+        int kprev = mir ? mk + 1 : mk;            // record whose B / U couples to the next block
+        for (int i = 0; i < (mir ? n0p - 2 - mk : mk); ++i) {
+            const int k = mir ? mk + 2 + i : mk - 1 - i;
+            R.T15(k, Tk); R.B(kprev, l0, ld); R.get(k, mir, v);
+            couple_upper<T>(l0, ld, x, q);
+            sym_matvec<T>(Tk, q, tq);
+            for (int r = 0; r < 5; ++r) x[r] = v[r] - tq[r];
+            R.put(k, mir, x);
+            kprev = k;
+        }
     }
-}
-
-template <class T>
-EMG_HD void line_backward_ref(int n0, int nlines, int lid, const T *fac, const double *lfac, T *vec)
-{
-    T x[5];
-    double up0[4], upd[4];
-    for (int r = 0; r < 5; ++r) x[r] = zero<T>();
-    for (int j = 0; j < 4; ++j) { up0[j] = 0.0; upd[j] = 0.0; }
-    for (int k = n0 - 1; k >= 0; --k) {
-        const size_t rec = (size_t)k * nlines + lid;
-        T Tk[15], wk[5];
-        for (int j = 0; j < 15; ++j) Tk[j] = fac[rec * 15 + j];
-        for (int r = 0; r < 5; ++r) wk[r] = vec[rec * 5 + r];
-        line_backward_step<T>(Tk, up0, upd, wk, x);
-        for (int r = 0; r < 5; ++r) vec[rec * 5 + r] = x[r];
-        for (int j = 0; j < 4; ++j) { up0[j] = lfac[rec * 8 + j]; upd[j] = lfac[rec * 8 + 4 + j]; }
-    }
+    for (int r = 0; r < 5; ++r) R.slot(mk, r, false) = xq[r];
+    R.slot(mk + 1, 0, false) = xq[5];
 }
 
 // Scatter block k of the solution into the field (core.py:775-783).

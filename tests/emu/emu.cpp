@@ -88,11 +88,11 @@ void line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac
     for_threads(emg::lineblk_grid(lc, true), emg::lineblk_block(), [&](int gx, int gy, int gz) {
         emg::line_rhs_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, vec);
     });
-    // the GPU runs these two with four lanes per line (kernels.hip); the arithmetic per
-    // line is that of the reference walks below
+    // the GPU runs these two with four lanes per line and one wave per half-chain
+    // (kernels.hip); the arithmetic per line is that of the reference walks below
     // (walked over the PADDED block count, like the kernels: identity blocks are no-ops)
-    for (int lid = 0; lid < lc.lines; ++lid) emg::line_forward_ref<T>(lc.n0p, lc.lines, lid, f, lf, vec);
-    for (int lid = 0; lid < lc.lines; ++lid) emg::line_backward_ref<T>(lc.n0p, lc.lines, lid, f, lf, vec);
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_forward_ref<T>(lc.n0, lc.n0p, lc.lines, lid, f, lf, vec);
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_backward_ref<T>(lc.n0, lc.n0p, lc.lines, lid, f, lf, vec);
     for_threads(emg::lineblk_grid(lc, false), emg::lineblk_block(), [&](int gx, int gy, int gz) {
         emg::line_scatter_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, (const T *)vec);
     });

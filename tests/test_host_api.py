@@ -24,9 +24,12 @@ def test_library_loads_and_exports_all_declared_symbols():
     assert lib.emg3d_device_count() >= 0
     # pure-arithmetic helpers of the ABI work without a device
     assert lib.emg3d_gs_scratch_bytes(0, 8, 8, 8, 1) == 0
-    assert lib.emg3d_gs_scratch_bytes(1, 8, 6, 4, 1) == (5 * 8 * 3 * 2 + 80) * 16
-    assert lib.emg3d_line_fac_bytes(1, 8, 6, 4, 1) == 15 * 8 * 5 * 3 * 16
-    assert lib.emg3d_line_lfac_bytes(3, 8, 6, 5) == 8 * 8 * 7 * 5 * 8     # 5 blocks padded to 8
+    # records per line of the two-sided factorisation (stencil.h: line_padded):
+    # n0 = 8 -> 4 top + 2 middle + 2 bottom padded to 4 = 10;  n0 = 5 -> 0 + 2 + 3 -> 4 = 6
+    assert lib.emg3d_gs_scratch_bytes(1, 8, 6, 4, 1) == (5 * 10 * 3 * 2 + 80) * 16
+    assert lib.emg3d_line_fac_bytes(1, 8, 6, 4, 1) == 15 * 10 * 5 * 3 * 16
+    assert lib.emg3d_line_lfac_bytes(3, 8, 6, 5) == 8 * 6 * 7 * 5 * 8
+    assert lib.emg3d_point_fac_bytes(8, 6, 4, 1) == (8 * 7 * 5 + 9 * 6 * 5 + 9 * 7 * 4) * 16
     assert lib.emg3d_residual_ws_len(64, 8, 4) == 2 * 3 * 5
 
 
