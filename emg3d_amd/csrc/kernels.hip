@@ -326,19 +326,32 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines
     else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, vec, dummy);
 }
 
-// Middle block of the two-sided solve (stencil.h: line_middle), computed by every lane of
-// both half-waves redundantly: x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}]).
+// Middle block of the two-sided solve (stencil.h: line_middle), by both half-waves:
+// x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}]). Every lane forms the 6-vector z (cheap,
+// real x complex), lane j the rows j and j2 = 4 + (j & 1) of T_Q z (rows 4 / 5 are computed
+// twice); xa = x_Q[j], xb = x_Q[j2].
 template <class T>
-__device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int line, const T *fac, const double *lfac,
-                                            const T *vec, T (&xq)[6])
+__device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int line, int j, const T *fac,
+                                            const double *lfac, const T *vec, T &xa, T &xb)
 {
     const int mk = emg::line_mid(n0);
     const size_t rm = (size_t)mk * nlines + line, rp = rm + nlines;
+    // rows of the packed symmetric T_Q (15 entries in record m, 6 in record m+1), loaded
+    // first: they do not depend on the forward pass
+    const int j2 = 4 + (j & 1);
+    T ta[6], tb[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        const int ia = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
+        const int ib = j2 >= m ? j2 * (j2 + 1) / 2 + m : m * (m + 1) / 2 + j2;
+        ta[m] = ia < 15 ? fac[rm * 15 + ia] : fac[rp * 15 + (ia - 15)];
+        tb[m] = ib < 15 ? fac[rm * 15 + ib] : fac[rp * 15 + (ib - 15)];
+    }
     T z[6];
 #pragma unroll
     for (int r = 0; r < 5; ++r) z[r] = vec[rm * 5 + r];
     z[5] = vec[rp * 5];
-    {   // top coupling B_m w_{m-1} (zero if there is no top half: B_0 = 0 is stored as zeros)
+    {   // top coupling B_m w_{m-1} (zero if there is no top half: B_0 is stored as zeros)
         const size_t rt = mk > 0 ? rm - nlines : rm;
         const double *lf = lfac + rm * 8;
         T q0 = emg::zero<T>();
@@ -351,7 +364,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
         z[0] -= q0;
     }
     {   // bottom coupling U_{m+1} w_{m+2}; w_{m+2} = slots (m+2, 0), (m+1, 1..4); U of an
-        // identity padding block is zero, so no guard is needed (m+2 <= n0p-1 always)
+        // identity padding block is zero, so no guard is needed
         const double *lf = lfac + rp * 8;
         T q0 = emg::zero<T>();
 #pragma unroll
@@ -362,18 +375,8 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
         }
         z[5] -= q0;
     }
-    T tq[21];
-#pragma unroll
-    for (int jj = 0; jj < 15; ++jj) tq[jj] = fac[rm * 15 + jj];
-#pragma unroll
-    for (int jj = 0; jj < 6; ++jj) tq[15 + jj] = fac[rp * 15 + jj];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        T acc = emg::zero<T>();
-#pragma unroll
-        for (int m = 0; m < 6; ++m) acc += tq[emg::sym(r, m)] * z[m];
-        xq[r] = acc;
-    }
+    xa = (ta[0] * z[0] + ta[1] * z[1]) + (ta[2] * z[2] + ta[3] * z[3]) + (ta[4] * z[4] + ta[5] * z[5]);
+    xb = (tb[0] * z[0] + tb[1] * z[1]) + (tb[2] * z[2] + tb[3] * z[3]) + (tb[4] * z[4] + tb[5] * z[5]);
 }
 
 // Backward substitution of one half, outwards from the middle block, fused with the scatter
@@ -418,28 +421,26 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     QuadRow<T> qm;
     qm.load_b(lfac, (size_t)(HALF ? mk + 1 : mk) * nlines + line, j);
 
-    T xq[6];
-    quad_middle<T>(n0, n0p, nlines, line, fac, lfac, vec, xq);
-    // per-lane selection by 0/1 weights: a select chain on the lane index would be compiled
-    // into a scratch-memory array lookup
-    const double xsel[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
+    // x_Q: this lane's entry j (xa) and entry 4 (even lanes) / 5 (odd lanes) (xb)
+    T xa, xb;
+    quad_middle<T>(n0, n0p, nlines, line, j, fac, lfac, vec, xa, xb);
+    const T xq0 = quad_bcast<0>(xa), xq4 = quad_bcast<0>(xb), xq5 = quad_bcast<1>(xb);
     if (HALF == 0) {
-        // lanes 0..3 write entries 0..3 of x_Q (E0(m), t(m+1)_1..3), lane 0 also entry 4,
-        // lane 1 entry 5 (E0(m+1)); the transverse edges of node m+1 are the entries of
-        // "standard block m"
+        // lane j writes entry j of x_Q (E0(m), t(m+1)_1..3), lane 0 also entry 4, lane 1
+        // entry 5 (E0(m+1)); t(m+1) are the transverse entries of "standard block m"
         const int dkm = j == 0 ? 0 : 1;
         T *const pm = A.E(cj) + A.idx(cj, mk + dkm, i1 - d1, i2 - d2);
-        *(active ? pm : dj) = xsel[0] * xq[0] + xsel[1] * xq[1] + (xsel[2] * xq[2] + xsel[3] * xq[3]);
+        *(active ? pm : dj) = xa;
         T *const p4 = A.E(2) + A.idx(2, mk + 1, i1, i2);
         T *const p5 = A.E(0) + A.idx(0, mk + 1, i1, i2);
-        *((active && j == 0) ? p4 : ((active && j == 1) ? p5 : d4)) = xsel[1] * xq[5] + (1.0 - xsel[1]) * xq[4];
+        *((active && j == 0) ? p4 : ((active && j == 1) ? p5 : d4)) = xb;
     }
     // x of the block next to the walk: standard block m / mirrored block m+1 of x_Q
-    T x[5];
-    x[0] = HALF ? xq[5] : xq[0];
-#pragma unroll
-    for (int r = 1; r < 5; ++r) x[r] = xq[r];
-    T xmine = xsel[0] * x[0] + xsel[1] * x[1] + (xsel[2] * x[2] + xsel[3] * x[3]);   // this lane's own entry of x
+    T x[5];                  // only x[0], x[4] and the own entry are needed by the coupling
+    x[0] = HALF ? xq5 : xq0;
+    x[4] = xq4;
+    const double own0 = j == 0 ? 1.0 : 0.0;
+    T xmine = HALF ? own0 * xq5 + (1.0 - own0) * xa : xa;   // this lane's own entry of x
     double upA = qm.bA, upD = qm.bD, up03 = qm.l0[3], up44 = qm.d4;        // entries of the coupling block
     const double nz = j != 0 ? 1.0 : 0.0;
     for (int i0 = 0; i0 < W.steps; i0 += QD) {
@@ -453,7 +454,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
             const T h0 = quad_bcast<0>(hj), h1 = quad_bcast<1>(hj), h2 = quad_bcast<2>(hj), h3 = quad_bcast<3>(hj);
             const T xn = q.v - (q.t[0] * h0 + q.t[1] * h1 + (q.t[2] * h2 + q.t[3] * h3) + q.t[4] * h4);
             const T x4 = q.v4 - (quad_sum(q.t[4] * hj) + q.t44 * h4);
-            x[0] = quad_bcast<0>(xn); x[1] = quad_bcast<1>(xn); x[2] = quad_bcast<2>(xn); x[3] = quad_bcast<3>(xn);
+            x[0] = quad_bcast<0>(xn);
             x[4] = x4;
             xmine = xn;
             upA = q.bA; upD = q.bD; up03 = q.l0[3]; up44 = q.d4;

@@ -74,11 +74,13 @@ def main():
     ap.add_argument('--case', default='triaxial')
     ap.add_argument('--slabs', default='0,2,4,8,16,32')
     ap.add_argument('--nu', type=int, default=2)
+    ap.add_argument('--shape', default='', help='nx,ny,nz instead of n^3')
     args = ap.parse_args()
     lib = _lib.lib()
-    lv, grid = make_level(args.n, args.case)
+    shape = tuple(int(x) for x in args.shape.split(',')) if args.shape else None
+    lv, grid = make_level(args.n, args.case, shape=shape)
     nc = grid.n_cells
-    print(f"# {args.n}^3 {args.case}, nu={args.nu}")
+    print(f"# {shape or args.n} {args.case}, nu={args.nu}")
     if args.what in ('point', 'all'):
         lib.emg3d_set_option(b'point_tile_min', 1)
         med, mn = timeit(lambda: lv.smooth(0, args.nu))
