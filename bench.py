@@ -16,6 +16,8 @@ GPU: weak scaling). Rank 0 prints ONE JSON line, which als
 * "roofline": algorithmic HBM bytes of the dominant kernel (a level-0 smoother; 184 B per
   cell-sweep for VTI) over its measured duration (HIP events on the
   launch stream, inside the timed region), against the 8 TB/s HBM peak;
+* "smoothers_256" (1 GPU): the four smoothers on a 256^3 tri-axial level -- the kernel figure
+  BASELINE.json's target (>= 40 % of the HBM roofline on gauss_seidel at 256^3) is stated for;
 * "cpu_baseline": the oracle (C restatement of the reference's sequential numba kernels +
   its multigrid driver, oracle/) timed on this host on one cycle of the same workload.
 
@@ -151,6 +153,72 @@ class Bench:
         return stats
 
 
+def smoothers_256(device, n=256, nu=2, reps=5):
+    """BASELINE.json's north-star kernel figure: each smoother on a 256^3 tri-axial level
+    (random model and fields, complex fp64), nu sweeps per call, HIP events on the launch
+    stream; algorithmic bytes = 200 B per cell and sweep."""
+    import torch
+    from emg3d_amd._device import DeviceLevel
+    import emg3d_amd as emg3d
+    shape = (n, n, n)
+    rng = np.random.default_rng(1)
+    h = [widths(n // 2, n // 4, 25., 1.03)] * 3
+    grid = emg3d.TensorMesh(h, (0, 0, 0))
+    vol = grid.cell_volumes.reshape(shape, order='F')
+    smu0 = 2j * np.pi * 1.25663706127e-06
+
+    class VM:
+        pass
+    vm = VM()
+    vm.grid, vm.case = grid, 'triaxial'
+    sig = 10 ** rng.uniform(-1.5, 0.5, shape)
+    vm.eta_x = np.asfortranarray(-smu0 * vol * sig)
+    vm.eta_y = np.asfortranarray(vm.eta_x / 1.5)
+    vm.eta_z = np.asfortranarray(vm.eta_x / 2.5)
+    vm.zeta = np.asfortranarray(vol)
+    lv = DeviceLevel.from_host(vm, device)
+    gen = torch.Generator(device=device).manual_seed(1)
+    for t in (lv.e, lv.s):
+        t.copy_(torch.complex(torch.randn(grid.n_edges, generator=gen, device=device, dtype=torch.float64),
+                              torch.randn(grid.n_edges, generator=gen, device=device, dtype=torch.float64)))
+    lv.pec_zero()
+    out = {}
+    names = {0: 'gauss_seidel (k_gs_point_tile)', 1: 'gauss_seidel_x', 2: 'gauss_seidel_y',
+             3: 'gauss_seidel_z'}
+    for lr in (0, 1, 2, 3):
+        lv.smooth(lr, nu)                       # builds factors, warms up
+        lv.smooth(lr, nu)
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            lv.smooth(lr, nu)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        ms = float(np.median(ts)) / nu
+        gbs = BYTES_PER_CELL_SWEEP['triaxial'] * grid.n_cells / (ms * 1e-3) / 1e9
+        out[names[lr]] = {'ms_per_sweep': ms, 'achieved': gbs, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                          'gcell_sweeps_per_s': grid.n_cells / (ms * 1e-3) / 1e9}
+        lv._factors.pop(lr, None)               # 15 GB of line factors per direction: free them
+        torch.cuda.empty_cache()
+    return {'level': f'{n}^3 tri-axial, complex fp64, {nu} sweeps per call',
+            'bytes_per_cell_sweep': BYTES_PER_CELL_SWEEP['triaxial'], 'peak': HBM_PEAK_GBS, 'smoothers': out}
+
+
+def pmc_traffic(workload_name, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
+    of this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+    None if there is no entry for this workload and kernel."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f)[workload_name][kernel]['bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def run_gpu(args, rank, world):
     import torch
     import torch.distributed as dist
@@ -232,7 +300,7 @@ def run_gpu(args, rank, world):
             'roofline': {
                 'bound': 'hbm', 'kernel': names[dom],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload, names[dom]),
                 'bytes_per_launch': bytes_per_launch, 'ms_per_launch': ms_launch,
                 'launches_timed': stats[dom]['launches'],
                 'gcell_sweeps_per_s': n0 / 4.0 / (ms_launch * 1e-3) / 1e9,
@@ -241,6 +309,10 @@ def run_gpu(args, rank, world):
                     'GB/s': bytes_per_launch / (v['ms'] / v['launches'] * 1e-3) / 1e9}
                     for k, v in stats.items()}},
         }
+    if rank == 0 and world == 1 and not args.no_256:
+        del b
+        torch.cuda.empty_cache()
+        out['smoothers_256'] = smoothers_256(device)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -277,6 +349,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='marine128')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-256', action='store_true',
+                    help="skip the separate 256^3 smoother measurement ('smoothers_256')")
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))

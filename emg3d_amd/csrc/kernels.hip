@@ -69,7 +69,7 @@ int g_point_tile_min = 1 << 20;
 // Line smoothers: 0 = three launches per colour (rhs, forward, backward), 1 = one fused
 // launch per colour, 2 = fused when the colour class has at most g_line_fuse_max lines.
 int g_line_fuse = 2;
-int g_line_fuse_max = 1024;
+int g_line_fuse_max = 4096;
 
 // ----------------------------------------------------------------------------- kernels --
 

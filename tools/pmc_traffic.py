@@ -1,0 +1,71 @@
+"""Turn the two PMC passes of a bench run into profiles/r01_pmc_traffic.json.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/f -o run -- python bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/w -o run -- python bench.py ...
+    python tools/pmc_traffic.py WORKLOAD out/f/run_counter_collection.csv out/w/run_counter_collection.csv
+
+Per kernel the launches with the LARGEST grid (= the finest level) are averaged. Units and
+corrections as MI355X_MICROARCH.md (HBM section) prescribes: the counters are KiB; on gfx950
+FETCH_SIZE reports half of the bytes of wide streaming reads and is doubled; WRITE_SIZE is
+taken as is (calibrated exact against a torch fill in profiles/r01_v4_pmc_hbm_traffic_256.txt).
+The bench names a level-0 smoother call after its direction; its bytes are the sum of the
+kernels one colour pass launches (fused: k_line_colour; else rhs + forward + backward).
+"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    rows = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r['Counter_Name'] != counter:
+                continue
+            grid = int(r['Grid_Size']) if 'Grid_Size' in r else int(r['Grid_Size_X']) * int(r.get('Grid_Size_Y', 1))
+            rows[r['Kernel_Name']].append((grid, float(r['Counter_Value'])))
+    out = {}
+    for k, v in rows.items():
+        g = max(x[0] for x in v)
+        vals = [x[1] for x in v if x[0] == g]
+        out[k] = (g, sum(vals) / len(vals), len(vals))
+    return out
+
+
+def main():
+    wl, fpath, wpath = sys.argv[1:4]
+    fetch, write = per_kernel(fpath, 'FETCH_SIZE'), per_kernel(wpath, 'WRITE_SIZE')
+    res = {}
+    for d, name in ((0, 'k_gs_line<x>'), (1, 'k_gs_line<y>'), (2, 'k_gs_line<z>')):
+        parts = {}
+        for k in fetch:
+            for tag in (f'k_line_colour<emg::cplx, {d}>', f'k_line_backward<emg::cplx, {d}>',
+                        f'k_line_rhs<emg::cplx, {d}>', 'k_line_rhs_xt<emg::cplx>' if d == 0 else None):
+                if tag and tag in k:
+                    parts[tag] = {'read': 2 * fetch[k][1] * 1024, 'write': write[k][1] * 1024,
+                                  'grid': fetch[k][0], 'launches': fetch[k][2]}
+        if not parts:
+            continue
+        gmax = max(p['grid'] for p in parts.values())
+        # fused and unfused kernels never serve the same level: keep the finest level's set
+        fused = {k: p for k, p in parts.items() if 'colour' in k}
+        use = fused if fused and max(p['grid'] for p in fused.values()) * 2 >= gmax else \
+            {k: p for k, p in parts.items() if 'colour' not in k}
+        total = sum(p['read'] + p['write'] for p in use.values())
+        res[name] = {'bytes_per_launch': total, 'kernels': use}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            allres = json.load(f)
+    except OSError:
+        allres = {}
+    allres[wl] = res
+    with open(path, 'w') as f:
+        json.dump(allres, f, indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main()
