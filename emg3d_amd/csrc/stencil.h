@@ -610,10 +610,8 @@ EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
     rhs[0] += (mzyLxm * h10) * A.e(0, i0m, i1m, i2);
     rhs[0] += (myzRxm * h21) * A.e(0, i0m, i1, i2p);
     rhs[0] += (myzLxm * h20) * A.e(0, i0m, i1, i2m);
-    if (k == n0 - 1) {   // last block: only the along-line edge
-        rhs[1] = rhs[2] = rhs[3] = rhs[4] = zero<T>();
-        return;
-    }
+    // (the last block has only the along-line edge: its entries 1..4 are zeroed at the end --
+    // no early return, so that callers can batch several blocks with all loads in flight)
     const double z100 = A.zeta(i0, i1m, i2m), z110 = A.zeta(i0, i1, i2m);
     const double z101 = A.zeta(i0, i1m, i2), z111 = A.zeta(i0, i1, i2);
     const double mzxLym = k00 * (z001 + z000), mzxRym = k01 * (z101 + z100);
@@ -649,7 +647,9 @@ EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
                      mxyLzp * A.e(1, i0, i1m, i2p) - mxyRzp * A.e(1, i0, i1, i2p));
     rhs[4] += (mxyRzp * h11) * A.e(2, i0, i1p, i2);
     rhs[4] += (mxyLzp * h10) * A.e(2, i0, i1m, i2);
+    if (k == n0 - 1) rhs[1] = rhs[2] = rhs[3] = rhs[4] = zero<T>();
 }
+
 
 // In-register LDL^T of a symmetric 5x5 block given by its lower triangle S (S[r][m], m<=r):
 // C[tri(r,m)] (m<r) and dinv[r]. nrows < 5 factorises the leading nrows x nrows part.
