@@ -248,9 +248,9 @@ def run_gpu(args, rank, world):
 
     # Untimed preparation, independent of --warmup: every (sc_dir, lr_dir) variant of the
     # cycle builds its coarse levels and line factors on first use and captures its
-    # coarse-grid HIP graph on second use. Two passes over the variants put the solver in
-    # its steady state, like a solve that is a few cycles old.
-    b.cycles(2 * b.var.maxcycle)
+    # coarse-grid HIP graph on its third use (solver._GRAPH_AFTER). Three passes over the
+    # variants put the solver in its steady state, like a solve that is a few cycles old.
+    b.cycles((b.solver._GRAPH_AFTER + 1) * b.var.maxcycle)
     if args.warmup > 0:
         b.cycles(args.warmup)
     w0 = b.var.smoother_cell_sweeps

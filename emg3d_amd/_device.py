@@ -56,8 +56,28 @@ class Workspace:
         self.device = device
         self.gs_scratch = None
         self.gs_bytes = 0
+        self._pin, self._pin_used, self._pins = None, 0, []
         self.ws = None
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def upload(self, a):
+        """Small host array -> device tensor through a pinned staging pool, asynchronously on
+        the current stream. A plain ``.to(device)`` from pageable memory goes through the
+        runtime's synchronous staging path: measured ~2.5 ms of idle GPU per call (and one
+        70 ms outlier) -- with three uploads per level that was a third of a 128^3 solve."""
+        a = np.ascontiguousarray(a)
+        nbytes = a.nbytes
+        if self._pin is None or self._pin_used + nbytes > self._pin.numel():
+            # a fresh block; the old one stays referenced by the tensors staged from it
+            self._pin = torch.empty(max(1 << 20, 2 * nbytes), dtype=torch.uint8).pin_memory()
+            self._pin_used = 0
+            self._pins.append(self._pin)
+        view = self._pin[self._pin_used:self._pin_used + nbytes]
+        self._pin_used += (nbytes + 63) // 64 * 64
+        view.numpy()[:] = a.view(np.uint8).reshape(-1)
+        dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        dev.copy_(view, non_blocking=True)
+        return dev.view(torch.from_numpy(a[:0]).dtype)
 
     def need_gs(self, nbytes):
         """Line-smoother scratch. Sized once for the largest request of the hierarchy
@@ -84,13 +104,16 @@ class DeviceLevel:
         self.dtype = dtype                                  # torch.complex128 / float64
         self.is_complex = int(dtype == torch.complex128)
         self.eta_x, self.eta_y, self.eta_z, self.zeta = eta_x, eta_y, eta_z, zeta
-        self.ih = [torch.from_numpy(np.ascontiguousarray(1.0 / h)).to(device) for h in grid.h]
+        ihall = work.upload(np.concatenate([1.0 / np.asarray(h, dtype=np.float64) for h in grid.h]))
+        nh = np.cumsum([0] + [len(h) for h in grid.h])
+        self.ih = [ihall[nh[d]:nh[d + 1]] for d in range(3)]      # one upload, three views
         n = grid.n_edges
         self.e = torch.zeros(n, dtype=dtype, device=device)
         self.s = torch.zeros(n, dtype=dtype, device=device)
         self._r = None
         self.children = {}
         self._factors = {}
+        self._parts = {}
         self.n_cells = grid.n_cells
         self._o1, self._o2 = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y
         nx, ny, nz = grid.shape_cells
@@ -108,6 +131,15 @@ class DeviceLevel:
     def from_host(cls, vmodel, device, work=None):
         """Upload a host ``VolumeModel`` (finest level)."""
         work = work or Workspace(device)
+        if hasattr(vmodel, 'device_arrays'):
+            # emg3d_amd.models.VolumeModel: form eta / zeta in HBM from the conductivities
+            ex, ey, ez, zeta = vmodel.device_arrays(device)
+            top = cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case, ex, ey, ez,
+                      zeta, ex.dtype, work, device)
+            nx, ny, nz = top.grid.shape_cells
+            work.need_gs(max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
+                             for lr in (1, 2, 3)))
+            return top
         cplx = np.iscomplexobj(vmodel.eta_x)
         dtype = torch.complex128 if cplx else torch.float64
         ndt = np.complex128 if cplx else np.float64
@@ -133,8 +165,15 @@ class DeviceLevel:
         return self._r
 
     def parts(self, t):
-        """(px, py, pz) pointers into a 1-D buffer [fx|fy|fz]."""
-        return _ptr(t), _ptr(t, self._o1), _ptr(t, self._o2)
+        """(px, py, pz) pointers into a 1-D buffer [fx|fy|fz] (cached per tensor: the level's
+        own buffers never move)."""
+        key = id(t)
+        hit = self._parts.get(key)
+        if hit is None or hit[0] is not t:
+            hit = (t, (_ptr(t), _ptr(t, self._o1), _ptr(t, self._o2)))
+            if t is self.e or t is self.s or t is self._r:
+                self._parts[key] = hit
+        return hit[1]
 
     # ------------------------------------------------------------------- kernels ------
     def line_factors(self, lr):
@@ -243,28 +282,36 @@ class DeviceLevel:
         clevel = DeviceLevel(cgrid, self.case, ceta_x, ceta_y, ceta_z, czeta, self.dtype,
                              self.work, self.device)
 
-        # restriction weights (only for coarsened directions; others are never read)
-        weights = []
+        # restriction weights (only for coarsened directions; others are never read) and
+        # prolongation tables: all 1-D arrays of the link go up in ONE float64 and ONE int32
+        # transfer (a dozen tiny uploads per level were a third of the level-build time)
+        fparts, slots = [], []
         for d, coarsened in enumerate((cx, cy, cz)):
             if coarsened:
                 nodes = (g.nodes_x, g.nodes_y, g.nodes_z)[d]
                 cc = (g.cell_centers_x, g.cell_centers_y, g.cell_centers_z)[d]
                 cnodes = (cgrid.nodes_x, cgrid.nodes_y, cgrid.nodes_z)[d]
                 ccc = (cgrid.cell_centers_x, cgrid.cell_centers_y, cgrid.cell_centers_z)[d]
-                w3 = _core.restrict_weights(nodes, cc, g.h[d], cnodes, ccc, cgrid.h[d])
-                weights.append([torch.from_numpy(np.ascontiguousarray(w)).to(self.device)
-                                for w in w3])
+                for w in _core.restrict_weights(nodes, cc, g.h[d], cnodes, ccc, cgrid.h[d]):
+                    slots.append(len(fparts))
+                    fparts.append(np.ascontiguousarray(w, dtype=np.float64))
             else:
-                weights.append([None, None, None])
-        wptr = [(_ptr(w) if w is not None else None) for w3 in weights for w in w3]
-
-        # prolongation tables
+                slots += [None, None, None]
         tabs = [interp_table(cn, n) for cn, n in ((cgrid.nodes_x, g.nodes_x),
                                                   (cgrid.nodes_y, g.nodes_y),
                                                   (cgrid.nodes_z, g.nodes_z))]
-        il = [torch.from_numpy(t[0]).to(self.device) for t in tabs]
-        pw = [torch.from_numpy(t[1]).to(self.device) for t in tabs]
-        link = {'level': clevel, 'weights': weights, 'wptr': wptr, 'il': il, 'pw': pw}
+        pw_slots = []
+        for t in tabs:
+            pw_slots.append(len(fparts))
+            fparts.append(t[1])
+        foff = np.cumsum([0] + [a.size for a in fparts])
+        fbuf = self.work.upload(np.concatenate(fparts))
+        ioff = np.cumsum([0] + [t[0].size for t in tabs])
+        ibuf = self.work.upload(np.concatenate([t[0] for t in tabs]))
+        wptr = [(_ptr(fbuf, int(foff[i])) if i is not None else None) for i in slots]
+        pwptr = [_ptr(fbuf, int(foff[i])) for i in pw_slots]
+        ilptr = [_ptr(ibuf, int(ioff[d])) for d in range(3)]
+        link = {'level': clevel, 'buffers': (fbuf, ibuf), 'wptr': wptr, 'ilptr': ilptr, 'pwptr': pwptr}
         self.children[sc_dir] = link
         return link
 
@@ -285,6 +332,6 @@ class DeviceLevel:
         c = link['level']
         nx, ny, nz = self.grid.shape_cells
         _lib.check(_lib.lib().emg3d_dev_prolong(
-            *self.parts(self.e), *c.parts(c.e), *[_ptr(t) for t in link['il']],
-            *[_ptr(t) for t in link['pw']], nx, ny, nz, sc_dir, self.is_complex, _stream()),
+            *self.parts(self.e), *c.parts(c.e), *link['ilptr'], *link['pwptr'], nx, ny, nz, sc_dir,
+            self.is_complex, _stream()),
             'emg3d_dev_prolong')

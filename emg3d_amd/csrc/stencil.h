@@ -790,28 +790,50 @@ template <class T> EMG_HD void invert5(const T (&C)[10], const T (&dinv)[5], T (
 // pivoting, packed symmetric result Tq[sym(r,m)]
 template <class T> EMG_HD void invert6(const T (&S)[6][6], T (&Tq)[21])
 {
+    // fully unrolled: every array index is a compile-time constant, so that the arrays live
+    // in registers (a kernel that needs scratch memory stalls the whole queue while the
+    // runtime resizes it -- measured 74 ms)
     T Lm[6][6], dinv[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         T u[6];
-        for (int j = 0; j < i; ++j) {
-            T t = S[i][j];
-            for (int kk = 0; kk < j; ++kk) t -= u[kk] * Lm[j][kk];
-            u[j] = t;
-            Lm[i][j] = t * dinv[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (j < i) {
+                T t = S[i][j];
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk)
+                    if (kk < j) t -= u[kk] * Lm[j][kk];
+                u[j] = t;
+                Lm[i][j] = t * dinv[j];
+            }
         }
         T d = S[i][i];
-        for (int kk = 0; kk < i; ++kk) d -= u[kk] * Lm[i][kk];
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk)
+            if (kk < i) d -= u[kk] * Lm[i][kk];
         dinv[i] = recip(d);
     }
+#pragma unroll
     for (int m = 0; m < 6; ++m) {
         T b[6];
+#pragma unroll
         for (int r = 0; r < 6; ++r) b[r] = (r == m) ? T(1.0) : zero<T>();
+#pragma unroll
         for (int i = 1; i < 6; ++i)
-            for (int kk = 0; kk < i; ++kk) b[i] -= Lm[i][kk] * b[kk];
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk)
+                if (kk < i) b[i] -= Lm[i][kk] * b[kk];
+#pragma unroll
         for (int i = 0; i < 6; ++i) b[i] *= dinv[i];
+#pragma unroll
         for (int j = 4; j >= 0; --j)
-            for (int kk = j + 1; kk < 6; ++kk) b[j] -= Lm[kk][j] * b[kk];
-        for (int r = m; r < 6; ++r) Tq[sym(r, m)] = b[r];
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk)
+                if (kk > j) b[j] -= Lm[kk][j] * b[kk];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            if (r >= m) Tq[sym(r, m)] = b[r];
     }
 }
 

@@ -83,41 +83,99 @@ class Model:
 
 
 class VolumeModel:
-    """Volume-integrated eta_{x,y,z} and zeta for one frequency (taken from `sfield`)."""
+    """Volume-integrated eta_{x,y,z} and zeta for one frequency (taken from `sfield`);
+    semantics of the reference's class (emg3d/models.py:627-717).
+
+    The host arrays are formed on first access only: the solver builds the same quantities
+    directly in HBM (``device_arrays``), which for a 128^3 model replaces ~150 ms of NumPy
+    work and a 100 MB upload by a 17 MB upload per conductivity array and a few
+    element-wise device kernels.
+    """
 
     def __init__(self, model, sfield):
         self.case = model.case
         self.grid = meshes.BaseMesh(model.grid.h, model.grid.origin)
-        vol = self.grid.cell_volumes.reshape(model.shape, order='F')
         if sfield.sval is None:
             raise ValueError("Source field is missing frequency information.")
+        self._model = model
+        self._sval, self._smu0 = sfield.sval, sfield.smu0
+        self._host = None
 
-        etas = {}
-        for name in ('property_x', 'property_y', 'property_z'):
-            cond = model.conductivity(name)
+    # ---- the formulas (emg3d/models.py:654-691): eta = -s mu0 V (sigma [+ s eps0 eps_r]),
+    #      zeta = V / mu_r -- evaluated with NumPy (host) or torch (device), same order
+    def _conductivities(self):
+        return [self._model.conductivity(n) for n in ('property_x', 'property_y', 'property_z')]
+
+    def _build_host(self):
+        if self._host is not None:
+            return self._host
+        model = self._model
+        vol = self.grid.cell_volumes.reshape(model.shape, order='F')
+        etas = []
+        for cond in self._conductivities():
             if cond is None:
-                etas[name] = None
+                etas.append(None)
             elif model.epsilon_r is None:                       # diffusive approximation
-                etas[name] = np.asfortranarray(-sfield.smu0 * vol * cond)
+                etas.append(np.asfortranarray(-self._smu0 * vol * cond))
             else:
-                smu = sfield.sval * EPSILON_0 * model.epsilon_r
-                etas[name] = np.asfortranarray(-sfield.smu0 * vol * (cond + smu))
-        self._eta_x, self._eta_y, self._eta_z = (etas['property_x'], etas['property_y'],
-                                                 etas['property_z'])
-        self._zeta = np.asfortranarray(vol.copy() if model.mu_r is None else vol / model.mu_r)
+                smu = self._sval * EPSILON_0 * model.epsilon_r
+                etas.append(np.asfortranarray(-self._smu0 * vol * (cond + smu)))
+        zeta = np.asfortranarray(vol.copy() if model.mu_r is None else vol / model.mu_r)
+        self._host = (etas[0], etas[1], etas[2], zeta)
+        return self._host
+
+    def device_arrays(self, device):
+        """(eta_x, eta_y, eta_z, zeta) as flat F-ordered torch tensors on `device`, with the
+        reference's aliasing (eta_y / eta_z are eta_x's tensor unless the model has them)."""
+        import torch
+        model = self._model
+        cplx = np.iscomplexobj(self._smu0)
+        dtype = torch.complex128 if cplx else torch.float64
+
+        def up(a):
+            a = np.broadcast_to(np.asarray(a, dtype=np.float64), model.shape)
+            a = a.ravel('F')
+            if not a.flags.writeable or not a.flags.c_contiguous:
+                a = np.array(a)                         # torch wants a writable, dense buffer
+            return torch.from_numpy(a).to(device)
+        hx, hy, hz = (torch.from_numpy(np.ascontiguousarray(h, dtype=np.float64)).to(device)
+                      for h in self.grid.h)
+        # (hx[:, None] * hy) in numpy's cell_volumes order: x fastest
+        vol = ((hx[None, None, :] * hy[None, :, None]) * hz[:, None, None]).reshape(-1)
+        smu0 = complex(self._smu0) if cplx else float(self._smu0)
+        base = (-smu0) * vol.to(dtype)
+        eps = None
+        if model.epsilon_r is not None:
+            sval = complex(self._sval) if cplx else float(self._sval)
+            eps = (sval * EPSILON_0) * up(model.epsilon_r).to(dtype)
+        etas = []
+        for cond in self._conductivities():
+            if cond is None:
+                etas.append(None)
+            elif eps is None:
+                etas.append(base * up(cond))
+            else:
+                etas.append(base * (up(cond) + eps))
+        zeta = vol.clone() if model.mu_r is None else vol / up(model.mu_r)
+        ex = etas[0]
+        ey = etas[1] if self.case in ('HTI', 'triaxial') else ex
+        ez = etas[2] if self.case in ('VTI', 'triaxial') else ex
+        return ex, ey, ez, zeta
 
     @property
     def eta_x(self):
-        return self._eta_x
+        return self._build_host()[0]
 
     @property
     def eta_y(self):
-        return self._eta_y if self.case in ('HTI', 'triaxial') else self._eta_x
+        h = self._build_host()
+        return h[1] if self.case in ('HTI', 'triaxial') else h[0]
 
     @property
     def eta_z(self):
-        return self._eta_z if self.case in ('VTI', 'triaxial') else self._eta_x
+        h = self._build_host()
+        return h[2] if self.case in ('VTI', 'triaxial') else h[0]
 
     @property
     def zeta(self):
-        return self._zeta
+        return self._build_host()[3]

@@ -89,7 +89,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     var.cprint(f"\n:: emg3d START :: {var.time.now} :: emg3d_amd (MI355X)\n", 2)
     var.cprint(var, 2)
 
-    var.l2_refe = float(np.linalg.norm(sfield.field))
+    var.l2_refe = _host_norm(sfield.field)
     var.error_at_cycle[0] = var.l2_refe
 
     if sfield.frequency is None:
@@ -195,6 +195,20 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
         return info_dict
 
 
+def _host_norm(x):
+    """2-norm of a host array (scipy.linalg.norm in the reference, emg3d/solver.py:312) with
+    the BLAS pool capped: OpenBLAS / OpenMP start one spinning thread per visible core (256
+    on an MI355X host) for one nrm2 call, and under a container CPU quota the process is
+    then throttled for most of a scheduler period -- measured as a ~80 ms stall in a 200 ms
+    solve."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                  # pragma: no cover
+        return float(np.linalg.norm(x))
+    with threadpool_limits(limits=4):
+        return float(np.linalg.norm(x))
+
+
 def solve_source(model, source, frequency, **kwargs):
     """``get_source_field`` + ``solve`` (emg3d/solver.py:452-467)."""
     sfield = fields.get_source_field(model.grid, source, frequency)
@@ -257,11 +271,16 @@ def _smooth(lv, nu, lr_dir, var):
 # per variant into a HIP graph and replayed (MI355X_MICROARCH.md: a dependent kernel
 # boundary costs ~1.5 us inside a graph against ~5-10 us of host time per eager launch).
 _USE_GRAPHS = os.environ.get('EMG3D_AMD_GRAPHS', '1') != '0'
+_GRAPH_AFTER = int(os.environ.get('EMG3D_AMD_GRAPH_AFTER', '2'))   # eager occurrences before capture
 
 
 def _coarse_correction_graphed(clv, var, new_cycmax):
-    """_multigrid(clv, var, 1, new_cycmax) through a HIP graph, captured at its second
-    occurrence (the first, eager one builds all levels, factors and scratch it touches)."""
+    """_multigrid(clv, var, 1, new_cycmax) through a HIP graph, captured at its third
+    occurrence: the first, eager one builds all levels, factors and scratch it touches;
+    capturing costs about as much host time as an eager pass and pays off only for variants
+    that keep recurring (long solves, multigrid as a Krylov preconditioner, small grids whose
+    kernels are shorter than a host launch) -- a typical 6-cycle solve with three variants
+    never captures."""
     cache = clv.__dict__.setdefault('_graphs', {})
     key = (int(var.sc_dir), int(var.lr_dir), new_cycmax, var.cycle, var.nu_pre, var.nu_post,
            var.nu_coarse, tuple(int(c) for c in var.clevel))
@@ -269,7 +288,11 @@ def _coarse_correction_graphed(clv, var, new_cycmax):
     if entry is None:                       # first time: eager, remember the work it does
         w0 = var.smoother_cell_sweeps
         _multigrid(clv, var, 1, new_cycmax)
-        cache[key] = {'work': var.smoother_cell_sweeps - w0, 'graph': None}
+        cache[key] = {'work': var.smoother_cell_sweeps - w0, 'graph': None, 'seen': 1}
+        return
+    if entry['graph'] is None and entry['seen'] < _GRAPH_AFTER:
+        entry['seen'] += 1
+        _multigrid(clv, var, 1, new_cycmax)
         return
     if entry['graph'] is None:
         w0 = var.smoother_cell_sweeps
