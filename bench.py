@@ -96,6 +96,31 @@ def workload(name, source_index=0):
         return dict(h=[h, h, h], origin=(-25. * n,) * 3, res=res, source=(0., 0., 0., 0., 0.),
                     frequency=1.0, opts=opts, case='isotropic',
                     label=f"{n}^3 uniform fullspace, plain F-cycle (point smoother)")
+    if name in ('salt384', 'salt96'):
+        # config 5: 384 x 256 x 256 (or a quarter-size copy), isotropic: sea water above
+        # z = -1000 m, sediments 1 -> 3 Ohm m linear with depth, an analytic "salt" body =
+        # union of three ellipsoids at 100 Ohm m (deterministic stand-in for the SEG/EAGE salt
+        # model, which is not part of the reference repository); 4 frequencies x 2 sources =
+        # 8 independent (source, frequency) pairs, pair index = source_index
+        q = 1 if name == 'salt384' else 4
+        hx = widths(256 // q, 64 // q, 50. * q, 1.04 ** q)
+        hy = widths(128 // q, 64 // q, 50. * q, 1.04 ** q)
+        origin = (-hx.sum() / 2, -hy.sum() / 2, -hy[:64 // q].sum() - 5400.)
+        xc, yc, zc = (o + np.cumsum(h) - h / 2 for o, h in zip(origin, (hx, hy, hy)))
+        X, Y, Z = np.meshgrid(xc, yc, zc, indexing='ij')
+        rho = np.where(Z > -1000., 0.3, 1.0 + 2.0 * np.clip((-1000. - Z) / 5000., 0., 1.))
+        for cx, cy, cz, ax, ay, az in ((-800., 0., -3000., 2200., 1500., 900.),
+                                       (1500., 600., -3600., 1400., 1800., 700.),
+                                       (200., -900., -2400., 900., 700., 500.)):
+            inside = ((X - cx) / ax) ** 2 + ((Y - cy) / ay) ** 2 + ((Z - cz) / az) ** 2 < 1.
+            rho = np.where(inside & (Z <= -1000.), 100., rho)
+        freq = (0.25, 0.5, 1.0, 2.0)[(source_index // 2) % 4]
+        src = (-2000. if source_index % 2 == 0 else 2000., 0., -950., 0., 0.)
+        opts = dict(cycle='F', semicoarsening=True, linerelaxation=True)
+        return dict(h=[hx, hy, hy], origin=origin, res={'property_x': rho}, source=src,
+                    frequency=freq, opts=opts, case='isotropic',
+                    label=f"{hx.size} x {hy.size} x {hy.size} salt-like isotropic model, x-dipole at "
+                    f"x = {src[0]:+.0f} m, {freq} Hz, F-cycle + semicoarsening + line relaxation")
     raise ValueError(f"unknown workload {name!r}")
 
 
