@@ -477,6 +477,7 @@ __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colou
     else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, vec, dummy);
 }
 
+constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves + helper waves for the rhs phase
 // One launch per colour for small levels: a workgroup of two waves owns 16 lines -- wave 0
 // their top halves, wave 1 their bottom halves -- and runs rhs assembly, forward and
 // backward substitution for them back to back. Lines of one colour class are independent,
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colou
 // barriers; both waves sit on one CU and share its L1). On the coarse levels the three
 // separate launches are bound by launch latency, not by work.
 template <class T, int DIR>
-__global__ __launch_bounds__(128) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+__global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                      const T *fac, const double *lfac, T *vec, T *dummy)
 {
     const emg::Axes<T, DIR> A(L);
@@ -492,13 +493,14 @@ __global__ __launch_bounds__(128) void k_line_colour(emg::Level<T> L, int colour
     const int line0 = blockIdx.x * 16;
     const int nl = min(16, nlines - line0);
     // (1) right-hand sides of the workgroup's lines; x-lines run the lanes along the line
-    for (int i = threadIdx.x; i < nl * n0p; i += 128) {
+    for (int i = threadIdx.x; i < nl * n0p; i += LC_THREADS) {
         const int ll = DIR == 0 ? i / n0p : i % nl;
         const int k = DIR == 0 ? i % n0p : i / nl;
         const int lid = line0 + ll;
         emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, lid % cntp, lid / cntp, k, vec);
     }
     __syncthreads();
+    if (threadIdx.x >= 128) return;      // helper waves of the rhs phase are done
     const int half = threadIdx.x >> 6;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, j, fac, lfac, vec, dummy);
@@ -617,7 +619,7 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
     const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
     if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
-        hipLaunchKernelGGL((k_line_colour<T, DIR>), dim3(q1.x), dim3(128), 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f,
+        hipLaunchKernelGGL((k_line_colour<T, DIR>), dim3(q1.x), dim3(LC_THREADS), 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f,
                            lf, vec, vec + dummy_off);
         return;
     }

@@ -562,3 +562,56 @@ def test_solve_with_tiled_point_smoother_vs_oracle():
     assert info['exit'] == 0 and io['exit'] == 0
     assert info['it_mg'] == io['it_mg']
     assert relerr(e.field, eo.field) < 1e-8
+
+
+def test_bench_workload_marine64_converged_vs_oracle():
+    """BASELINE.json config 2 at half size (bench.py workload 'marine64': stretched marine
+    halfspace, VTI, F-cycle + semicoarsening + line relaxation): converged field of the GPU
+    path vs the oracle in the reference's lexicographic order, both at tol 1e-10 -> 1e-8."""
+    from bench import workload
+    wl = workload('marine64')
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **wl['opts'])
+    assert info['exit'] == 0, info['exit_message']
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in wl['res'].items()}
+    vm = mg_ref.volume_model(ogrid, wl['frequency'], cond['property_x'], None, cond['property_z'])
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **wl['opts'])
+    assert io['exit'] == 0
+    assert relerr(e.field, eo.field) < 1e-8
+    assert abs(info['it_mg'] - io['it_mg']) <= 3
+
+
+@pytest.mark.parametrize('freq', [1.0, 0.01, -3.0])
+def test_line_smoothers_low_frequency_accuracy(freq):
+    """The two-sided line factorisation must keep the accuracy of the reference's one-sided
+    LDL^T when the blocks are nearly singular (low frequency: the gradient null space of the
+    curl-curl operator is only weakly regularised). Eliminating the far half in the
+    reference's block grouping loses accuracy like cond^2 (2e-8 at 0.01 Hz); the mirrored
+    grouping of stencil.h keeps cond * eps."""
+    shape = (64, 6, 10)
+    rng = np.random.default_rng(1)
+    h = [np.ones(n) * 20. for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, freq, *sig)
+    dtype = complex if freq > 0 else float
+    s = mg_ref.Field(grid, dtype=dtype)
+    e0 = mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    tol = {1.0: 2e-12, 0.01: 2e-10, -3.0: 2e-11}[freq]
+    for fn in ('gauss_seidel_x', 'gauss_seidel_y', 'gauss_seidel_z'):
+        a, b = e0.copy(), e0.copy()
+        getattr(ocore, fn)(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                           vm.zeta, *grid.h, 1, order=1)
+        getattr(core, fn)(b.fx, b.fy, b.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                          vm.zeta, *grid.h, 1)
+        assert relerr(b.field, a.field) < tol, (fn, freq)

@@ -218,3 +218,50 @@ def test_point_tiled_schedule_matches_oracle_tile_order(shape, dtype):
                 assert relerr(c.field, a.field) > 1e-6
     finally:
         emu.lib().emu_set_point_tile_min(1 << 20)
+
+
+@pytest.mark.parametrize('freq', [1.0, 0.01, -3.0])
+def test_two_sided_line_factorisation_keeps_accuracy_at_low_frequency(freq):
+    """CPU emulation of the two-sided (twisted) line factorisation with the mirrored far
+    half: same accuracy against the oracle's one-sided LDL^T as frequency drops (nearly
+    singular blocks); lines of 64, 6 and 10 blocks exercise middle positions 32, 0 and 4."""
+    shape = (64, 6, 10)
+    rng = np.random.default_rng(1)
+    h = [np.ones(n) * 20. for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, freq, *sig)
+    dtype = complex if freq > 0 else float
+    s = mg_ref.Field(grid, dtype=dtype)
+    e0 = mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    tol = {1.0: 2e-12, 0.01: 2e-10, -3.0: 2e-11}[freq]
+    for fn, lr in LR.items():
+        if lr == 0:
+            continue
+        a, b = e0.copy(), e0.copy()
+        getattr(ocore, fn)(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                           vm.zeta, *grid.h, 1, order=1)
+        emu.gauss_seidel(b, s, vm, lr, 1)
+        assert relerr(b.field, a.field) < tol, (fn, freq)
+
+
+def test_bench_workloads_build():
+    """Every bench.py workload builds (shapes, positive resistivities, source inside)."""
+    from bench import workload
+    for name, shape in (('marine32', (32, 32, 32)), ('triaxial64', (64, 64, 64)),
+                        ('uniform32', (32, 32, 32)), ('salt96', (96, 64, 64))):
+        for idx in (0, 3):
+            wl = workload(name, idx)
+            assert tuple(h.size for h in wl['h']) == shape
+            for v in wl['res'].values():
+                assert np.shape(v) == shape and np.all(np.asarray(v) > 0)
+            for d in range(3):
+                assert wl['origin'][d] < wl['source'][d] < wl['origin'][d] + wl['h'][d].sum()
+    assert {workload('salt96', i)['frequency'] for i in range(8)} == {0.25, 0.5, 1.0, 2.0}
