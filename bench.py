@@ -248,17 +248,26 @@ def run_gpu(args, rank, world):
     import torch
     import torch.distributed as dist
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # EMG3D_BENCH_BACKEND=gloo: dry run of the multi-rank code path on a box with fewer GPUs
+    # than ranks (all ranks share the visible devices, collectives go through host tensors)
+    backend = os.environ.get('EMG3D_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    cdev = device if backend == 'nccl' else torch.device('cpu')     # where collectives run
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     wl = workload(args.workload, source_index=rank if world > 1 else 0)
     if world > 1:
         # the model is built on rank 0 and broadcast over RCCL/xGMI; every rank builds its
         # own eta(f), zeta and source locally
         for k in sorted(wl['res']):
-            t = torch.from_numpy(np.ascontiguousarray(wl['res'][k], dtype=np.float64)).to(device)
+            t = torch.from_numpy(np.ascontiguousarray(wl['res'][k], dtype=np.float64)).to(cdev)
             if rank != 0:
                 t.zero_()
             dist.broadcast(t, 0)
@@ -289,7 +298,7 @@ def run_gpu(args, rank, world):
     work = b.var.smoother_cell_sweeps - w0
     l2 = b.var.l2 / b.var.l2_refe
 
-    tt = torch.tensor([dt, float(work)], dtype=torch.float64, device=device)
+    tt = torch.tensor([dt, float(work)], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
