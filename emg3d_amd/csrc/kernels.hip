@@ -127,12 +127,44 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
 
 // Line smoothers (stencil.h: line_setup / line_rhs / line_forward / line_backward /
 // line_scatter); thread mappings in launch.h.
+// Two waves per 64 lines: wave 0 factorises the top chains, wave 1 the bottom chains (they are
+// independent and the setup is one long dependent recurrence per line); the LDL^T factors of
+// the bottom chain's last block go through LDS to wave 0, which finishes with the middle block.
 template <class T, int DIR>
-__global__ __launch_bounds__(64) void k_line_setup(emg::Level<T> L, int colour, int cntp, int cntq, T *fac,
-                                                   double *lfac)
+__global__ __launch_bounds__(128) void k_line_setup(emg::Level<T> L, int colour, int cntp, int cntq, T *fac,
+                                                    double *lfac)
 {
-    emg::line_setup_thread<T, DIR>(L, colour, cntp, cntq, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y,
-                                   fac, lfac);
+    __shared__ T xch[15][64];
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int i1, i2, lid;
+    const bool valid = emg::line_of_thread<DIR>(colour, cntp, cntq, blockIdx.x * 64 + lane, blockIdx.y, i1, i2, lid);
+    const emg::LineStore<T> st{fac, lfac, cntp * cntq, lid};
+    const int n0p = emg::line_padded(emg::Axes<T, DIR>(L).n0());
+    T C[10], dinv[5];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) C[j] = emg::zero<T>();
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dinv[j] = T(1.0);
+    if (valid) {
+        if (role == 0) {
+            emg::line_setup_top<T, DIR>(L, i1, i2, st, C, dinv);
+        } else {
+            emg::line_setup_bottom<T, DIR>(L, i1, i2, st, n0p, C, dinv);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) xch[j][lane] = C[j];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) xch[10 + j][lane] = dinv[j];
+        }
+    }
+    __syncthreads();
+    if (valid && role == 0) {
+        T Cb[10], db[5];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) Cb[j] = xch[j][lane];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) db[j] = xch[10 + j][lane];
+        emg::line_setup_middle<T, DIR>(L, i1, i2, st, C, dinv, Cb, db);
+    }
 }
 
 template <class T, int DIR>
@@ -701,8 +733,8 @@ void launch_line_setup_dir(const emg::Level<T> &L, T *fac, double *lfac, hipStre
     for (int c = 0; c < 4; ++c) {
         const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
         if (lc.lines <= 0) continue;
-        hipLaunchKernelGGL((k_line_setup<T, DIR>), d3(emg::line_grid(lc)), d3(emg::line_block()), 0, st, L, c,
-                           lc.cntp, lc.cntq, fac + lc.fac_off, lfac + lc.lfac_off);
+        hipLaunchKernelGGL((k_line_setup<T, DIR>), d3(emg::line_grid(lc)), dim3(128), 0, st, L, c, lc.cntp, lc.cntq,
+                           fac + lc.fac_off, lfac + lc.lfac_off);
     }
 }
 

@@ -862,65 +862,69 @@ EMG_HD void line_matrix_mirrored(const Axes<T, DIR> &A, int k, int i1, int i2, T
     ud[0] = 0.0;
 }
 
-// Setup of one line: two-sided block factorisation, stored in (fac, lfac). Sequential
-// along the line (once per level and direction).
-template <class T, int DIR>
-EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int nlines, int lid, int n0p)
-{
-    const Axes<T, DIR> A(L);
-    const int n0 = A.n0();
-    const int mk = line_mid(n0);
-    T C[10], dinv[5];        // factors of the previous block's S (top chain)
-    T dg[5];
-    double mid[5][5], left0[5], leftd[5];
-    auto put_T = [&](int k, const T (&Tp)[15]) {
+// Setup of one line: two-sided block factorisation, stored in (fac, lfac), once per level
+// and direction. The two chains are independent (line_setup_top / line_setup_bottom: the HIP
+// kernel runs them in two waves) and meet in line_setup_middle, which needs the LDL^T
+// factors (C, dinv) of the last block of either chain.
+template <class T> struct LineStore {
+    T *fac;
+    double *lfac;
+    int nlines, lid;
+    EMG_HD void put_T(int k, const T (&Tp)[15]) const
+    {
         T *f = fac + ((size_t)k * nlines + lid) * 15;
 #pragma unroll
         for (int j = 0; j < 15; ++j) f[j] = Tp[j];
-    };
-    auto put_B = [&](int k, const double (&b0)[5], const double (&bd)[5], bool any) {
+    }
+    EMG_HD void put_B(int k, const double (&b0)[5], const double (&bd)[5], bool any) const
+    {
         double *lf = lfac + ((size_t)k * nlines + lid) * 8;
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
             lf[m - 1] = any ? b0[m] : 0.0;
             lf[3 + m] = any ? bd[m] : 0.0;
         }
-    };
-    auto std_S = [&](T (&S)[5][5]) {
+    }
+};
+template <class T> EMG_HD void std_block(const T (&dg)[5], const double (&mid)[5][5], T (&S)[5][5])
+{
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            S[r][r] = dg[r];
+    for (int r = 0; r < 5; ++r) {
+        S[r][r] = dg[r];
 #pragma unroll
-            for (int m = 0; m < r; ++m) S[r][m] = T(mid[r][m]);
-        }
-    };
-    // ---- top chain: standard blocks k = 0 .. m-1
+        for (int m = 0; m < r; ++m) S[r][m] = T(mid[r][m]);
+    }
+}
+
+// top chain: standard blocks k = 0 .. m-1; (C, dinv) = factors of S_{m-1} (untouched if m = 0)
+template <class T, int DIR>
+EMG_HD void line_setup_top(const Level<T> &L, int i1, int i2, const LineStore<T> &st, T (&C)[10], T (&dinv)[5])
+{
+    const Axes<T, DIR> A(L);
+    const int mk = line_mid(A.n0());
+    T dg[5];
+    double mid[5][5], left0[5], leftd[5];
     for (int k = 0; k < mk; ++k) {
         line_matrix<T, DIR>(A, k, i1, i2, dg, mid, left0, leftd);
         T S[5][5];
-        std_S(S);
+        std_block<T>(dg, mid, S);
         if (k > 0) sub_lower_coupling<T>(S, C, dinv, left0, leftd);
         ldlt5<T>(S, 5, C, dinv);
         T Tp[15];
         invert5<T>(C, dinv, Tp);
-        put_T(k, Tp);
-        put_B(k, left0, leftd, k > 0);
+        st.put_T(k, Tp);
+        st.put_B(k, left0, leftd, k > 0);
     }
-    // standard part of the middle: S_m = M_m - B_m T_{m-1} B_m^T  (rows/cols 0..4 of S_Q)
-    T SQ[6][6];
-    {
-        line_matrix<T, DIR>(A, mk, i1, i2, dg, mid, left0, leftd);
-        T S[5][5];
-        std_S(S);
-        if (mk > 0) sub_lower_coupling<T>(S, C, dinv, left0, leftd);
-        put_B(mk, left0, leftd, mk > 0);
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-            for (int m = 0; m <= r; ++m) SQ[r][m] = S[r][m];
-    }
-    // ---- bottom chain: mirrored blocks k = n0-1 .. m+2
-    T Cb[10], db[5];         // factors of the previous block's S (bottom chain)
+}
+// bottom chain: mirrored blocks k = n0-1 .. m+2; (Cb, db) = factors of S_{m+2} (untouched if
+// the chain is empty); also writes the identity padding blocks behind block n0-1
+template <class T, int DIR>
+EMG_HD void line_setup_bottom(const Level<T> &L, int i1, int i2, const LineStore<T> &st, int n0p, T (&Cb)[10],
+                              T (&db)[5])
+{
+    const Axes<T, DIR> A(L);
+    const int n0 = A.n0();
+    const int mk = line_mid(n0);
     double u0[5], ud[5];
     for (int k = n0 - 1; k >= mk + 2; --k) {
         T S[5][5];
@@ -929,14 +933,44 @@ EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, 
         ldlt5<T>(S, 5, Cb, db);
         T Tp[15];
         invert5<T>(Cb, db, Tp);
-        put_T(k, Tp);
-        put_B(k, u0, ud, true);
+        st.put_T(k, Tp);
+        st.put_B(k, u0, ud, true);
     }
-    // mirrored part of the middle: block m+1 = {E0(m+1), t(m+1)} -> Q indices {5, 1..4}
-    {
+    for (int k = n0; k < n0p; ++k) {
+        T *f = st.fac + ((size_t)k * st.nlines + st.lid) * 15;
+        double *lf = st.lfac + ((size_t)k * st.nlines + st.lid) * 8;
+        for (int r = 0; r < 5; ++r)
+            for (int m = 0; m <= r; ++m) f[tri(r + 1, m)] = (r == m) ? T(1.0) : zero<T>();
+        for (int j = 0; j < 8; ++j) lf[j] = 0.0;
+    }
+}
+// middle block Q = {E0(m), t(m+1), E0(m+1)}
+template <class T, int DIR>
+EMG_HD void line_setup_middle(const Level<T> &L, int i1, int i2, const LineStore<T> &st, const T (&C)[10],
+                              const T (&dinv)[5], const T (&Cb)[10], const T (&db)[5])
+{
+    const Axes<T, DIR> A(L);
+    const int n0 = A.n0();
+    const int mk = line_mid(n0);
+    T SQ[6][6];
+    {   // standard part: S_m = M_m - B_m T_{m-1} B_m^T  (rows/cols 0..4 of S_Q)
+        T dg[5];
+        double mid[5][5], left0[5], leftd[5];
+        line_matrix<T, DIR>(A, mk, i1, i2, dg, mid, left0, leftd);
         T S[5][5];
+        std_block<T>(dg, mid, S);
+        if (mk > 0) sub_lower_coupling<T>(S, C, dinv, left0, leftd);
+        st.put_B(mk, left0, leftd, mk > 0);
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int m = 0; m <= r; ++m) SQ[r][m] = S[r][m];
+    }
+    {   // mirrored part: block m+1 = {E0(m+1), t(m+1)} -> Q indices {5, 1..4}
+        T S[5][5];
+        double u0[5], ud[5];
         line_matrix_mirrored<T, DIR>(A, mk + 1, i1, i2, S, u0, ud);
-        put_B(mk + 1, u0, ud, true);
+        st.put_B(mk + 1, u0, ud, true);
         // only what block m has not contributed: E0(m+1) row/column (t(m+1) x t(m+1) is M_m's)
         T Sc[5][5];
 #pragma unroll
@@ -956,26 +990,30 @@ EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, 
             for (int b = 1; b <= a; ++b) SQ[a][b] += Sc[a][b];
         }
     }
-    {
-        T Tq[21];
-        invert6<T>(SQ, Tq);
-        T *f = fac + ((size_t)mk * nlines + lid) * 15;
-        T *g = fac + ((size_t)(mk + 1) * nlines + lid) * 15;
+    T Tq[21];
+    invert6<T>(SQ, Tq);
+    T *f = st.fac + ((size_t)mk * st.nlines + st.lid) * 15;
+    T *g = st.fac + ((size_t)(mk + 1) * st.nlines + st.lid) * 15;
 #pragma unroll
-        for (int j = 0; j < 15; ++j) f[j] = Tq[j];
+    for (int j = 0; j < 15; ++j) f[j] = Tq[j];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) g[j] = Tq[15 + j];
+    for (int j = 0; j < 6; ++j) g[j] = Tq[15 + j];
 #pragma unroll
-        for (int j = 6; j < 15; ++j) g[j] = zero<T>();
-    }
-    // identity padding blocks behind the last block
-    for (int k = n0; k < n0p; ++k) {
-        T *f = fac + ((size_t)k * nlines + lid) * 15;
-        double *lf = lfac + ((size_t)k * nlines + lid) * 8;
-        for (int r = 0; r < 5; ++r)
-            for (int m = 0; m <= r; ++m) f[tri(r + 1, m)] = (r == m) ? T(1.0) : zero<T>();
-        for (int j = 0; j < 8; ++j) lf[j] = 0.0;
-    }
+    for (int j = 6; j < 15; ++j) g[j] = zero<T>();
+}
+// all of it by one thread (CPU emulation of the unit tests)
+template <class T, int DIR>
+EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int nlines, int lid, int n0p)
+{
+    const LineStore<T> st{fac, lfac, nlines, lid};
+    T C[10], dinv[5], Cb[10], db[5];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) C[j] = Cb[j] = zero<T>();
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dinv[j] = db[j] = T(1.0);
+    line_setup_top<T, DIR>(L, i1, i2, st, C, dinv);
+    line_setup_bottom<T, DIR>(L, i1, i2, st, n0p, Cb, db);
+    line_setup_middle<T, DIR>(L, i1, i2, st, C, dinv, Cb, db);
 }
 
 // q = B y  /  q = B^T y  for B = e0 l0^T + diag(0, ld)
