@@ -70,6 +70,10 @@ int g_point_tile_min = 1 << 20;
 // launch per colour, 2 = fused when the colour class has at most g_line_fuse_max lines.
 int g_line_fuse = 2;
 int g_line_fuse_max = 4096;
+// fused line kernel: keep the right-hand-side / solution records of a workgroup's lines in
+// LDS when they fit into this many bytes (0 = never)
+int g_line_lds = 1;
+int g_line_lds_max = 150 * 1024;
 
 // ----------------------------------------------------------------------------- kernels --
 
@@ -290,10 +294,19 @@ template <int HALF> struct HalfWalk {
     __device__ __forceinline__ int bwd(int i) const { return HALF ? mk + 2 + i : mk - 1 - i; }
     __device__ __forceinline__ int clampi(int i) const { return max(min(i, steps - 1), 0); }
 };
+// Where the right-hand-side / solution records of the lines live: record of (block k, line)
+// = k * stride + (line - line0). Global scratch: stride = lines of the colour class, line0 = 0.
+// LDS copy of one workgroup's 16 lines (fused kernel): stride = 16, line0 = its first line.
+template <class T> struct VecRef {
+    T *base;
+    int stride, line0;
+    __device__ __forceinline__ size_t rec(int k, int line) const { return (size_t)k * stride + (line - line0); }
+};
 // records of the vec slots of lane j / of slot 4 for block k of line `line`
-template <int HALF> __device__ __forceinline__ size_t slot_rec(int k, int nlines, int line, bool first)
+template <int HALF, class T>
+__device__ __forceinline__ size_t slot_rec(int k, const VecRef<T> &V, int line, bool first)
 {
-    return (size_t)((HALF && !first) ? k - 1 : k) * nlines + line;
+    return V.rec((HALF && !first) ? k - 1 : k, line);
 }
 
 // The loops below are branch-free inside: loads and stores are unconditional (the halves
@@ -303,8 +316,9 @@ template <int HALF> __device__ __forceinline__ size_t slot_rec(int k, int nlines
 // last line walk the last line again but store into a dummy area behind the records.
 template <class T, int HALF>
 __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int j, const T *fac,
-                                             const double *lfac, T *vec, T *dummy)
+                                             const double *lfac, const VecRef<T> V, T *dummy)
 {
+    T *const vec = V.base;
     const HalfWalk<HALF> W(n0, n0p);
     const bool active = qline < nlines;
     const int line = min(qline, nlines - 1);
@@ -312,8 +326,8 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
     QuadRow<T> ring[QD];
     auto fetch = [&](QuadRow<T> &q, int i) {
         const int k = W.fwd(W.clampi(i));
-        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, nlines, line, j == 0),
-               slot_rec<HALF>(k, nlines, line, false), j);
+        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, V, line, j == 0),
+               slot_rec<HALF>(k, V, line, false), j);
     };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
@@ -340,8 +354,8 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
             w[0] = quad_bcast<0>(wn); w[1] = quad_bcast<1>(wn); w[2] = quad_bcast<2>(wn); w[3] = quad_bcast<3>(wn);
             w[4] = w4;
             wmine = wn;
-            T *const oj = active ? vec + slot_rec<HALF>(k, nlines, line, j == 0) * 5 + j : dslot + j;
-            T *const o4 = active ? vec + slot_rec<HALF>(k, nlines, line, false) * 5 + 4 : dslot + 4;
+            T *const oj = active ? vec + slot_rec<HALF>(k, V, line, j == 0) * 5 + j : dslot + j;
+            T *const o4 = active ? vec + slot_rec<HALF>(k, V, line, false) * 5 + 4 : dslot + 4;
             *oj = wn;
             *o4 = w4;
             fetch(ring[d], i0 + d + QD);
@@ -354,8 +368,9 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines
                                                      T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
-    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, vec, dummy);
-    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+    const VecRef<T> V{vec, nlines, 0};
+    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy);
+    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy);
 }
 
 // Middle block of the two-sided solve (stencil.h: line_middle), by both half-waves:
@@ -364,10 +379,12 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines
 // twice); xa = x_Q[j], xb = x_Q[j2].
 template <class T>
 __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int line, int j, const T *fac,
-                                            const double *lfac, const T *vec, T &xa, T &xb)
+                                            const double *lfac, const VecRef<T> V, T &xa, T &xb)
 {
     const int mk = emg::line_mid(n0);
     const size_t rm = (size_t)mk * nlines + line, rp = rm + nlines;
+    const T *const vec = V.base;
+    const size_t vm = V.rec(mk, line), vp = vm + V.stride;
     // rows of the packed symmetric T_Q (15 entries in record m, 6 in record m+1), loaded
     // first: they do not depend on the forward pass
     const int j2 = 4 + (j & 1);
@@ -381,10 +398,10 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
     }
     T z[6];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) z[r] = vec[rm * 5 + r];
-    z[5] = vec[rp * 5];
+    for (int r = 0; r < 5; ++r) z[r] = vec[vm * 5 + r];
+    z[5] = vec[vp * 5];
     {   // top coupling B_m w_{m-1} (zero if there is no top half: B_0 is stored as zeros)
-        const size_t rt = mk > 0 ? rm - nlines : rm;
+        const size_t rt = mk > 0 ? vm - V.stride : vm;
         const double *lf = lfac + rm * 8;
         T q0 = emg::zero<T>();
 #pragma unroll
@@ -401,7 +418,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
         T q0 = emg::zero<T>();
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
-            const T y = vec[rp * 5 + m];
+            const T y = vec[vp * 5 + m];
             q0 += lf[m - 1] * y;
             z[m] -= lf[3 + m] * y;
         }
@@ -418,9 +435,10 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 // writes the middle block.
 template <class T, int DIR, int HALF>
 __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
-                                              int qline, int j, const T *fac, const double *lfac, const T *vec,
-                                              T *dummy)
+                                              int qline, int j, const T *fac, const double *lfac,
+                                              const VecRef<T> V, T *dummy)
 {
+    const T *const vec = V.base;
     const emg::Axes<T, DIR> A(L);
     const int n0 = A.n0();
     const HalfWalk<HALF> W(n0, n0p);
@@ -444,8 +462,8 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     QuadRow<T> ring[QD];
     auto fetch = [&](QuadRow<T> &q, int i) {
         const int k = min(max(W.bwd(W.clampi(i)), HALF), n0p - 1);   // a half without blocks still prefetches
-        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, nlines, line, j == 0),
-               slot_rec<HALF>(k, nlines, line, false), j);
+        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, V, line, j == 0),
+               slot_rec<HALF>(k, V, line, false), j);
     };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
@@ -455,7 +473,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
 
     // x_Q: this lane's entry j (xa) and entry 4 (even lanes) / 5 (odd lanes) (xb)
     T xa, xb;
-    quad_middle<T>(n0, n0p, nlines, line, j, fac, lfac, vec, xa, xb);
+    quad_middle<T>(n0, n0p, nlines, line, j, fac, lfac, V, xa, xb);
     const T xq0 = quad_bcast<0>(xa), xq4 = quad_bcast<0>(xb), xq5 = quad_bcast<1>(xb);
     if (HALF == 0) {
         // lane j writes entry j of x_Q (E0(m), t(m+1)_1..3), lane 0 also entry 4, lane 1
@@ -505,8 +523,9 @@ __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colou
                                                       const T *fac, const double *lfac, const T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
-    if (blockIdx.y == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, vec, dummy);
-    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, vec, dummy);
+    const VecRef<T> V{const_cast<T *>(vec), cntp * cntq, 0};
+    if (blockIdx.y == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, V, dummy);
+    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, V, dummy);
 }
 
 constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves + helper waves for the rhs phase
@@ -516,30 +535,52 @@ constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves +
 // so only the workgroup's own records have to be complete between the phases (workgroup
 // barriers; both waves sit on one CU and share its L1). On the coarse levels the three
 // separate launches are bound by launch latency, not by work.
-template <class T, int DIR>
+template <class T, int DIR, bool VLDS>
 __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                     const T *fac, const double *lfac, T *vec, T *dummy)
+                                                            const T *fac, const double *lfac, T *vec, T *dummy)
 {
+    // VLDS: the right-hand-side / solution records of the workgroup's 16 lines never leave
+    // the CU -- they live in LDS (16 x n0p x 80 B; the launcher checks that it fits) instead
+    // of the global scratch: no HBM/L2 round trips between the three phases.
+    extern __shared__ double2 lc_smem[];
     const emg::Axes<T, DIR> A(L);
     const int nlines = cntp * cntq;
     const int line0 = blockIdx.x * 16;
     const int nl = min(16, nlines - line0);
+    T *const lvec = reinterpret_cast<T *>(lc_smem);
+    VecRef<T> V;
+    T *dum;
+    if (VLDS) { V.base = lvec; V.stride = 16; V.line0 = line0; dum = lvec + (size_t)16 * n0p * 5; }
+    else { V.base = vec; V.stride = nlines; V.line0 = 0; dum = dummy; }
     // (1) right-hand sides of the workgroup's lines; x-lines run the lanes along the line
     for (int i = threadIdx.x; i < nl * n0p; i += LC_THREADS) {
         const int ll = DIR == 0 ? i / n0p : i % nl;
         const int k = DIR == 0 ? i % n0p : i / nl;
         const int lid = line0 + ll;
-        emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, lid % cntp, lid / cntp, k, vec);
+        if (VLDS) {
+            int i1, i2, l2;
+            emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+            T rhs[5];
+            emg::line_rhs<T, DIR>(A, min(k, A.n0() - 1), i1, i2, rhs);
+            const double keep = k < A.n0() ? 1.0 : 0.0;        // identity padding blocks: rhs = 0
+            T *o = lvec + V.rec(k, lid) * 5;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) o[r] = keep * rhs[r];
+        } else {
+            emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, lid % cntp, lid / cntp, k, vec);
+        }
     }
     __syncthreads();
     if (threadIdx.x >= 128) return;      // helper waves of the rhs phase are done
     const int half = threadIdx.x >> 6;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
-    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, j, fac, lfac, vec, dummy);
-    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, j, fac, lfac, vec, dummy);
+    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum);
+    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum);
     __syncthreads();
-    if (half == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, vec, dummy);
-    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, vec, dummy);
+    // the backward pass stores into the FIELD; its dummy slots must be global memory too, or
+    // the address select mixes address spaces and the stores become flat instructions
+    if (half == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, V, dummy);
+    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, V, dummy);
 }
 
 // Residual + per-block partial sums of |r|^2.
@@ -651,8 +692,21 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
     const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
     if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
-        hipLaunchKernelGGL((k_line_colour<T, DIR>), dim3(q1.x), dim3(LC_THREADS), 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f,
-                           lf, vec, vec + dummy_off);
+        // records in LDS if 16 lines fit (+ the dummy slots) and every workgroup gets a CU
+        const size_t smem = ((size_t)16 * lc.n0p * 5 + emg::LINE_DUMMY) * sizeof(T);
+        if (g_line_lds && smem <= (size_t)g_line_lds_max && (int)q1.x <= 256 * (int)((160 * 1024) / smem)) {
+            static size_t attr = 0;
+            if (smem > attr) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_line_lds_max);
+                attr = g_line_lds_max;
+            }
+            hipLaunchKernelGGL((k_line_colour<T, DIR, true>), dim3(q1.x), dim3(LC_THREADS), smem, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+        } else {
+            hipLaunchKernelGGL((k_line_colour<T, DIR, false>), dim3(q1.x), dim3(LC_THREADS), 0, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+        }
         return;
     }
     if (DIR == 0)
@@ -881,6 +935,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "point_tile_min")) { g_point_tile_min = value; return 0; }
     if (!std::strcmp(name, "line_fuse")) { g_line_fuse = value; return 0; }
     if (!std::strcmp(name, "line_fuse_max")) { g_line_fuse_max = value; return 0; }
+    if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
     return fail(EMG3D_ERR_BADARG, "set_option: unknown option");
 }
 
@@ -890,6 +945,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "point_tile_min")) return g_point_tile_min;
     if (name && !std::strcmp(name, "line_fuse")) return g_line_fuse;
     if (name && !std::strcmp(name, "line_fuse_max")) return g_line_fuse_max;
+    if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
     return -1;
 }
 

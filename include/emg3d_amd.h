@@ -75,7 +75,9 @@ const char *emg3d_last_error(void);
 int emg3d_device_count(void);
 /* Tuning knobs; all but "point_tile_min" never change results. "point_slab": plane-slab thickness of the point
  * smoother's launch schedule (0 = one launch per colour over all planes). "point_tile_min"
- * DOES select the sweep order of the point smoother (see above; <= 0 never tiled). "line_fuse":
+ * DOES select the sweep order of the point smoother (see above; <= 0 never tiled). "line_lds":
+ * 1 (default) keeps the right-hand-side / solution records of a fused line launch in LDS
+ * when 16 lines fit, 0 always uses the global scratch. "line_fuse":
  * 0 three launches per colour and line direction (rhs, forward, backward), 1 one fused
  * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines. */
 int emg3d_set_option(const char *name, int value);

@@ -461,16 +461,18 @@ def test_tuning_options_do_not_change_results(golden_kernels):
             lib.emg3d_set_option(b'line_fuse', 0)
             getattr(core, fn)(a.fx, a.fy, a.fz, *args)
             ref[fn] = a.field.copy()
-        for slab, fuse in ((2, 1), (3, 2), (5, 1)):
+        for slab, fuse, lds in ((2, 1, 1), (3, 2, 0), (5, 1, 0), (0, 2, 1)):
             lib.emg3d_set_option(b'point_slab', slab)
             lib.emg3d_set_option(b'line_fuse', fuse)
+            lib.emg3d_set_option(b'line_lds', lds)
             for fn in SMOOTHERS:
                 b = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
                 getattr(core, fn)(b.fx, b.fy, b.fz, *args)
-                assert np.array_equal(b.field, ref[fn]), (fn, slab, fuse)
+                assert np.array_equal(b.field, ref[fn]), (fn, slab, fuse, lds)
     finally:
         lib.emg3d_set_option(b'point_slab', 0)
         lib.emg3d_set_option(b'line_fuse', 2)
+        lib.emg3d_set_option(b'line_lds', 1)
 
 
 @pytest.mark.parametrize('shape,kw', [
