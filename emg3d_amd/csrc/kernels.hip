@@ -73,7 +73,6 @@ int g_line_fuse_max = 4096;
 // fused line kernel: keep the right-hand-side / solution records of a workgroup's lines in
 // LDS when they fit into this many bytes (0 = never)
 int g_line_lds = 1;
-int g_line_lds_max = 150 * 1024;
 
 // ----------------------------------------------------------------------------- kernels --
 
@@ -241,8 +240,8 @@ template <class T> __device__ __forceinline__ T quad_sum(T x)
     return x;
 }
 // Lane j's share of one block record (all loads unconditional, addresses per lane).
-// rec: record of the block's factors; rvj / rv4: records holding this lane's vec slot j and
-// slot 4 (they differ from rec for the mirrored blocks of the bottom half, stencil.h).
+// rec: record of the block's factors; pvj / pv4: this lane's vec slot j and slot 4 (they
+// belong to another record than rec for the mirrored blocks of the bottom half, stencil.h).
 template <class T> struct QuadRow {
     T t[5];          // T_k(j, 0..4)
     T t44;           // T_k(4,4)
@@ -260,8 +259,8 @@ template <class T> struct QuadRow {
         bD = lf[4 + jm];
         d4 = lf[7];
     }
-    __device__ __forceinline__ void load(const T *fac, const double *lfac, const T *vec, size_t rec, size_t rvj,
-                                         size_t rv4, int j)
+    __device__ __forceinline__ void load(const T *fac, const double *lfac, size_t rec, const T *pvj, const T *pv4,
+                                         int j)
     {
         const T *f = fac + rec * 15;
 #pragma unroll
@@ -270,8 +269,8 @@ template <class T> struct QuadRow {
             t[m] = f[idx];
         }
         t44 = f[14];
-        v = vec[rvj * 5 + j];
-        v4 = vec[rv4 * 5 + 4];
+        v = *pvj;
+        v4 = *pv4;
         load_b(lfac, rec, j);
     }
 };
@@ -294,19 +293,40 @@ template <int HALF> struct HalfWalk {
     __device__ __forceinline__ int bwd(int i) const { return HALF ? mk + 2 + i : mk - 1 - i; }
     __device__ __forceinline__ int clampi(int i) const { return max(min(i, steps - 1), 0); }
 };
-// Where the right-hand-side / solution records of the lines live: record of (block k, line)
-// = k * stride + (line - line0). Global scratch: stride = lines of the colour class, line0 = 0.
-// LDS copy of one workgroup's 16 lines (fused kernel): stride = 16, line0 = its first line.
+// Where the right-hand-side / solution records of the lines live. Slots 0..3 of (block k,
+// line): base + (k * stride + line - line0) * width + r; slot 4: base4 + (k * stride4 +
+// line - line04) * 5 + 4.
+//   global scratch:       both in `vec`, stride = lines of the colour class, width 5
+//   LDS (fused kernel):   the workgroup's 16 lines, stride 16, width 5, both in LDS
+//   LDS, partial:         slots 0..3 in LDS (width 4), slot 4 stays in the global scratch --
+//                         for lines so long that 16 full records exceed the LDS of a CU
 template <class T> struct VecRef {
     T *base;
-    int stride, line0;
-    __device__ __forceinline__ size_t rec(int k, int line) const { return (size_t)k * stride + (line - line0); }
+    int stride, line0, width;
+    T *base4;
+    int stride4, line04;
+    __device__ __forceinline__ T *p(int k, int line, int r) const
+    {
+        return base + ((size_t)k * stride + (line - line0)) * width + r;
+    }
+    __device__ __forceinline__ T *p4(int k, int line) const
+    {
+        return base4 + ((size_t)k * stride4 + (line - line04)) * 5 + 4;
+    }
+    static __device__ __forceinline__ VecRef global(T *vec, int nlines)
+    {
+        return VecRef{vec, nlines, 0, 5, vec, nlines, 0};
+    }
 };
-// records of the vec slots of lane j / of slot 4 for block k of line `line`
-template <int HALF, class T>
-__device__ __forceinline__ size_t slot_rec(int k, const VecRef<T> &V, int line, bool first)
+// vec slots of lane j / slot 4 for block k: a mirrored block (HALF = 1) keeps its entries
+// 1..4 in record k-1
+template <int HALF, class T> __device__ __forceinline__ T *slot_j(const VecRef<T> &V, int k, int line, int j)
 {
-    return V.rec((HALF && !first) ? k - 1 : k, line);
+    return V.p((HALF && j > 0) ? k - 1 : k, line, j);
+}
+template <int HALF, class T> __device__ __forceinline__ T *slot_4(const VecRef<T> &V, int k, int line)
+{
+    return V.p4(HALF ? k - 1 : k, line);
 }
 
 // The loops below are branch-free inside: loads and stores are unconditional (the halves
@@ -316,18 +336,18 @@ __device__ __forceinline__ size_t slot_rec(int k, const VecRef<T> &V, int line, 
 // last line walk the last line again but store into a dummy area behind the records.
 template <class T, int HALF>
 __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int j, const T *fac,
-                                             const double *lfac, const VecRef<T> V, T *dummy)
+                                             const double *lfac, const VecRef<T> V, T *dummy, T *dummy4)
 {
-    T *const vec = V.base;
+    // dummy / dummy4: store targets of surplus quads, in the address spaces of V.base / V.base4
     const HalfWalk<HALF> W(n0, n0p);
     const bool active = qline < nlines;
     const int line = min(qline, nlines - 1);
     T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
+    T *const dslot4 = dummy4 + ((threadIdx.x & 63) >> 2) * 5;
     QuadRow<T> ring[QD];
     auto fetch = [&](QuadRow<T> &q, int i) {
         const int k = W.fwd(W.clampi(i));
-        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, V, line, j == 0),
-               slot_rec<HALF>(k, V, line, false), j);
+        q.load(fac, lfac, (size_t)k * nlines + line, slot_j<HALF>(V, k, line, j), slot_4<HALF>(V, k, line), j);
     };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
@@ -354,8 +374,8 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
             w[0] = quad_bcast<0>(wn); w[1] = quad_bcast<1>(wn); w[2] = quad_bcast<2>(wn); w[3] = quad_bcast<3>(wn);
             w[4] = w4;
             wmine = wn;
-            T *const oj = active ? vec + slot_rec<HALF>(k, V, line, j == 0) * 5 + j : dslot + j;
-            T *const o4 = active ? vec + slot_rec<HALF>(k, V, line, false) * 5 + 4 : dslot + 4;
+            T *const oj = active ? slot_j<HALF>(V, k, line, j) : dslot + j;
+            T *const o4 = active ? slot_4<HALF>(V, k, line) : dslot4 + 4;
             *oj = wn;
             *o4 = w4;
             fetch(ring[d], i0 + d + QD);
@@ -368,9 +388,9 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines
                                                      T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
-    const VecRef<T> V{vec, nlines, 0};
-    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy);
-    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy);
+    const VecRef<T> V = VecRef<T>::global(vec, nlines);
+    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy, dummy);
+    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy, dummy);
 }
 
 // Middle block of the two-sided solve (stencil.h: line_middle), by both half-waves:
@@ -383,8 +403,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 {
     const int mk = emg::line_mid(n0);
     const size_t rm = (size_t)mk * nlines + line, rp = rm + nlines;
-    const T *const vec = V.base;
-    const size_t vm = V.rec(mk, line), vp = vm + V.stride;
+
     // rows of the packed symmetric T_Q (15 entries in record m, 6 in record m+1), loaded
     // first: they do not depend on the forward pass
     const int j2 = 4 + (j & 1);
@@ -398,15 +417,16 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
     }
     T z[6];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) z[r] = vec[vm * 5 + r];
-    z[5] = vec[vp * 5];
+    for (int r = 0; r < 4; ++r) z[r] = *V.p(mk, line, r);
+    z[4] = *V.p4(mk, line);
+    z[5] = *V.p(mk + 1, line, 0);
     {   // top coupling B_m w_{m-1} (zero if there is no top half: B_0 is stored as zeros)
-        const size_t rt = mk > 0 ? vm - V.stride : vm;
+        const int kt = mk > 0 ? mk - 1 : mk;
         const double *lf = lfac + rm * 8;
         T q0 = emg::zero<T>();
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
-            const T y = vec[rt * 5 + m];
+            const T y = m < 4 ? *V.p(kt, line, m) : *V.p4(kt, line);
             q0 += lf[m - 1] * y;
             z[m] -= lf[3 + m] * y;
         }
@@ -418,7 +438,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
         T q0 = emg::zero<T>();
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
-            const T y = vec[vp * 5 + m];
+            const T y = m < 4 ? *V.p(mk + 1, line, m) : *V.p4(mk + 1, line);
             q0 += lf[m - 1] * y;
             z[m] -= lf[3 + m] * y;
         }
@@ -438,7 +458,6 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
                                               int qline, int j, const T *fac, const double *lfac,
                                               const VecRef<T> V, T *dummy)
 {
-    const T *const vec = V.base;
     const emg::Axes<T, DIR> A(L);
     const int n0 = A.n0();
     const HalfWalk<HALF> W(n0, n0p);
@@ -462,8 +481,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     QuadRow<T> ring[QD];
     auto fetch = [&](QuadRow<T> &q, int i) {
         const int k = min(max(W.bwd(W.clampi(i)), HALF), n0p - 1);   // a half without blocks still prefetches
-        q.load(fac, lfac, vec, (size_t)k * nlines + line, slot_rec<HALF>(k, V, line, j == 0),
-               slot_rec<HALF>(k, V, line, false), j);
+        q.load(fac, lfac, (size_t)k * nlines + line, slot_j<HALF>(V, k, line, j), slot_4<HALF>(V, k, line), j);
     };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
@@ -523,7 +541,7 @@ __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colou
                                                       const T *fac, const double *lfac, const T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
-    const VecRef<T> V{const_cast<T *>(vec), cntp * cntq, 0};
+    const VecRef<T> V = VecRef<T>::global(const_cast<T *>(vec), cntp * cntq);
     if (blockIdx.y == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, V, dummy);
     else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, V, dummy);
 }
@@ -535,13 +553,15 @@ constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves +
 // so only the workgroup's own records have to be complete between the phases (workgroup
 // barriers; both waves sit on one CU and share its L1). On the coarse levels the three
 // separate launches are bound by launch latency, not by work.
-template <class T, int DIR, bool VLDS>
+// VMODE: where the right-hand-side / solution records of the workgroup's 16 lines live
+// (VecRef): 0 global scratch; 1 LDS (16 x n0p x 80 B + dummy slots); 2 slots 0..3 in LDS
+// (16 x n0p x 64 B), slot 4 in the global scratch -- for lines too long for mode 1 (128
+// blocks: 166 KB). The launcher picks the first mode that fits. In LDS the records never leave
+// the CU: no HBM/L2 round trips between the three phases.
+template <class T, int DIR, int VMODE>
 __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                             const T *fac, const double *lfac, T *vec, T *dummy)
 {
-    // VLDS: the right-hand-side / solution records of the workgroup's 16 lines never leave
-    // the CU -- they live in LDS (16 x n0p x 80 B; the launcher checks that it fits) instead
-    // of the global scratch: no HBM/L2 round trips between the three phases.
     extern __shared__ double2 lc_smem[];
     const emg::Axes<T, DIR> A(L);
     const int nlines = cntp * cntq;
@@ -549,33 +569,38 @@ __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int
     const int nl = min(16, nlines - line0);
     T *const lvec = reinterpret_cast<T *>(lc_smem);
     VecRef<T> V;
-    T *dum;
-    if (VLDS) { V.base = lvec; V.stride = 16; V.line0 = line0; dum = lvec + (size_t)16 * n0p * 5; }
-    else { V.base = vec; V.stride = nlines; V.line0 = 0; dum = dummy; }
+    T *dum, *dum4;           // dummy store targets in the address spaces of V.base / V.base4
+    if (VMODE == 1) {
+        V = VecRef<T>{lvec, 16, line0, 5, lvec, 16, line0};
+        dum = dum4 = lvec + (size_t)16 * n0p * 5;
+    } else if (VMODE == 2) {
+        V = VecRef<T>{lvec, 16, line0, 4, vec, nlines, 0};
+        dum = lvec + (size_t)16 * n0p * 4;
+        dum4 = dummy;
+    } else {
+        V = VecRef<T>::global(vec, nlines);
+        dum = dum4 = dummy;
+    }
     // (1) right-hand sides of the workgroup's lines; x-lines run the lanes along the line
     for (int i = threadIdx.x; i < nl * n0p; i += LC_THREADS) {
         const int ll = DIR == 0 ? i / n0p : i % nl;
         const int k = DIR == 0 ? i % n0p : i / nl;
         const int lid = line0 + ll;
-        if (VLDS) {
-            int i1, i2, l2;
-            emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
-            T rhs[5];
-            emg::line_rhs<T, DIR>(A, min(k, A.n0() - 1), i1, i2, rhs);
-            const double keep = k < A.n0() ? 1.0 : 0.0;        // identity padding blocks: rhs = 0
-            T *o = lvec + V.rec(k, lid) * 5;
+        int i1, i2, l2;
+        emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+        T rhs[5];
+        emg::line_rhs<T, DIR>(A, min(k, A.n0() - 1), i1, i2, rhs);
+        const double keep = k < A.n0() ? 1.0 : 0.0;            // identity padding blocks: rhs = 0
 #pragma unroll
-            for (int r = 0; r < 5; ++r) o[r] = keep * rhs[r];
-        } else {
-            emg::line_rhs_thread<T, DIR>(L, colour, cntp, cntq, lid % cntp, lid / cntp, k, vec);
-        }
+        for (int r = 0; r < 4; ++r) *V.p(k, lid, r) = keep * rhs[r];
+        *V.p4(k, lid) = keep * rhs[4];
     }
     __syncthreads();
     if (threadIdx.x >= 128) return;      // helper waves of the rhs phase are done
     const int half = threadIdx.x >> 6;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
-    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum);
-    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum);
+    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum, dum4);
+    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum, dum4);
     __syncthreads();
     // the backward pass stores into the FIELD; its dummy slots must be global memory too, or
     // the address select mixes address spaces and the stores become flat instructions
@@ -693,20 +718,29 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
     if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
         // records in LDS if 16 lines fit (+ the dummy slots) and every workgroup gets a CU
-        const size_t smem = ((size_t)16 * lc.n0p * 5 + emg::LINE_DUMMY) * sizeof(T);
-        if (g_line_lds && smem <= (size_t)g_line_lds_max && (int)q1.x <= 256 * (int)((160 * 1024) / smem)) {
-            static size_t attr = 0;
-            if (smem > attr) {
-                hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_line_lds_max);
-                attr = g_line_lds_max;
-            }
-            hipLaunchKernelGGL((k_line_colour<T, DIR, true>), dim3(q1.x), dim3(LC_THREADS), smem, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
-        } else {
-            hipLaunchKernelGGL((k_line_colour<T, DIR, false>), dim3(q1.x), dim3(LC_THREADS), 0, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+        const size_t lds_cu = 160 * 1024;
+        auto fits = [&](size_t smem) {
+            return g_line_lds && smem <= lds_cu && (size_t)q1.x <= 256 * (lds_cu / smem);
+        };
+        const size_t smem1 = ((size_t)16 * lc.n0p * 5 + emg::LINE_DUMMY) * sizeof(T);
+        const size_t smem2 = ((size_t)16 * lc.n0p * 4 + emg::LINE_DUMMY) * sizeof(T);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+            attr = true;
         }
+        if (fits(smem1))
+            hipLaunchKernelGGL((k_line_colour<T, DIR, 1>), dim3(q1.x), dim3(LC_THREADS), smem1, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+        else if (fits(smem2))
+            hipLaunchKernelGGL((k_line_colour<T, DIR, 2>), dim3(q1.x), dim3(LC_THREADS), smem2, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+        else
+            hipLaunchKernelGGL((k_line_colour<T, DIR, 0>), dim3(q1.x), dim3(LC_THREADS), 0, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
         return;
     }
     if (DIR == 0)
