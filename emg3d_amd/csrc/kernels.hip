@@ -73,6 +73,8 @@ int g_line_fuse_max = 4096;
 // fused line kernel: keep the right-hand-side / solution records of a workgroup's lines in
 // LDS when they fit into this many bytes (0 = never)
 int g_line_lds = 1;
+// fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
+int g_line_lpw = 0;
 
 // ----------------------------------------------------------------------------- kernels --
 
@@ -335,13 +337,15 @@ template <int HALF, class T> __device__ __forceinline__ T *slot_4(const VecRef<T
 // vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
 // last line walk the last line again but store into a dummy area behind the records.
 template <class T, int HALF>
-__device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int j, const T *fac,
+__device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int qend, int j, const T *fac,
                                              const double *lfac, const VecRef<T> V, T *dummy, T *dummy4)
 {
     // dummy / dummy4: store targets of surplus quads, in the address spaces of V.base / V.base4
+    // quads with qline >= qend (the end of the caller's line range) are surplus: they walk
+    // line qend-1 again and store into the dummy slots
     const HalfWalk<HALF> W(n0, n0p);
-    const bool active = qline < nlines;
-    const int line = min(qline, nlines - 1);
+    const bool active = qline < qend;
+    const int line = min(qline, qend - 1);
     T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
     T *const dslot4 = dummy4 + ((threadIdx.x & 63) >> 2) * 5;
     QuadRow<T> ring[QD];
@@ -389,8 +393,8 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const VecRef<T> V = VecRef<T>::global(vec, nlines);
-    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy, dummy);
-    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, gt & 3, fac, lfac, V, dummy, dummy);
+    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, nlines, gt & 3, fac, lfac, V, dummy, dummy);
+    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, nlines, gt & 3, fac, lfac, V, dummy, dummy);
 }
 
 // Middle block of the two-sided solve (stencil.h: line_middle), by both half-waves:
@@ -455,7 +459,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 // writes the middle block.
 template <class T, int DIR, int HALF>
 __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
-                                              int qline, int j, const T *fac, const double *lfac,
+                                              int qline, int qend, int j, const T *fac, const double *lfac,
                                               const VecRef<T> V, T *dummy)
 {
     const emg::Axes<T, DIR> A(L);
@@ -463,8 +467,8 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     const HalfWalk<HALF> W(n0, n0p);
     const int mk = W.mk;
     const int nlines = cntp * cntq;
-    const bool active = qline < nlines;
-    const int line = min(qline, nlines - 1);
+    const bool active = qline < qend;
+    const int line = min(qline, qend - 1);
     int i1, i2, lid;
     emg::line_of_thread<DIR>(colour, cntp, cntq, line % cntp, line / cntp, i1, i2, lid);
     // entry j lives on component cj at (k + dk, i1 - d1, i2 - d2); entry 4 on component 2.
@@ -542,8 +546,9 @@ __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colou
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const VecRef<T> V = VecRef<T>::global(const_cast<T *>(vec), cntp * cntq);
-    if (blockIdx.y == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, V, dummy);
-    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, gt & 3, fac, lfac, V, dummy);
+    const int nl = cntp * cntq;
+    if (blockIdx.y == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, gt >> 2, nl, gt & 3, fac, lfac, V, dummy);
+    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, nl, gt & 3, fac, lfac, V, dummy);
 }
 
 constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves + helper waves for the rhs phase
@@ -560,22 +565,26 @@ constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves +
 // the CU: no HBM/L2 round trips between the three phases.
 template <class T, int DIR, int VMODE>
 __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                            const T *fac, const double *lfac, T *vec, T *dummy)
+                                                            int lpw, const T *fac, const double *lfac, T *vec,
+                                                            T *dummy)
 {
+    // lpw = lines per workgroup (16, 8 or 4): the chain phases cost the same however full
+    // the two waves are, but the right-hand-side phase is spread over more CUs when the
+    // colour class has fewer than 16 x 256 lines
     extern __shared__ double2 lc_smem[];
     const emg::Axes<T, DIR> A(L);
     const int nlines = cntp * cntq;
-    const int line0 = blockIdx.x * 16;
-    const int nl = min(16, nlines - line0);
+    const int line0 = blockIdx.x * lpw;
+    const int nl = min(lpw, nlines - line0);
     T *const lvec = reinterpret_cast<T *>(lc_smem);
     VecRef<T> V;
     T *dum, *dum4;           // dummy store targets in the address spaces of V.base / V.base4
     if (VMODE == 1) {
-        V = VecRef<T>{lvec, 16, line0, 5, lvec, 16, line0};
-        dum = dum4 = lvec + (size_t)16 * n0p * 5;
+        V = VecRef<T>{lvec, lpw, line0, 5, lvec, lpw, line0};
+        dum = dum4 = lvec + (size_t)lpw * n0p * 5;
     } else if (VMODE == 2) {
-        V = VecRef<T>{lvec, 16, line0, 4, vec, nlines, 0};
-        dum = lvec + (size_t)16 * n0p * 4;
+        V = VecRef<T>{lvec, lpw, line0, 4, vec, nlines, 0};
+        dum = lvec + (size_t)lpw * n0p * 4;
         dum4 = dummy;
     } else {
         V = VecRef<T>::global(vec, nlines);
@@ -599,13 +608,14 @@ __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int
     if (threadIdx.x >= 128) return;      // helper waves of the rhs phase are done
     const int half = threadIdx.x >> 6;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
-    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum, dum4);
-    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, j, fac, lfac, V, dum, dum4);
+    const int qend = line0 + nl;
+    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
+    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
     __syncthreads();
     // the backward pass stores into the FIELD; its dummy slots must be global memory too, or
     // the address select mixes address spaces and the stores become flat instructions
-    if (half == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, V, dummy);
-    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, qline, j, fac, lfac, V, dummy);
+    if (half == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy);
+    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy);
 }
 
 // Residual + per-block partial sums of |r|^2.
@@ -717,30 +727,36 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
     const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
     if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
-        // records in LDS if 16 lines fit (+ the dummy slots) and every workgroup gets a CU
+        // lines per workgroup: as few as keeps the workgroup count within one per CU
+        int lpw = 16;
+        if (g_line_lpw > 0) lpw = g_line_lpw;
+        else if (cdiv(lc.lines, 4) <= 256) lpw = 4;
+        else if (cdiv(lc.lines, 8) <= 256) lpw = 8;
+        const unsigned nwg = cdiv(lc.lines, lpw);
+        // records in LDS if they fit (+ the dummy slots) and every workgroup gets a CU
         const size_t lds_cu = 160 * 1024;
         auto fits = [&](size_t smem) {
-            return g_line_lds && smem <= lds_cu && (size_t)q1.x <= 256 * (lds_cu / smem);
+            return g_line_lds && smem <= lds_cu && (size_t)nwg <= 256 * (lds_cu / smem);
         };
-        const size_t smem1 = ((size_t)16 * lc.n0p * 5 + emg::LINE_DUMMY) * sizeof(T);
-        const size_t smem2 = ((size_t)16 * lc.n0p * 4 + emg::LINE_DUMMY) * sizeof(T);
+        const size_t smem1 = ((size_t)lpw * lc.n0p * 5 + emg::LINE_DUMMY) * sizeof(T);
+        const size_t smem2 = ((size_t)lpw * lc.n0p * 4 + emg::LINE_DUMMY) * sizeof(T);
         static bool attr = false;
         if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
             attr = true;
         }
         if (fits(smem1))
-            hipLaunchKernelGGL((k_line_colour<T, DIR, 1>), dim3(q1.x), dim3(LC_THREADS), smem1, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+            hipLaunchKernelGGL((k_line_colour<T, DIR, 1>), dim3(nwg), dim3(LC_THREADS), smem1, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off);
         else if (fits(smem2))
-            hipLaunchKernelGGL((k_line_colour<T, DIR, 2>), dim3(q1.x), dim3(LC_THREADS), smem2, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+            hipLaunchKernelGGL((k_line_colour<T, DIR, 2>), dim3(nwg), dim3(LC_THREADS), smem2, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off);
         else
-            hipLaunchKernelGGL((k_line_colour<T, DIR, 0>), dim3(q1.x), dim3(LC_THREADS), 0, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, f, lf, vec, vec + dummy_off);
+            hipLaunchKernelGGL((k_line_colour<T, DIR, 0>), dim3(nwg), dim3(LC_THREADS), 0, st, L, c, lc.cntp,
+                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off);
         return;
     }
     if (DIR == 0)
@@ -970,6 +986,11 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "line_fuse")) { g_line_fuse = value; return 0; }
     if (!std::strcmp(name, "line_fuse_max")) { g_line_fuse_max = value; return 0; }
     if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
+    if (!std::strcmp(name, "line_lpw")) {
+        if (value != 0 && value != 4 && value != 8 && value != 16) return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8 or 16");
+        g_line_lpw = value;
+        return 0;
+    }
     return fail(EMG3D_ERR_BADARG, "set_option: unknown option");
 }
 
@@ -980,6 +1001,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "line_fuse")) return g_line_fuse;
     if (name && !std::strcmp(name, "line_fuse_max")) return g_line_fuse_max;
     if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
+    if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
     return -1;
 }
 

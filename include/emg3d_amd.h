@@ -77,7 +77,8 @@ int emg3d_device_count(void);
  * smoother's launch schedule (0 = one launch per colour over all planes). "point_tile_min"
  * DOES select the sweep order of the point smoother (see above; <= 0 never tiled). "line_lds":
  * 1 (default) keeps the right-hand-side / solution records of a fused line launch in LDS
- * when 16 lines fit, 0 always uses the global scratch. "line_fuse":
+ * when they fit, 0 always uses the global scratch. "line_lpw": lines per workgroup of a fused
+ * line launch (4, 8, 16; 0 = automatic). "line_fuse":
  * 0 three launches per colour and line direction (rhs, forward, backward), 1 one fused
  * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines. */
 int emg3d_set_option(const char *name, int value);
