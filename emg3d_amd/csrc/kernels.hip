@@ -241,24 +241,31 @@ template <class T> __device__ __forceinline__ T quad_sum(T x)
     x = x + dpp_move<0x4E>(x);   // quad_perm:[2,3,0,1]
     return x;
 }
+// cyclic shift inside every quad: lane j receives the value of lane (j + R) & 3
+template <int R, class T> __device__ __forceinline__ T quad_rot(T x)
+{
+    static_assert(R >= 1 && R <= 3, "rotation 1..3");
+    return dpp_move<R == 1 ? 0x39 : (R == 2 ? 0x4E : 0x93)>(x);   // quad_perm [1,2,3,0] / [2,3,0,1] / [3,0,1,2]
+}
 // Lane j's share of one block record (all loads unconditional, addresses per lane).
 // rec: record of the block's factors; pvj / pv4: this lane's vec slot j and slot 4 (they
 // belong to another record than rec for the mirrored blocks of the bottom half, stencil.h).
+// The row of T_k is kept in ROTATED order, t[r] = T_k(j, (j + r) & 3): the quad all-gathers a
+// 4-vector with three cyclic shifts (12 DPP moves) instead of four broadcasts (16), lane j
+// then holds entry (j + r) & 3 in its r-th register.
 template <class T> struct QuadRow {
-    T t[5];          // T_k(j, 0..4)
+    T t[5];          // T_k(j, (j+r)&3), r = 0..3;  t[4] = T_k(j, 4)
     T t44;           // T_k(4,4)
     T v, v4;         // vec[j], vec[4]
-    double l0[4];    // B_k(0, m), m = 1..4           (row 0 of B_k; used by lane 0 / entry 4)
-    double bA, bD;   // B_k(0, j), B_k(j, j) for lane j >= 1 (lane 0: entries of m = 1, masked out)
-    double d4;       // B_k(4, 4)
+    double bA;       // lane j >= 1: B_k(0, j);  lane 0: B_k(0, 4)
+    double bD;       // lane j >= 1: B_k(j, j)   (lane 0: B_k(1,1), masked out)
+    double b04, d4;  // B_k(0, 4), B_k(4, 4)
     __device__ __forceinline__ void load_b(const double *lfac, size_t rec, int j)
     {
         const double *lf = lfac + rec * 8;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) l0[m] = lf[m];
-        const int jm = max(j, 1) - 1;
-        bA = lf[jm];
-        bD = lf[4 + jm];
+        bA = lf[j == 0 ? 3 : j - 1];
+        bD = lf[4 + max(j, 1) - 1];
+        b04 = lf[3];
         d4 = lf[7];
     }
     __device__ __forceinline__ void load(const T *fac, const double *lfac, size_t rec, const T *pvj, const T *pv4,
@@ -266,10 +273,12 @@ template <class T> struct QuadRow {
     {
         const T *f = fac + rec * 15;
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
+        for (int r = 0; r < 4; ++r) {
+            const int m = (j + r) & 3;
             const int idx = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
-            t[m] = f[idx];
+            t[r] = f[idx];
         }
+        t[4] = f[10 + j];
         t44 = f[14];
         v = *pvj;
         v4 = *pv4;
@@ -355,29 +364,27 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
     };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
-    T w[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) w[r] = emg::zero<T>();
-    T wmine = emg::zero<T>();                    // this lane's own entry of w
+    // Of w_{k-1} the coupling needs: lane j >= 1 its own entry (B(j,j) w_j), everybody w_4,
+    // and lane 0 the row sum  sum_m B(0,m) w_m, m = 1..4 -- formed as a quad sum of one
+    // product per lane (lane j >= 1: B(0,j) w_j, lane 0: B(0,4) w_4) instead of broadcasting w.
+    T wsel = emg::zero<T>();                     // lane 0: w_4, lane j >= 1: own entry w_j
+    T w4p = emg::zero<T>();                      // w_4 of the previous block
     const double nz = j != 0 ? 1.0 : 0.0, is0 = 1.0 - nz;
     for (int i0 = 0; i0 < W.steps; i0 += QD) {
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = W.fwd(i0 + d);
             const QuadRow<T> &q = ring[d];
-            // c_j = rhs_j - (B w_prev)_j ; row 0: sum_m B(0,m) w_m (lane 0) ; row j: B(j,j) w_j
-            T bw0 = emg::zero<T>();
-#pragma unroll
-            for (int m = 0; m < 4; ++m) bw0 += q.l0[m] * w[m + 1];
-            const T cj = q.v - ((q.bD * nz) * wmine + is0 * bw0);
-            const T c4 = q.v4 - q.d4 * w[4];
-            const T c0 = quad_bcast<0>(cj), c1 = quad_bcast<1>(cj), c2 = quad_bcast<2>(cj), c3 = quad_bcast<3>(cj);
+            // c_j = rhs_j - (B w_prev)_j ; row 0: the row sum ; row j: B(j,j) w_j
+            const T rowsum = quad_sum(q.bA * wsel);
+            const T cj = q.v - (is0 * rowsum + (q.bD * nz) * wsel);
+            const T c4 = q.v4 - q.d4 * w4p;
+            const T c1 = quad_rot<1>(cj), c2 = quad_rot<2>(cj), c3 = quad_rot<3>(cj);
             // w_j = sum_m T(j,m) c_m ; w_4 from the partial products T(j,4) c_j
-            const T wn = q.t[0] * c0 + q.t[1] * c1 + (q.t[2] * c2 + q.t[3] * c3) + q.t[4] * c4;
+            const T wn = q.t[0] * cj + q.t[1] * c1 + (q.t[2] * c2 + q.t[3] * c3) + q.t[4] * c4;
             const T w4 = quad_sum(q.t[4] * cj) + q.t44 * c4;
-            w[0] = quad_bcast<0>(wn); w[1] = quad_bcast<1>(wn); w[2] = quad_bcast<2>(wn); w[3] = quad_bcast<3>(wn);
-            w[4] = w4;
-            wmine = wn;
+            wsel = nz * wn + is0 * w4;
+            w4p = w4;
             T *const oj = active ? slot_j<HALF>(V, k, line, j) : dslot + j;
             T *const o4 = active ? slot_4<HALF>(V, k, line) : dslot4 + 4;
             *oj = wn;
@@ -513,7 +520,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     x[4] = xq4;
     const double own0 = j == 0 ? 1.0 : 0.0;
     T xmine = HALF ? own0 * xq5 + (1.0 - own0) * xa : xa;   // this lane's own entry of x
-    double upA = qm.bA, upD = qm.bD, up03 = qm.l0[3], up44 = qm.d4;        // entries of the coupling block
+    double upA = qm.bA, upD = qm.bD, up04 = qm.b04, up44 = qm.d4;          // entries of the coupling block
     const double nz = j != 0 ? 1.0 : 0.0;
     for (int i0 = 0; i0 < W.steps; i0 += QD) {
 #pragma unroll
@@ -522,14 +529,14 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
             const QuadRow<T> &q = ring[d];
             // h = B^T x_prev: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
             const T hj = (upA * nz) * x[0] + (upD * nz) * xmine;
-            const T h4 = up03 * x[0] + up44 * x[4];
-            const T h0 = quad_bcast<0>(hj), h1 = quad_bcast<1>(hj), h2 = quad_bcast<2>(hj), h3 = quad_bcast<3>(hj);
-            const T xn = q.v - (q.t[0] * h0 + q.t[1] * h1 + (q.t[2] * h2 + q.t[3] * h3) + q.t[4] * h4);
+            const T h4 = up04 * x[0] + up44 * x[4];
+            const T h1 = quad_rot<1>(hj), h2 = quad_rot<2>(hj), h3 = quad_rot<3>(hj);
+            const T xn = q.v - (q.t[0] * hj + q.t[1] * h1 + (q.t[2] * h2 + q.t[3] * h3) + q.t[4] * h4);
             const T x4 = q.v4 - (quad_sum(q.t[4] * hj) + q.t44 * h4);
             x[0] = quad_bcast<0>(xn);
             x[4] = x4;
             xmine = xn;
-            upA = q.bA; upD = q.bD; up03 = q.l0[3]; up44 = q.d4;
+            upA = q.bA; upD = q.bD; up04 = q.b04; up44 = q.d4;
             const bool real_block = HALF ? k <= n0 - 1 : true;
             T *const oj = (active && real_block) ? ej + (long)k * sj : dj;
             T *const o4 = (active && real_block) ? e4 + (long)k * s4 : d4;
