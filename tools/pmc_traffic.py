@@ -41,11 +41,14 @@ def main():
     for d, name in ((0, 'k_gs_line<x>'), (1, 'k_gs_line<y>'), (2, 'k_gs_line<z>')):
         parts = {}
         for k in fetch:
-            for tag in (f'k_line_colour<emg::cplx, {d}>', f'k_line_backward<emg::cplx, {d}>',
+            for tag in (f'k_line_colour<emg::cplx, {d},', f'k_line_backward<emg::cplx, {d}>',
                         f'k_line_rhs<emg::cplx, {d}>', 'k_line_rhs_xt<emg::cplx>' if d == 0 else None):
                 if tag and tag in k:
-                    parts[tag] = {'read': 2 * fetch[k][1] * 1024, 'write': write[k][1] * 1024,
-                                  'grid': fetch[k][0], 'launches': fetch[k][2]}
+                    cand = {'read': 2 * fetch[k][1] * 1024, 'write': write[k][1] * 1024,
+                            'grid': fetch[k][0], 'launches': fetch[k][2], 'kernel': k.split('(emg::Level')[0][-40:]}
+                    # several instantiations (LDS modes) share a tag: the finest level's moves most
+                    if tag not in parts or cand['read'] + cand['write'] > parts[tag]['read'] + parts[tag]['write']:
+                        parts[tag] = cand
         if not parts:
             continue
         gmax = max(p['grid'] for p in parts.values())
