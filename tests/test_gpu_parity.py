@@ -617,3 +617,30 @@ def test_line_smoothers_low_frequency_accuracy(freq):
         getattr(core, fn)(b.fx, b.fy, b.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
                           vm.zeta, *grid.h, 1)
         assert relerr(b.field, a.field) < tol, (fn, freq)
+
+
+@pytest.mark.parametrize('freq', [1.3, -2.5])
+@pytest.mark.parametrize('case', ['isotropic', 'VTI', 'HTI', 'triaxial'])
+def test_volume_model_device_arrays_match_host(case, freq):
+    """solve() forms eta / zeta directly in HBM (VolumeModel.device_arrays); they must equal
+    the host formulas of the reference (emg3d/models.py:654-691), including epsilon_r, mu_r,
+    the Laplace domain and the aliasing of eta_y / eta_z."""
+    rng = np.random.default_rng(3)
+    shape = (6, 5, 7)
+    grid = emg3d.TensorMesh([rng.uniform(1, 3, n) for n in shape], (0., 0., 0.))
+    kw = dict(property_x=10 ** rng.uniform(-1, 1, shape), mu_r=rng.uniform(1, 2, shape),
+              epsilon_r=rng.uniform(1, 80, shape))
+    if case in ('HTI', 'triaxial'):
+        kw['property_y'] = 10 ** rng.uniform(-1, 1, shape)
+    if case in ('VTI', 'triaxial'):
+        kw['property_z'] = 10 ** rng.uniform(-1, 1, shape)
+    for drop in ((), ('mu_r',), ('epsilon_r',), ('mu_r', 'epsilon_r')):
+        model = emg3d.Model(grid, **{k: v for k, v in kw.items() if k not in drop})
+        sfield = emg3d.Field(grid, frequency=freq)
+        vm = emg3d.models.VolumeModel(model, sfield)
+        ex, ey, ez, zeta = vm.device_arrays(torch.device('cuda'))
+        assert (ey is ex) == (vm.eta_y is vm.eta_x) and (ez is ex) == (vm.eta_z is vm.eta_x)
+        for dev, host in ((ex, vm.eta_x), (ey, vm.eta_y), (ez, vm.eta_z), (zeta, vm.zeta)):
+            got = dev.cpu().numpy()
+            assert got.dtype == host.dtype
+            assert relerr(got, host.ravel('F')) < 1e-15, (case, freq, drop)
