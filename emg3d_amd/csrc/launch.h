@@ -92,7 +92,7 @@ template <int BX_, int BY_, int BZ_> struct TileBox {
     static constexpr int THREADS = BX * BY * BZ / 4;   // one thread per node of a colour class
     static_assert(BX % 2 == 0 && BY % 2 == 0, "tile extents in x and y must be even");
 };
-using PointTile = TileBox<16, 8, 8>;
+using PointTile = TileBox<32, 4, 6>;
 
 struct TileCount { int x, y, z; };
 template <class TB> inline TileCount tile_count(int nx, int ny, int nz)

@@ -34,7 +34,7 @@
  *     lines:  colour = (p&1) | ((q&1)<<1), (p,q) the transverse node indices in memory
  *             order: x-lines (iy,iz), y-lines (ix,iz), z-lines (ix,iy).
  *     Point smoother on LARGE levels -- (nx-1)(ny-1)(nz-1) >= option "point_tile_min"
- *     (default 2^20) -- the interior nodes are cut into tiles of 16 x 8 x 8 nodes (tile t
+ *     (default 2^20) -- the interior nodes are cut into tiles of 32 x 4 x 6 nodes (tile t
  *     along an axis = nodes 1 + t*B .. (t+1)*B) which are coloured
  *     (tx&1)|((ty&1)<<1)|((tz&1)<<2); a forward sweep visits the tile colours 0..7 (backward
  *     7..0) and, inside every tile, the four node colours as above. This is the order in
