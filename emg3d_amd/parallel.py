@@ -157,13 +157,18 @@ def gather_objects(obj, dst=0):
 
 
 def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, solve_fn=None,
-            keep_fields=True):
+            keep_fields=True, per_gpu=1):
     """Solve all source-frequency pairs, sharded over the ranks of the process group.
 
     model: on rank 0 (None elsewhere is fine; it is broadcast). sources: dict name ->
     source coordinates; frequencies: dict name -> Hz. Returns, on every rank, a dict
     {(src, freq): (efield or None, info)} for the pairs THIS rank computed; rank 0
     additionally gets key '_all_info': {(src, freq): info} gathered from all ranks.
+
+    per_gpu > 1: the rank works on that many of its pairs at a time, each in its own host
+    thread on its own HIP stream (the max_workers of the reference's process pool, but
+    inside one GPU): a multigrid cycle leaves most of an MI355X idle on its coarse levels,
+    and 3-4 concurrent solves raise the throughput by ~1.5x.
     """
     rank, world, device = init()
     model = broadcast_model(model, 0, device)
@@ -171,12 +176,61 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
     mine = shard(len(pairs), rank, world, costs)
     solve_fn = solve_fn or solve
     out = {}
-    for i in mine:
+
+    def job(i, stream=None):
         s, f = pairs[i]
         inp = {'model': model, 'grid': grid or model.grid, 'source': sources[s],
                'frequency': frequencies[f], 'efield': None, 'solver_opts': solver_opts or {}}
-        efield, info = solve_fn(inp)
-        out[(s, f)] = (efield if keep_fields else None, info)
+        if stream is None:
+            efield, info = solve_fn(inp)
+        else:
+            import torch
+            with torch.cuda.stream(stream):
+                efield, info = solve_fn(inp)
+                stream.synchronize()
+        return (s, f), (efield if keep_fields else None, info)
+
+    if per_gpu <= 1 or len(mine) <= 1:
+        for i in mine:
+            k, v = job(i)
+            out[k] = v
+    else:
+        import queue
+        import threading
+        todo = queue.Queue()
+        for i in mine:
+            todo.put(i)
+        errors = []
+
+        def worker():
+            stream = None
+            if device.type == 'cuda':
+                import torch
+                torch.cuda.set_device(device)
+                stream = torch.cuda.Stream(device)
+            while True:
+                try:
+                    i = todo.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    k, v = job(i, stream)
+                    out[k] = v
+                except BaseException as exc:      # surfaced after the join
+                    errors.append(exc)
+                    return
+        from emg3d_amd import solver as _solver
+        threads = [threading.Thread(target=worker) for _ in range(min(per_gpu, len(mine)))]
+        _solver._CONCURRENT += 1          # no stream capture while several threads solve
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            _solver._CONCURRENT -= 1
+        if errors:
+            raise errors[0]
     small = {k: {kk: vv for kk, vv in v[1].items() if kk not in ('log',)} for k, v in out.items()}
     gathered = gather_objects(small, 0)
     if rank == 0:

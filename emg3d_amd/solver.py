@@ -272,6 +272,9 @@ def _smooth(lv, nu, lr_dir, var):
 # boundary costs ~1.5 us inside a graph against ~5-10 us of host time per eager launch).
 _USE_GRAPHS = os.environ.get('EMG3D_AMD_GRAPHS', '1') != '0'
 _GRAPH_AFTER = int(os.environ.get('EMG3D_AMD_GRAPH_AFTER', '2'))   # eager occurrences before capture
+# > 0 while several host threads solve on one GPU (parallel.compute(per_gpu > 1)): stream
+# capture is then off -- a synchronous copy in one thread is illegal while another captures
+_CONCURRENT = 0
 
 
 def _coarse_correction_graphed(clv, var, new_cycmax):
@@ -298,7 +301,9 @@ def _coarse_correction_graphed(clv, var, new_cycmax):
         w0 = var.smoother_cell_sweeps
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: other host threads may be launching their own solves (parallel.compute
+        # with per_gpu > 1) while this one captures
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             _multigrid(clv, var, 1, new_cycmax)
         var.smoother_cell_sweeps = w0       # capturing does not execute
         entry['graph'] = g
@@ -354,7 +359,7 @@ def _multigrid(lv, var, level, new_cycmax):
             sc_dir = _current_sc_dir(var.sc_dir, lv.grid)
             lv.residual(store=True, norm=False)
             clv = lv.restrict_to(sc_dir)
-            if level == 0 and var.verb < 5 and _USE_GRAPHS:
+            if level == 0 and var.verb < 5 and _USE_GRAPHS and _CONCURRENT == 0:
                 _coarse_correction_graphed(clv, var, cycmax - cyc)
             else:
                 _multigrid(clv, var, level + 1, cycmax - cyc)

@@ -644,3 +644,24 @@ def test_volume_model_device_arrays_match_host(case, freq):
             got = dev.cpu().numpy()
             assert got.dtype == host.dtype
             assert relerr(got, host.ravel('F')) < 1e-15, (case, freq, drop)
+
+
+def test_parallel_compute_concurrent_solves_per_gpu():
+    """parallel.compute(per_gpu=2): two solves at a time on one GPU (own host threads and HIP
+    streams) give the fields of the one-after-the-other run."""
+    from emg3d_amd import parallel
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx, hx], (-hx.sum() / 2,) * 3)
+    rng = np.random.default_rng(5)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells))
+    sources = {f'S{i}': (-40. + 30. * i, 0., 10., 0., 0.) for i in range(4)}
+    freqs = {'f1': 1.0, 'f2': 3.0}
+    opts = {'sslsolver': False, 'tol': 1e-8, 'verb': 0}
+    seq = parallel.compute(model, grid, sources, freqs, opts)
+    con = parallel.compute(model, grid, sources, freqs, opts, per_gpu=3)
+    keys = sorted(k for k in seq if k != '_all_info')
+    assert sorted(k for k in con if k != '_all_info') == keys and len(keys) == 8
+    for k in keys:
+        assert seq[k][1]['exit'] == 0 and con[k][1]['exit'] == 0
+        assert con[k][1]['it_mg'] == seq[k][1]['it_mg']
+        assert np.array_equal(con[k][0].field, seq[k][0].field), k

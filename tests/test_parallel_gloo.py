@@ -53,6 +53,11 @@ def _worker(rank, world, port, q):
                                solve_fn=fake_solve)
         mine = sorted(k for k in out if k != '_all_info')
         res = {'rank': rank, 'mine': mine, 'case': None, 'all': None}
+        # several pairs at a time per rank (host threads): same pairs, same results
+        out3 = parallel.compute(model, None, sources, freqs, {'sslsolver': False},
+                                solve_fn=fake_solve, per_gpu=3)
+        res['threads_ok'] = (sorted(k for k in out3 if k != '_all_info') == mine and
+                             all(out3[k][1]['chk'] == out[k][1]['chk'] for k in mine))
         if rank == 0:
             res['all'] = {k: v['chk'] for k, v in out['_all_info'].items()}
         # LPT sharding is deterministic and balanced
@@ -83,6 +88,7 @@ def test_two_process_gloo_sharding_and_broadcast():
         p.join(60)
         assert p.exitcode == 0
     assert all('error' not in r for r in results), results
+    assert all(r['threads_ok'] for r in results)
     res = {r['rank']: r for r in results}
     pairs = [(f'S{i}', f) for i in range(5) for f in ('f1', 'f2')]
     assert sorted(res[0]['mine'] + res[1]['mine']) == sorted(pairs)      # each pair once
