@@ -665,3 +665,41 @@ def test_parallel_compute_concurrent_solves_per_gpu():
         assert seq[k][1]['exit'] == 0 and con[k][1]['exit'] == 0
         assert con[k][1]['it_mg'] == seq[k][1]['it_mg']
         assert np.array_equal(con[k][0].field, seq[k][0].field), k
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_randomised_smoother_parity(seed):
+    """Randomised sweep over grid shapes (even, odd, 2-cell, long and short lines: every
+    middle-block position and padding of the two-sided line solve, every lines-per-workgroup /
+    LDS-record mode of the fused kernel), anisotropy cases, dtypes and sweep counts: each
+    smoother on the GPU against the oracle in the same ordering, per call."""
+    rng = np.random.default_rng(1000 + seed)
+    shape = tuple(int(rng.choice([2, 3, 4, 5, 6, 8, 9, 12, 16, 17, 24, 33, 40, 70])) for _ in range(3))
+    if np.prod(shape) > 60000:
+        shape = (shape[0], min(shape[1], 12), min(shape[2], 16))
+    case = str(rng.choice(['isotropic', 'VTI', 'HTI', 'triaxial']))
+    freq = float(rng.choice([1.0, 0.1, -1.0]))
+    h = [rng.uniform(5., 15., n) * 1.1 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sx = 10 ** rng.uniform(-1, 1, shape)
+    sy = 10 ** rng.uniform(-1, 1, shape) if case in ('HTI', 'triaxial') else None
+    sz = 10 ** rng.uniform(-1, 1, shape) if case in ('VTI', 'triaxial') else None
+    vm = mg_ref.volume_model(grid, freq, sx, sy, sz)
+    dtype = complex if freq > 0 else float
+    s = mg_ref.Field(grid, dtype=dtype)
+    e0 = mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    nu = int(rng.integers(1, 4))
+    for fn in SMOOTHERS:
+        a, b = e0.copy(), e0.copy()
+        getattr(ocore, fn)(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                           vm.zeta, *grid.h, nu, order=1)
+        getattr(core, fn)(b.fx, b.fy, b.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                          vm.zeta, *grid.h, nu)
+        assert relerr(b.field, a.field) < 1e-10, (shape, case, freq, nu, fn)
