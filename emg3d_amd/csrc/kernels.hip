@@ -284,6 +284,19 @@ template <class T> struct QuadRow {
         v4 = *pv4;
         load_b(lfac, rec, j);
     }
+    template <class A> __device__ __forceinline__ void load(const A &a, int k)
+    {
+        const char *f = a.fac + (size_t)k * a.frow, *lf = a.lfac + (size_t)k * a.lrow;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) t[r] = *reinterpret_cast<const T *>(f + a.ft[r]);
+        t44 = *reinterpret_cast<const T *>(f + a.ft[5]);
+        v = *a.pvj(k);
+        v4 = *a.pv4(k);
+        bA = *reinterpret_cast<const double *>(lf + a.la);
+        bD = *reinterpret_cast<const double *>(lf + a.ld);
+        b04 = *reinterpret_cast<const double *>(lf + a.l04);
+        d4 = *reinterpret_cast<const double *>(lf + a.l4);
+    }
 };
 
 constexpr int QD = emg::LINE_PAD;   // blocks in flight per line = padding granule
@@ -340,6 +353,56 @@ template <int HALF, class T> __device__ __forceinline__ T *slot_4(const VecRef<T
     return V.p4(HALF ? k - 1 : k, line);
 }
 
+// Addresses of one lane inside the half-chain loops, split into a per-block part that is
+// uniform over the wave (block index x row size: scalar registers, scalar multiplies) and a
+// loop-invariant, non-negative 32-bit per-lane part. Without the split every load of every
+// step pays 64-bit per-lane multiplies (v_mad_u64_u32: quarter rate) -- a quarter of the
+// issue slots of a step.
+template <class T, int HALF> struct LaneAddr {
+    const char *fac, *lfac;      // uniform
+    size_t frow, lrow;           // bytes of one block row of the factor arrays (all lines)
+    unsigned ft[6];              // lane byte offsets in a fac row: T(j,(j+r)&3) r=0..3, T(j,4), T(4,4)
+    unsigned la, ld, l04, l4;    // lane byte offsets in an lfac row: bA, bD, B(0,4), B(4,4)
+    char *vb, *vb4;              // uniform bases of the vec slots 0..3 / slot 4
+    size_t vrow, vrow4;          // bytes of one block row of the records
+    unsigned vj, v4;             // lane byte offsets of slot j / slot 4
+    __device__ __forceinline__ LaneAddr(const T *f, const double *lf, int nlines, int line, int j, const VecRef<T> &V)
+    {
+        fac = reinterpret_cast<const char *>(f);
+        lfac = reinterpret_cast<const char *>(lf);
+        frow = (size_t)nlines * 15 * sizeof(T);
+        lrow = (size_t)nlines * 8 * sizeof(double);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = (j + r) & 3;
+            const int idx = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
+            ft[r] = (unsigned)((line * 15 + idx) * sizeof(T));
+        }
+        ft[4] = (unsigned)((line * 15 + 10 + j) * sizeof(T));
+        ft[5] = (unsigned)((line * 15 + 14) * sizeof(T));
+        la = (unsigned)((line * 8 + (j == 0 ? 3 : j - 1)) * sizeof(double));
+        ld = (unsigned)((line * 8 + 4 + max(j, 1) - 1) * sizeof(double));
+        l04 = (unsigned)((line * 8 + 3) * sizeof(double));
+        l4 = (unsigned)((line * 8 + 7) * sizeof(double));
+        // a mirrored block (HALF 1) keeps entries 1..4 in record k-1, entry 0 in record k: the
+        // uniform part uses k-1, lane 0 adds one row
+        vb = reinterpret_cast<char *>(V.base);
+        vb4 = reinterpret_cast<char *>(V.base4);
+        vrow = (size_t)V.stride * V.width * sizeof(T);
+        vrow4 = (size_t)V.stride4 * 5 * sizeof(T);
+        vj = (unsigned)(((line - V.line0) * V.width + j) * sizeof(T)) + ((HALF && j == 0) ? (unsigned)vrow : 0u);
+        v4 = (unsigned)(((line - V.line04) * 5 + 4) * sizeof(T));
+    }
+    __device__ __forceinline__ T *pvj(int k) const
+    {
+        return reinterpret_cast<T *>(vb + (size_t)(HALF ? k - 1 : k) * vrow + vj);
+    }
+    __device__ __forceinline__ T *pv4(int k) const
+    {
+        return reinterpret_cast<T *>(vb4 + (size_t)(HALF ? k - 1 : k) * vrow4 + v4);
+    }
+};
+
 // The loops below are branch-free inside: loads and stores are unconditional (the halves
 // are padded to a multiple of QD blocks with identity blocks, stencil.h), because with
 // branches around memory operations the compiler's s_waitcnt insertion falls back to
@@ -358,10 +421,8 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
     T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
     T *const dslot4 = dummy4 + ((threadIdx.x & 63) >> 2) * 5;
     QuadRow<T> ring[QD];
-    auto fetch = [&](QuadRow<T> &q, int i) {
-        const int k = W.fwd(W.clampi(i));
-        q.load(fac, lfac, (size_t)k * nlines + line, slot_j<HALF>(V, k, line, j), slot_4<HALF>(V, k, line), j);
-    };
+    const LaneAddr<T, HALF> LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T> &q, int i) { q.load(LA, W.fwd(W.clampi(i))); };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
     // Of w_{k-1} the coupling needs: lane j >= 1 its own entry (B(j,j) w_j), everybody w_4,
@@ -385,8 +446,8 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
             const T w4 = quad_sum(q.t[4] * cj) + q.t44 * c4;
             wsel = nz * wn + is0 * w4;
             w4p = w4;
-            T *const oj = active ? slot_j<HALF>(V, k, line, j) : dslot + j;
-            T *const o4 = active ? slot_4<HALF>(V, k, line) : dslot4 + 4;
+            T *const oj = active ? LA.pvj(k) : dslot + j;
+            T *const o4 = active ? LA.pv4(k) : dslot4 + 4;
             *oj = wn;
             *o4 = w4;
             fetch(ring[d], i0 + d + QD);
@@ -490,9 +551,9 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     T *const dj = dslot + j, *const d4 = dslot + 4;
 
     QuadRow<T> ring[QD];
+    const LaneAddr<T, HALF> LA(fac, lfac, nlines, line, j, V);
     auto fetch = [&](QuadRow<T> &q, int i) {
-        const int k = min(max(W.bwd(W.clampi(i)), HALF), n0p - 1);   // a half without blocks still prefetches
-        q.load(fac, lfac, (size_t)k * nlines + line, slot_j<HALF>(V, k, line, j), slot_4<HALF>(V, k, line), j);
+        q.load(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));   // a half without blocks still prefetches
     };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
@@ -521,6 +582,11 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     const double own0 = j == 0 ? 1.0 : 0.0;
     T xmine = HALF ? own0 * xq5 + (1.0 - own0) * xa : xa;   // this lane's own entry of x
     double upA = qm.bA, upD = qm.bD, up04 = qm.b04, up44 = qm.d4;          // entries of the coupling block
+    // running scatter pointers (surplus quads: the dummy slots, not advanced): no per-lane
+    // 64-bit multiply per step
+    T *pej = active ? ej + (long)W.bwd(0) * sj : dj;
+    T *pe4 = active ? e4 + (long)W.bwd(0) * s4 : d4;
+    const long incj = active ? (HALF ? sj : -sj) : 0, inc4 = active ? (HALF ? s4 : -s4) : 0;
     const double nz = j != 0 ? 1.0 : 0.0;
     for (int i0 = 0; i0 < W.steps; i0 += QD) {
 #pragma unroll
@@ -537,11 +603,13 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
             x[4] = x4;
             xmine = xn;
             upA = q.bA; upD = q.bD; up04 = q.b04; up44 = q.d4;
-            const bool real_block = HALF ? k <= n0 - 1 : true;
-            T *const oj = (active && real_block) ? ej + (long)k * sj : dj;
-            T *const o4 = (active && real_block) ? e4 + (long)k * s4 : d4;
+            const bool real_block = HALF ? k <= n0 - 1 : true;      // uniform over the wave
+            T *const oj = real_block ? pej : dj;
+            T *const o4 = real_block ? pe4 : d4;
             *oj = xn;
             *o4 = x4;
+            pej += incj;
+            pe4 += inc4;
             fetch(ring[d], i0 + d + QD);
         }
     }

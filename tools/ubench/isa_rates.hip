@@ -1,0 +1,78 @@
+// Micro-benchmark: cycles per wave64 instruction on gfx950 for the instruction classes of the
+// line-smoother block step, one wave per workgroup (as in k_line_colour's chain waves).
+//   hipcc --offload-arch=gfx950 -O3 isa_rates.hip -o isa_rates && ./isa_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define N 256
+template <int MODE> __global__ void k(double *out, unsigned long long *cyc, double a, double b)
+{
+    double x0 = a + threadIdx.x, x1 = b + threadIdx.x, x2 = a * 2 + threadIdx.x, x3 = b * 3 + threadIdx.x;
+    double y0 = x0 + 1, y1 = x1 + 1, y2 = x2 + 1, y3 = x3 + 1;
+    const unsigned long long t0 = clock64();
+#pragma unroll 1
+    for (int it = 0; it < N; ++it) {
+        if (MODE == 0) {          // 8 dependent fma (one chain)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x0 = x0 * a + b;
+        } else if (MODE == 1) {   // 8 independent fma (8 chains)
+            x0 = x0 * a + b; x1 = x1 * a + b; x2 = x2 * a + b; x3 = x3 * a + b;
+            y0 = y0 * a + b; y1 = y1 * a + b; y2 = y2 * a + b; y3 = y3 * a + b;
+        } else if (MODE == 2) {   // 8 dependent dpp moves of a double (16 v_mov_b32_dpp)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int lo = __builtin_amdgcn_mov_dpp(__double2loint(x0), 0x39, 0xf, 0xf, true);
+                int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x0), 0x39, 0xf, 0xf, true);
+                x0 = __hiloint2double(hi, lo);
+            }
+        } else if (MODE == 3) {   // 8 independent dpp moves of doubles (16 v_mov_b32_dpp)
+            double *p[8] = {&x0, &x1, &x2, &x3, &y0, &y1, &y2, &y3};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int lo = __builtin_amdgcn_mov_dpp(__double2loint(*p[u]), 0x39, 0xf, 0xf, true);
+                int hi = __builtin_amdgcn_mov_dpp(__double2hiint(*p[u]), 0x39, 0xf, 0xf, true);
+                *p[u] = __hiloint2double(hi, lo);
+            }
+        } else if (MODE == 4) {   // fma -> dpp -> fma -> dpp dependent (4 fma + 8 dpp movs)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x0 = x0 * a + b;
+                int lo = __builtin_amdgcn_mov_dpp(__double2loint(x0), 0x39, 0xf, 0xf, true);
+                int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x0), 0x39, 0xf, 0xf, true);
+                x0 = __hiloint2double(hi, lo);
+            }
+        } else if (MODE == 5) {   // 8 dependent mul_f64
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x0 = x0 * a;
+        } else if (MODE == 6) {   // 8 dependent add_f64
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x0 = x0 + a;
+        }
+    }
+    const unsigned long long t1 = clock64();
+    out[blockIdx.x * 64 + threadIdx.x] = x0 + x1 + x2 + x3 + y0 + y1 + y2 + y3;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE> void run(const char *name, int per_iter)
+{
+    double *out; unsigned long long *cyc, h[4];
+    hipMalloc(&out, 4 * 64 * 8); hipMalloc(&cyc, 4 * 8);
+    hipLaunchKernelGGL(k<MODE>, dim3(4), dim3(64), 0, 0, out, cyc, 1.0000001, 1e-9);
+    hipLaunchKernelGGL(k<MODE>, dim3(4), dim3(64), 0, 0, out, cyc, 1.0000001, 1e-9);
+    hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost);
+    printf("%-52s %7.2f clock64 ticks per instruction\n", name, (double)h[0] / (N * per_iter));
+    hipFree(out); hipFree(cyc);
+}
+
+int main()
+{
+    run<0>("v_fma_f64, dependent chain", 8);
+    run<1>("v_fma_f64, 8 independent chains", 8);
+    run<5>("v_mul_f64, dependent chain", 8);
+    run<6>("v_add_f64, dependent chain", 8);
+    run<2>("v_mov_b32_dpp quad_perm, dependent (per mov)", 16);
+    run<3>("v_mov_b32_dpp quad_perm, independent (per mov)", 16);
+    run<4>("fma -> dpp(lo,hi) -> fma ... (per instruction)", 12);
+    return 0;
+}
