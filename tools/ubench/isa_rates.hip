@@ -5,8 +5,11 @@
 #include <cstdio>
 
 #define N 256
-template <int MODE> __global__ void k(double *out, unsigned long long *cyc, double a, double b)
+template <int MODE> __global__ void k(double *out, unsigned long long *cyc, double a_, double b_)
 {
+    // per-lane operands: with wave-uniform (SGPR) operands a VOP3 instruction may need extra
+    // moves (one constant-bus read per instruction on gfx9) and the count is off
+    const double a = a_ + 1e-13 * threadIdx.x, b = b_ + 1e-13 * threadIdx.x;
     double x0 = a + threadIdx.x, x1 = b + threadIdx.x, x2 = a * 2 + threadIdx.x, x3 = b * 3 + threadIdx.x;
     double y0 = x0 + 1, y1 = x1 + 1, y2 = x2 + 1, y3 = x3 + 1;
     const unsigned long long t0 = clock64();
@@ -65,8 +68,25 @@ template <int MODE> void run(const char *name, int per_iter)
     hipFree(out); hipFree(cyc);
 }
 
+__global__ void kcal(unsigned long long *o)
+{
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    double x = threadIdx.x;
+    for (int i = 0; i < 200000; ++i) x = x * 1.0000001 + 1e-9;
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { o[0] = c1 - c0; o[1] = w1 - w0; o[2] = (unsigned long long)x; }
+}
+
 int main()
 {
+    {   // clock64 ticks per second, from the constant 100 MHz wall clock
+        unsigned long long *d, h[3];
+        (void)hipMalloc(&d, 24);
+        hipLaunchKernelGGL(kcal, dim3(1), dim3(64), 0, 0, d);
+        (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        printf("clock64: %.1f MHz (%llu ticks in %llu wall ticks of 10 ns); the 200000 dependent v_fma_f64 took %.2f ticks each\n",
+               (double)h[0] / ((double)h[1] * 1e-8) / 1e6, h[0], h[1], (double)h[0] / 200000.0);
+    }
     run<0>("v_fma_f64, dependent chain", 8);
     run<1>("v_fma_f64, 8 independent chains", 8);
     run<5>("v_mul_f64, dependent chain", 8);
