@@ -248,8 +248,6 @@ template <int R, class T> __device__ __forceinline__ T quad_rot(T x)
     return dpp_move<R == 1 ? 0x39 : (R == 2 ? 0x4E : 0x93)>(x);   // quad_perm [1,2,3,0] / [2,3,0,1] / [3,0,1,2]
 }
 // Lane j's share of one block record (all loads unconditional, addresses per lane).
-// rec: record of the block's factors; pvj / pv4: this lane's vec slot j and slot 4 (they
-// belong to another record than rec for the mirrored blocks of the bottom half, stencil.h).
 // The row of T_k is kept in ROTATED order, t[r] = T_k(j, (j + r) & 3): the quad all-gathers a
 // 4-vector with three cyclic shifts (12 DPP moves) instead of four broadcasts (16), lane j
 // then holds entry (j + r) & 3 in its r-th register.
@@ -267,22 +265,6 @@ template <class T> struct QuadRow {
         bD = lf[4 + max(j, 1) - 1];
         b04 = lf[3];
         d4 = lf[7];
-    }
-    __device__ __forceinline__ void load(const T *fac, const double *lfac, size_t rec, const T *pvj, const T *pv4,
-                                         int j)
-    {
-        const T *f = fac + rec * 15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = (j + r) & 3;
-            const int idx = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
-            t[r] = f[idx];
-        }
-        t[4] = f[10 + j];
-        t44 = f[14];
-        v = *pvj;
-        v4 = *pv4;
-        load_b(lfac, rec, j);
     }
     template <class A> __device__ __forceinline__ void load(const A &a, int k)
     {
@@ -342,17 +324,6 @@ template <class T> struct VecRef {
         return VecRef{vec, nlines, 0, 5, vec, nlines, 0};
     }
 };
-// vec slots of lane j / slot 4 for block k: a mirrored block (HALF = 1) keeps its entries
-// 1..4 in record k-1
-template <int HALF, class T> __device__ __forceinline__ T *slot_j(const VecRef<T> &V, int k, int line, int j)
-{
-    return V.p((HALF && j > 0) ? k - 1 : k, line, j);
-}
-template <int HALF, class T> __device__ __forceinline__ T *slot_4(const VecRef<T> &V, int k, int line)
-{
-    return V.p4(HALF ? k - 1 : k, line);
-}
-
 // Addresses of one lane inside the half-chain loops, split into a per-block part that is
 // uniform over the wave (block index x row size: scalar registers, scalar multiplies) and a
 // loop-invariant, non-negative 32-bit per-lane part. Without the split every load of every
