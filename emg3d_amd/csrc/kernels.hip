@@ -123,8 +123,9 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
         emg::PointIn<T> in;
         int ix, iy, iz;
         const bool ok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, (colours >> (2 * cc)) & 3, t, ix, iy, iz);
-        emg::point_load<T, ST>(L, pst, ix, iy, iz, in);
-        if (ok) emg::point_update<T, E>(L, in, E(lds, x0, y0, z0), ix, iy, iz);
+        const E ed(lds, x0, y0, z0);
+        emg::point_load<T, ST>(L, pst, emg::ZetaTile<E>{ed}, ix, iy, iz, in);
+        if (ok) emg::point_update<T, E>(L, in, ed, ix, iy, iz);
         lds_barrier();
     }
     emg::tile_store<T, TB>(L, lds, x0, y0, z0, t);
@@ -835,7 +836,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
         if (lr == 0 && tiled) {
             using TB = emg::PointTile;
             using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
-            const size_t smem = sizeof(T) * E::LDS_ELEMS;
+            const size_t smem = E::LDS_BYTES;
             static bool attr_set = false;
             if (!attr_set) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, true>),

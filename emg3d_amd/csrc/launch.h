@@ -171,6 +171,23 @@ EMG_HD void tile_load(const Level<T> &L, T *lds, int x0, int y0, int z0, int t)
         const int e = t + it * TB::THREADS;
         lds[e < E::NZE ? E::NXE + E::NYE + e : E::ELEMS] = vz[it];
     }
+    // zeta of the cells around the tile's nodes (each is used by up to eight node updates)
+    constexpr int TC = (E::NZC + TB::THREADS - 1) / TB::THREADS;
+    double vc[TC];
+#pragma unroll
+    for (int it = 0; it < TC; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int li = e % (TB::BX + 1), r = e / (TB::BX + 1), lj = r % (TB::BY + 1), lk = r / (TB::BY + 1);
+        const int i = ox + li, j = oy + lj, k = oz + lk;
+        const bool ok = e < E::NZC && i < L.nx && j < L.ny && k < L.nz;
+        vc[it] = L.zeta[ok ? i + L.nx * (j + L.ny * k) : 0];
+    }
+    double *const zb = reinterpret_cast<double *>(lds + E::LDS_ELEMS);
+#pragma unroll
+    for (int it = 0; it < TC; ++it) {
+        const int e = t + it * TB::THREADS;
+        zb[e < E::NZC ? e : E::NZC] = vc[it];
+    }
 }
 // Phase 2 (once per node colour): the node of colour class `colour` that thread t owns;
 // false if it lies outside the level (partial tile) -- the coordinates are then clamped to
@@ -192,7 +209,12 @@ EMG_HD void tile_colour(const Level<T> &L, const T *pst, T *lds, int x0, int y0,
     int ix, iy, iz;
     if (!tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, colour, t, ix, iy, iz)) return;
     using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
-    gs_point_node<T, E>(L, pst, E(lds, x0, y0, z0), ix, iy, iz);
+    const E ed(lds, x0, y0, z0);
+    const ZetaTile<E> zt{ed};
+    PointIn<T> in;
+    if (pst) point_load<T, true>(L, pst, zt, ix, iy, iz, in);
+    else point_load<T, false>(L, pst, zt, ix, iy, iz, in);
+    point_update<T, E>(L, in, ed, ix, iy, iz);
 }
 // Phase 3: write the edges attached to the tile's nodes back (the halo is read-only).
 template <class T, class TB>

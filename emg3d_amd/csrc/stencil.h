@@ -265,6 +265,15 @@ template <class T, int BX, int BY, int BZ> struct EdgesTile {
     static constexpr int NZE = (BX + 2) * (BY + 2) * (BZ + 1);
     static constexpr int ELEMS = NXE + NYE + NZE;
     static constexpr int LDS_ELEMS = ELEMS + 1;   // + one slot that absorbs out-of-range copies
+    // zeta of the (BX+1)(BY+1)(BZ+1) cells around the tile's nodes, as doubles behind the edges
+    static constexpr int NZC = (BX + 1) * (BY + 1) * (BZ + 1);
+    static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * sizeof(T) + (size_t)(NZC + 1) * sizeof(double);
+    EMG_HD double *zbox() const { return reinterpret_cast<double *>(lds + LDS_ELEMS); }
+    // cell (i,j,k), i in [x0-1, x0+BX-1] etc.  (ox = x0-1 is also the first cell)
+    EMG_HD double &zc(int i, int j, int k) const
+    {
+        return zbox()[(i - ox) + (BX + 1) * ((j - oy) + (BY + 1) * (k - oz))];
+    }
     T *lds;
     int ox, oy, oz;
     EMG_HD EdgesTile(T *l, int x0, int y0, int z0) : lds(l), ox(x0 - 1), oy(y0 - 1), oz(z0 - 1) {}
@@ -292,15 +301,26 @@ template <class T> struct PointIn {
     T s[6];
 };
 
-template <class T, bool ST>
-EMG_HD void point_load(const Level<T> &L, const T *pst, int ix, int iy, int iz, PointIn<T> &in)
+// zeta straight from the level's array ...
+template <class T> struct ZetaGlobal {
+    const Level<T> &L;
+    EMG_HD double operator()(int i, int j, int k) const { return L.zeta[i + L.nx * (j + L.ny * k)]; }
+};
+// ... or from the tile's LDS copy (EdgesTile::zc)
+template <class E> struct ZetaTile {
+    const E &ed;
+    EMG_HD double operator()(int i, int j, int k) const { return ed.zc(i, j, k); }
+};
+
+template <class T, bool ST, class Z>
+EMG_HD void point_load(const Level<T> &L, const T *pst, const Z &zeta, int ix, int iy, int iz, PointIn<T> &in)
 {
     const Axes<T, 0> A(L);
     const int ixm = ix - 1, iym = iy - 1, izm = iz - 1;
-    in.z[0] = L.zeta[A.icc(ixm, iym, izm)]; in.z[1] = L.zeta[A.icc(ix, iym, izm)];
-    in.z[2] = L.zeta[A.icc(ixm, iy, izm)];  in.z[3] = L.zeta[A.icc(ix, iy, izm)];
-    in.z[4] = L.zeta[A.icc(ixm, iym, iz)];  in.z[5] = L.zeta[A.icc(ix, iym, iz)];
-    in.z[6] = L.zeta[A.icc(ixm, iy, iz)];   in.z[7] = L.zeta[A.icc(ix, iy, iz)];
+    in.z[0] = zeta(ixm, iym, izm); in.z[1] = zeta(ix, iym, izm);
+    in.z[2] = zeta(ixm, iy, izm);  in.z[3] = zeta(ix, iy, izm);
+    in.z[4] = zeta(ixm, iym, iz);  in.z[5] = zeta(ix, iym, iz);
+    in.z[6] = zeta(ixm, iy, iz);   in.z[7] = zeta(ix, iy, iz);
     const int e0 = A.iex(ixm, iy, iz), e1 = A.iex(ix, iy, iz), e2 = A.iey(ix, iym, iz), e3 = A.iey(ix, iy, iz);
     const int e4 = A.iez(ix, iy, izm), e5 = A.iez(ix, iy, iz);
     in.s[0] = L.sx[e0]; in.s[1] = L.sx[e1]; in.s[2] = L.sy[e2]; in.s[3] = L.sy[e3];
@@ -467,8 +487,9 @@ template <class T, class E>
 EMG_HD void gs_point_node(const Level<T> &L, const T *pst, const E &ed, int ix, int iy, int iz)
 {
     PointIn<T> in;
-    if (pst) point_load<T, true>(L, pst, ix, iy, iz, in);
-    else point_load<T, false>(L, pst, ix, iy, iz, in);
+    const ZetaGlobal<T> zg{L};
+    if (pst) point_load<T, true>(L, pst, zg, ix, iy, iz, in);
+    else point_load<T, false>(L, pst, zg, ix, iy, iz, in);
     point_update<T, E>(L, in, ed, ix, iy, iz);
 }
 template <class T> EMG_HD void gs_point_node(const Level<T> &L, const T *pst, int ix, int iy, int iz)

@@ -34,7 +34,7 @@ template <class T> void gs_point_tiled(const emg::Level<T> &L, const T *pst, int
 {
     using TB = emg::PointTile;
     using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
-    std::vector<T> lds(E::LDS_ELEMS);
+    std::vector<T> lds(E::LDS_BYTES / sizeof(T) + 1);
     const int colours = emg::sweep_colours_packed(iback);
     for (int t8 = 0; t8 < 8; ++t8) {
         const int tc = emg::tile_colour_at(iback, t8);
