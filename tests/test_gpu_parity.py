@@ -9,6 +9,8 @@
 
 Nothing here reads /root/reference; the oracle (oracle/) is used only as the checker.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -21,6 +23,8 @@ from oracle import mg_ref
 from helpers import relerr, widths
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SMOOTHERS = ('gauss_seidel', 'gauss_seidel_x', 'gauss_seidel_y', 'gauss_seidel_z')
 
@@ -665,6 +669,34 @@ def test_parallel_compute_concurrent_solves_per_gpu():
         assert seq[k][1]['exit'] == 0 and con[k][1]['exit'] == 0
         assert con[k][1]['it_mg'] == seq[k][1]['it_mg']
         assert np.array_equal(con[k][0].field, seq[k][0].field), k
+
+
+def test_rccl_single_rank_model_broadcast():
+    """The collectives of the multi-GPU job (RCCL through torch.distributed 'nccl') on the
+    one GPU of this box: a world of one rank runs init, the model broadcast of
+    parallel.broadcast_model's tensor path, all-reduce and barrier. The sharding logic itself
+    is covered with two gloo processes in tests/test_parallel_gloo.py."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, torch, numpy as np\n"
+        "import torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from emg3d_amd import parallel\n"
+        "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "t = torch.arange(1000, dtype=torch.float64)\n"
+        "t = parallel._bcast_tensor(t, 0, dev)\n"
+        "assert t.is_cuda and float(t.sum()) == 499500.0\n"
+        "m = torch.tensor([3.0, 4.0], dtype=torch.float64, device=dev)\n"
+        "dist.all_reduce(m, op=dist.ReduceOp.MAX); dist.barrier(); torch.cuda.synchronize()\n"
+        "assert m.tolist() == [3.0, 4.0]\n"
+        "assert parallel.gather_objects({'a': 1}) == [{'a': 1}]\n"
+        "parallel.finalize(); print('rccl ok')\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize('seed', range(12))
