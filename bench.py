@@ -383,6 +383,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='marine128')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--opt', action='append', default=[],
+                    help='library tuning option name=value (emg3d_set_option), for experiments')
     ap.add_argument('--no-256', action='store_true',
                     help="skip the separate 256^3 smoother measurement ('smoothers_256')")
     args = ap.parse_args()
@@ -391,6 +393,12 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node "
                          f"{args.gpus} bench.py --gpus {args.gpus}")
+    if args.opt:
+        from emg3d_amd import _lib
+        for o in args.opt:
+            k, v = o.split('=')
+            if _lib.lib().emg3d_set_option(k.encode(), int(v)) != 0:
+                raise SystemExit(f"unknown option {o}")
     out, wl = run_gpu(args, rank, world)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

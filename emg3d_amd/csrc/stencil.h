@@ -220,14 +220,14 @@ template <class T> EMG_HD void solve6(const T (&dg)[6], const double (&od)[6][6]
             T t = T(od[i][j]);
 #pragma unroll
             for (int k = 0; k < j; ++k)
-                if (pt_nz(i, k) && pt_nz(j, k)) t -= u[k] * Lm[j][k];
+                if (pt_nz(i, k) && pt_nz(j, k)) t = nmad(u[k], Lm[j][k], t);
             u[j] = t;
             Lm[i][j] = t * dinv[j];
         }
         T d = dg[i];
 #pragma unroll
         for (int k = 0; k < i; ++k)
-            if (pt_nz(i, k)) d -= u[k] * Lm[i][k];
+            if (pt_nz(i, k)) d = nmad(u[k], Lm[i][k], d);
         dinv[i] = recip(d);
     }
     // forward substitution, diagonal scaling, backward substitution (core.py:1597-1616)
@@ -235,7 +235,7 @@ template <class T> EMG_HD void solve6(const T (&dg)[6], const double (&od)[6][6]
     for (int i = 1; i < 6; ++i) {
 #pragma unroll
         for (int k = 0; k < i; ++k)
-            if (pt_nz(i, k)) b[i] -= Lm[i][k] * b[k];
+            if (pt_nz(i, k)) b[i] = nmad(Lm[i][k], b[k], b[i]);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] *= dinv[i];
@@ -243,7 +243,7 @@ template <class T> EMG_HD void solve6(const T (&dg)[6], const double (&od)[6][6]
     for (int j = 4; j >= 0; --j) {
 #pragma unroll
         for (int k = j + 1; k < 6; ++k)
-            if (pt_nz(k, j)) b[j] -= Lm[k][j] * b[k];
+            if (pt_nz(k, j)) b[j] = nmad(Lm[k][j], b[k], b[j]);
     }
 }
 
@@ -312,15 +312,20 @@ template <class E> struct ZetaTile {
     EMG_HD double operator()(int i, int j, int k) const { return ed.zc(i, j, k); }
 };
 
-template <class T, bool ST, class Z>
-EMG_HD void point_load(const Level<T> &L, const T *pst, const Z &zeta, int ix, int iy, int iz, PointIn<T> &in)
+template <class T, class Z> EMG_HD void point_load_zeta(const Z &zeta, int ix, int iy, int iz, PointIn<T> &in)
 {
-    const Axes<T, 0> A(L);
     const int ixm = ix - 1, iym = iy - 1, izm = iz - 1;
     in.z[0] = zeta(ixm, iym, izm); in.z[1] = zeta(ix, iym, izm);
     in.z[2] = zeta(ixm, iy, izm);  in.z[3] = zeta(ix, iy, izm);
     in.z[4] = zeta(ixm, iym, iz);  in.z[5] = zeta(ix, iym, iz);
     in.z[6] = zeta(ixm, iy, iz);   in.z[7] = zeta(ix, iy, iz);
+}
+// source and eta sums of the node's six edges (everything of PointIn that is not zeta)
+template <class T, bool ST>
+EMG_HD void point_load_model(const Level<T> &L, const T *pst, int ix, int iy, int iz, PointIn<T> &in)
+{
+    const Axes<T, 0> A(L);
+    const int ixm = ix - 1, iym = iy - 1, izm = iz - 1;
     const int e0 = A.iex(ixm, iy, iz), e1 = A.iex(ix, iy, iz), e2 = A.iey(ix, iym, iz), e3 = A.iey(ix, iy, iz);
     const int e4 = A.iez(ix, iy, izm), e5 = A.iez(ix, iy, iz);
     in.s[0] = L.sx[e0]; in.s[1] = L.sx[e1]; in.s[2] = L.sy[e2]; in.s[3] = L.sy[e3];
@@ -346,6 +351,12 @@ EMG_HD void point_load(const Level<T> &L, const T *pst, const Z &zeta, int ix, i
                    ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ixm, iym, iz);
 #undef ETv
     }
+}
+template <class T, bool ST, class Z>
+EMG_HD void point_load(const Level<T> &L, const T *pst, const Z &zeta, int ix, int iy, int iz, PointIn<T> &in)
+{
+    point_load_zeta<T>(zeta, ix, iy, iz, in);
+    point_load_model<T, ST>(L, pst, ix, iy, iz, in);
 }
 
 // Eta edge sums of the three "lower" edges of extended cell (ix,iy,iz) (the ones attached

@@ -80,7 +80,8 @@ int emg3d_device_count(void);
  * when they fit, 0 always uses the global scratch. "line_lpw": lines per workgroup of a fused
  * line launch (4, 8, 16; 0 = automatic). "line_fuse":
  * 0 three launches per colour and line direction (rhs, forward, backward), 1 one fused
- * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines. */
+ * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines (default:
+ * no limit -- the fused launch is the faster one at every size measured). */
 int emg3d_set_option(const char *name, int value);
 int emg3d_get_option(const char *name);
 

@@ -75,8 +75,12 @@ def main():
     ap.add_argument('--slabs', default='0,2,4,8,16,32')
     ap.add_argument('--nu', type=int, default=2)
     ap.add_argument('--shape', default='', help='nx,ny,nz instead of n^3')
+    ap.add_argument('--opt', action='append', default=[], help='library option name=value (repeatable)')
     args = ap.parse_args()
     lib = _lib.lib()
+    for o in args.opt:
+        k, v = o.split('=')
+        assert lib.emg3d_set_option(k.encode(), int(v)) == 0, o
     shape = tuple(int(x) for x in args.shape.split(',')) if args.shape else None
     lv, grid = make_level(args.n, args.case, shape=shape)
     nc = grid.n_cells
@@ -86,7 +90,7 @@ def main():
         med, mn = timeit(lambda: lv.smooth(0, args.nu))
         report("gauss_seidel (point) tiled", med, nc, args.nu, args.case)
         lib.emg3d_set_option(b'point_tile_min', 0)
-        for slab in [int(x) for x in args.slabs.split(',')]:
+        for slab in [int(x) for x in args.slabs.split(',') if x != '']:
             lib.emg3d_set_option(b'point_slab', slab)
             med, mn = timeit(lambda: lv.smooth(0, args.nu))
             report(f"gauss_seidel (point) slab={slab}", med, nc, args.nu, args.case)
