@@ -103,6 +103,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
 
     if efield is None:
         efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
+        efield._is_zero = True
         var.do_return = True
     else:
         if sfield.field.dtype != efield.field.dtype:
@@ -230,10 +231,18 @@ class Hierarchy:
 
     def upload(self, sfield, efield):
         self.top.s.copy_(torch.from_numpy(np.ascontiguousarray(sfield.field)), non_blocking=False)
-        self.top.e.copy_(torch.from_numpy(np.ascontiguousarray(efield.field)), non_blocking=False)
+        if getattr(efield, '_is_zero', False):
+            self.top.e.zero_()           # the start field solve() made itself: nothing to send
+        else:
+            self.top.e.copy_(torch.from_numpy(np.ascontiguousarray(efield.field)), non_blocking=False)
 
     def download(self, efield):
-        efield.field[:] = self.top.e.cpu().numpy()
+        efield._is_zero = False
+        out = efield.field
+        if out.flags.c_contiguous and out.flags.writeable:
+            torch.from_numpy(out).copy_(self.top.e)     # one pass, straight into the field's buffer
+        else:
+            out[:] = self.top.e.cpu().numpy()
 
 
 def multigrid(model, sfield, efield, var, **kwargs):
@@ -448,7 +457,10 @@ def _bicgstab_device(hier, sfield, efield, var):
     dev = hier.device
     dtype = top.dtype
     b = torch.from_numpy(np.ascontiguousarray(sfield.field)).to(dev)
-    x = torch.from_numpy(np.ascontiguousarray(efield.field)).to(dev)
+    if getattr(efield, '_is_zero', False):
+        x = torch.zeros_like(b)
+    else:
+        x = torch.from_numpy(np.ascontiguousarray(efield.field)).to(dev)
     new = lambda: torch.empty_like(b)   # noqa: E731
 
     def norm(t):
@@ -517,7 +529,12 @@ def _bicgstab_device(hier, sfield, efield, var):
             r.sub_(t, alpha=omega)
             rho_prev = rho
             _krylov_callback(var, true_residual_norm())
-        efield.field[:] = x.cpu().numpy()
+        efield._is_zero = False
+        out = efield.field
+        if out.flags.c_contiguous and out.flags.writeable:
+            torch.from_numpy(out).copy_(x)
+        else:
+            out[:] = x.cpu().numpy()
     except _ConvergenceError:
         code = -1
         efield.field[:] = 0
