@@ -165,7 +165,13 @@ def _segment_to_edges(grid, p0, p1, out):
             t = (nodes[a] - p0[a]) / d[a]
             cuts.extend(t[(t > 0.0) & (t < 1.0)].tolist())
     cuts = np.unique(np.round(np.array(cuts), 14))
-    fx, fy, fz = out.fx, out.fy, out.fz
+    nx, ny, nz = grid.shape_cells
+    oy = nx * (ny + 1) * (nz + 1)
+    oz = oy + (nx + 1) * ny * (nz + 1)
+
+    def add(index, value):                  # `out`: flat edge index -> moment, in order of arrival
+        out[index] = out.get(index, 0.0) + value
+
     for t0, t1 in zip(cuts[:-1], cuts[1:]):
         if t1 - t0 <= 0:
             continue
@@ -178,21 +184,24 @@ def _segment_to_edges(grid, p0, p1, out):
             idx.append(i)
             r.append((mid[a] - nodes[a][i]) / grid.h[a][i])
         (ix, iy, iz), (rx, ry, rz) = idx, r
-        if piece[0] != 0.0:
-            fx[ix, iy, iz] += piece[0] * (1 - ry) * (1 - rz)
-            fx[ix, iy + 1, iz] += piece[0] * ry * (1 - rz)
-            fx[ix, iy, iz + 1] += piece[0] * (1 - ry) * rz
-            fx[ix, iy + 1, iz + 1] += piece[0] * ry * rz
-        if piece[1] != 0.0:
-            fy[ix, iy, iz] += piece[1] * (1 - rx) * (1 - rz)
-            fy[ix + 1, iy, iz] += piece[1] * rx * (1 - rz)
-            fy[ix, iy, iz + 1] += piece[1] * (1 - rx) * rz
-            fy[ix + 1, iy, iz + 1] += piece[1] * rx * rz
-        if piece[2] != 0.0:
-            fz[ix, iy, iz] += piece[2] * (1 - rx) * (1 - ry)
-            fz[ix + 1, iy, iz] += piece[2] * rx * (1 - ry)
-            fz[ix, iy + 1, iz] += piece[2] * (1 - rx) * ry
-            fz[ix + 1, iy + 1, iz] += piece[2] * rx * ry
+        if piece[0] != 0.0:                 # fx[i, j, k] -> i + nx (j + (ny + 1) k)
+            ex = lambda i, j, k: i + nx * (j + (ny + 1) * k)               # noqa: E731
+            add(ex(ix, iy, iz), piece[0] * (1 - ry) * (1 - rz))
+            add(ex(ix, iy + 1, iz), piece[0] * ry * (1 - rz))
+            add(ex(ix, iy, iz + 1), piece[0] * (1 - ry) * rz)
+            add(ex(ix, iy + 1, iz + 1), piece[0] * ry * rz)
+        if piece[1] != 0.0:                 # fy[i, j, k] -> oy + i + (nx + 1) (j + ny k)
+            ey = lambda i, j, k: oy + i + (nx + 1) * (j + ny * k)          # noqa: E731
+            add(ey(ix, iy, iz), piece[1] * (1 - rx) * (1 - rz))
+            add(ey(ix + 1, iy, iz), piece[1] * rx * (1 - rz))
+            add(ey(ix, iy, iz + 1), piece[1] * (1 - rx) * rz)
+            add(ey(ix + 1, iy, iz + 1), piece[1] * rx * rz)
+        if piece[2] != 0.0:                 # fz[i, j, k] -> oz + i + (nx + 1) (j + (ny + 1) k)
+            ez = lambda i, j, k: oz + i + (nx + 1) * (j + (ny + 1) * k)    # noqa: E731
+            add(ez(ix, iy, iz), piece[2] * (1 - rx) * (1 - ry))
+            add(ez(ix + 1, iy, iz), piece[2] * rx * (1 - ry))
+            add(ez(ix, iy + 1, iz), piece[2] * (1 - rx) * ry)
+            add(ez(ix + 1, iy + 1, iz), piece[2] * rx * ry)
 
 
 def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs):
@@ -228,14 +237,20 @@ def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs
     if np.any(pts < lo - 1e-9) or np.any(pts > hi + 1e-9):
         raise ValueError(f"Provided source outside grid: {pts}.")
 
-    vec = Field(grid, dtype=np.float64)
+    moments = {}
     for p0, p1 in zip(pts[:-1], pts[1:]):
         if np.linalg.norm(p1 - p0) < 1e-15:
             raise ValueError(f"Provided finite dipole has no length: {pts}.")
-        _segment_to_edges(grid, p0, p1, vec)
+        _segment_to_edges(grid, p0, p1, moments)
 
-    sfield = Field(grid, data=vec.field, frequency=frequency)   # casts to the field dtype
-    sfield._field = sfield._field * strength
+    # A source touches a handful of edges: the scaling is done on those, and the field
+    # (100 MB for 128^3) is written once -- zero pages of a fresh allocation stay untouched.
+    sfield = Field(grid, frequency=frequency, dtype=None if frequency is not None else np.float64)
+    index = np.fromiter(moments.keys(), dtype=np.int64, count=len(moments))
+    values = np.fromiter(moments.values(), dtype=np.float64, count=len(moments)).astype(sfield._field.dtype)
+    values = values * strength
     if frequency is not None:
-        sfield._field = sfield._field * -sfield.smu0
+        values = values * -sfield.smu0
+    sfield._field[index] = values
+    sfield._sparse = (index, values)     # valid only while the field is not modified (parallel.solve)
     return sfield

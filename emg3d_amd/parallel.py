@@ -133,7 +133,7 @@ def solve(inp):
     ``_multiprocessing.solve`` (emg3d/_multiprocessing.py:72-153). ``inp`` has the keys
     [model, sfield, efield, solver_opts] or [model, grid, source, frequency, efield,
     solver_opts]; always returns (efield, info_dict)."""
-    from emg3d_amd import fields, solver
+    from emg3d_amd import fields, models, solver
     opts = dict(inp['solver_opts'])
     if 'sfield' in inp:
         sfield = inp['sfield']
@@ -141,7 +141,20 @@ def solve(inp):
     else:
         grid = inp['grid']
         sfield = fields.get_source_field(grid, inp['source'], inp['frequency'])
+        opts['_sparse_source'] = True     # made here, not modified: its few non-zeros go up, not 100 MB
     model = inp['model'].interpolate_to_grid(grid)
+    cache = inp.get('hierarchies')
+    if cache is not None:
+        # pairs of one worker that share model, grid and frequency share the device-resident
+        # levels, line factorisations and graphs (not in the reference: its workers are
+        # separate processes that rebuild everything per pair)
+        key = (id(inp['model']), id(grid), complex(sfield.sval))
+        hier = cache.get(key)
+        if hier is None:
+            while len(cache) >= 2:            # bounded: a hierarchy is ~1.3 kB per cell
+                cache.pop(next(iter(cache)))
+            hier = cache[key] = solver.Hierarchy(models.VolumeModel(model, sfield))
+        opts['hierarchy'] = hier
     return solver.solve(model=model, sfield=sfield, efield=inp.get('efield'),
                         return_info=True, always_return=True, **opts)
 
@@ -157,13 +170,16 @@ def gather_objects(obj, dst=0):
 
 
 def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, solve_fn=None,
-            keep_fields=True, per_gpu=1):
+            keep_fields=True, per_gpu=1, reuse=True):
     """Solve all source-frequency pairs, sharded over the ranks of the process group.
 
     model: on rank 0 (None elsewhere is fine; it is broadcast). sources: dict name ->
     source coordinates; frequencies: dict name -> Hz. Returns, on every rank, a dict
     {(src, freq): (efield or None, info)} for the pairs THIS rank computed; rank 0
     additionally gets key '_all_info': {(src, freq): info} gathered from all ranks.
+
+    reuse: pairs of one worker with the same frequency share one device-resident level
+    hierarchy (model, coarse levels, line factorisations, graphs); results are bit-identical.
 
     per_gpu > 1: the rank works on that many of its pairs at a time, each in its own host
     thread on its own HIP stream (the max_workers of the reference's process pool, but
@@ -175,12 +191,19 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
     pairs = srcfreq_pairs(sources, frequencies)
     mine = shard(len(pairs), rank, world, costs)
     solve_fn = solve_fn or solve
+    if reuse:       # pairs of one frequency next to each other
+        forder = {f: n for n, f in enumerate(frequencies)}
+        mine = sorted(mine, key=lambda i: (forder[pairs[i][1]], i))
     out = {}
 
-    def job(i, stream=None):
+    the_grid = grid or model.grid
+
+    def job(i, stream=None, hierarchies=None):
         s, f = pairs[i]
-        inp = {'model': model, 'grid': grid or model.grid, 'source': sources[s],
+        inp = {'model': model, 'grid': the_grid, 'source': sources[s],
                'frequency': frequencies[f], 'efield': None, 'solver_opts': solver_opts or {}}
+        if hierarchies is not None and solve_fn is solve:
+            inp['hierarchies'] = hierarchies
         if stream is None:
             efield, info = solve_fn(inp)
         else:
@@ -191,9 +214,11 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
         return (s, f), (efield if keep_fields else None, info)
 
     if per_gpu <= 1 or len(mine) <= 1:
+        hierarchies = {} if reuse else None
         for i in mine:
-            k, v = job(i)
+            k, v = job(i, None, hierarchies)
             out[k] = v
+        del hierarchies
     else:
         import queue
         import threading
@@ -204,6 +229,7 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
 
         def worker():
             stream = None
+            hierarchies = {} if reuse else None      # per thread: a hierarchy serves one solve at a time
             if device.type == 'cuda':
                 import torch
                 torch.cuda.set_device(device)
@@ -214,7 +240,7 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                 except queue.Empty:
                     return
                 try:
-                    k, v = job(i, stream)
+                    k, v = job(i, stream, hierarchies)
                     out[k] = v
                 except BaseException as exc:      # surfaced after the join
                     errors.append(exc)

@@ -73,6 +73,10 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     ``maxit=50``, ``nu_init=0``, ``nu_pre=2``, ``nu_coarse=1``, ``nu_post=2``,
     ``clevel=-1``, ``return_info=False``, ``log=1``, ``plain=False``.
 
+    Not in the reference: ``hierarchy=`` (a ``Hierarchy`` built for the same model, grid and
+    frequency) reuses the device-resident levels, line factorisations and captured graphs of
+    an earlier solve -- what several sources at one frequency share.
+
     Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``).
     """
     always_return = kwargs.pop('always_return', False)
@@ -81,6 +85,8 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
         semicoarsening = False if semicoarsening is True else semicoarsening
         linerelaxation = False if linerelaxation is True else linerelaxation
     efield = kwargs.pop('efield', None)
+    hierarchy = kwargs.pop('hierarchy', None)
+    sparse_source = bool(kwargs.pop('_sparse_source', False)) and getattr(sfield, '_sparse', None) is not None
 
     var = MGParameters(sslsolver=sslsolver, semicoarsening=semicoarsening,
                        linerelaxation=linerelaxation, shape_cells=model.shape, verb=verb,
@@ -89,7 +95,8 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     var.cprint(f"\n:: emg3d START :: {var.time.now} :: emg3d_amd (MI355X)\n", 2)
     var.cprint(var, 2)
 
-    var.l2_refe = _host_norm(sfield.field)
+    var.sparse_source = sparse_source
+    var.l2_refe = _host_norm(sfield._sparse[1] if sparse_source else sfield.field)
     var.error_at_cycle[0] = var.l2_refe
 
     if sfield.frequency is None:
@@ -147,10 +154,12 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     elif var.cycle:
         var.cprint(header + f"{'[abs. error, last/prev]':>29}   l s\n", 3)
 
+    if hierarchy is not None:
+        hierarchy.check(vmodel)
     if var.sslsolver:
-        krylov(vmodel, sfield, efield, var)
+        krylov(vmodel, sfield, efield, var, hierarchy=hierarchy)
     elif var.cycle:
-        multigrid(vmodel, sfield, efield, var)
+        multigrid(vmodel, sfield, efield, var, hierarchy=hierarchy)
 
     exit_status = int(var.exit_message != 'CONVERGED')
 
@@ -228,9 +237,30 @@ class Hierarchy:
     def __init__(self, vmodel, device=None):
         self.device = device or _device()
         self.top = DeviceLevel.from_host(vmodel, self.device)
+        self.shape = tuple(vmodel.grid.shape_cells)
+        self.sval = complex(vmodel._sval)
 
-    def upload(self, sfield, efield):
-        self.top.s.copy_(torch.from_numpy(np.ascontiguousarray(sfield.field)), non_blocking=False)
+    def check(self, vmodel):
+        """A hierarchy handed to ``solve`` must belong to the same grid shape and frequency
+        (that the model is the same is the caller's responsibility)."""
+        if tuple(vmodel.grid.shape_cells) != self.shape or complex(vmodel._sval) != self.sval:
+            raise ValueError("hierarchy: built for another grid shape or frequency")
+
+    def put_source(self, sfield, out, sparse=False):
+        """Source field -> device tensor `out`. sparse: trust the (index, value) list that
+        ``get_source_field`` left on the field (valid while nobody modified the field: only
+        ``parallel.solve``, which makes the field itself, asks for it) -- a dipole touches a
+        handful of edges, the dense field is 100 MB at 128^3."""
+        sp = getattr(sfield, '_sparse', None) if sparse else None
+        if sp is None:
+            out.copy_(torch.from_numpy(np.ascontiguousarray(sfield.field)), non_blocking=False)
+        else:
+            out.zero_()
+            if sp[0].size:
+                out[self.top.work.upload(sp[0])] = self.top.work.upload(sp[1])
+
+    def upload(self, sfield, efield, sparse=False):
+        self.put_source(sfield, self.top.s, sparse)
         if getattr(efield, '_is_zero', False):
             self.top.e.zero_()           # the start field solve() made itself: nothing to send
         else:
@@ -253,7 +283,7 @@ def multigrid(model, sfield, efield, var, **kwargs):
     duration of the call; pass ``hierarchy=`` (a ``Hierarchy``) to reuse one.
     """
     hier = kwargs.get('hierarchy') or Hierarchy(model)
-    hier.upload(sfield, efield)
+    hier.upload(sfield, efield, getattr(var, 'sparse_source', False))
     try:
         _multigrid(hier.top, var, 0, 0)
     finally:
@@ -404,7 +434,7 @@ def _multigrid(lv, var, level, new_cycmax):
 
 
 # ----------------------------------------------------------------------------- krylov ---
-def krylov(model, sfield, efield, var):
+def krylov(model, sfield, efield, var, hierarchy=None):
     """Krylov subspace solver with multigrid preconditioner (emg3d/solver.py:652-784).
 
     ``bicgstab`` (the default of ``solve``) runs entirely on the device: vectors stay in
@@ -413,7 +443,7 @@ def krylov(model, sfield, efield, var):
     PCIe. ``cgs`` and ``gcrotmk`` use SciPy on the host, as the reference does, with device
     operator / preconditioner applications (vectors cross PCIe per call).
     """
-    hier = Hierarchy(model)
+    hier = hierarchy or Hierarchy(model)
     if var.sslsolver == 'bicgstab':
         i = _bicgstab_device(hier, sfield, efield, var)
     else:
@@ -456,7 +486,8 @@ def _bicgstab_device(hier, sfield, efield, var):
     top = hier.top
     dev = hier.device
     dtype = top.dtype
-    b = torch.from_numpy(np.ascontiguousarray(sfield.field)).to(dev)
+    b = torch.empty(top.e.numel(), dtype=top.e.dtype, device=dev)
+    hier.put_source(sfield, b, getattr(var, 'sparse_source', False))
     if getattr(efield, '_is_zero', False):
         x = torch.zeros_like(b)
     else:

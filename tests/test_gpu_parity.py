@@ -661,14 +661,38 @@ def test_parallel_compute_concurrent_solves_per_gpu():
     sources = {f'S{i}': (-40. + 30. * i, 0., 10., 0., 0.) for i in range(4)}
     freqs = {'f1': 1.0, 'f2': 3.0}
     opts = {'sslsolver': False, 'tol': 1e-8, 'verb': 0}
-    seq = parallel.compute(model, grid, sources, freqs, opts)
+    seq = parallel.compute(model, grid, sources, freqs, opts, reuse=False)
     con = parallel.compute(model, grid, sources, freqs, opts, per_gpu=3)
+    reu = parallel.compute(model, grid, sources, freqs, opts)      # shared hierarchies per frequency
     keys = sorted(k for k in seq if k != '_all_info')
     assert sorted(k for k in con if k != '_all_info') == keys and len(keys) == 8
     for k in keys:
         assert seq[k][1]['exit'] == 0 and con[k][1]['exit'] == 0
-        assert con[k][1]['it_mg'] == seq[k][1]['it_mg']
+        assert con[k][1]['it_mg'] == seq[k][1]['it_mg'] == reu[k][1]['it_mg']
         assert np.array_equal(con[k][0].field, seq[k][0].field), k
+        assert np.array_equal(reu[k][0].field, seq[k][0].field), k
+
+
+def test_solve_with_reused_hierarchy():
+    """solve(hierarchy=...): several sources at one frequency on one set of device-resident
+    levels / line factors / graphs -- same fields as separate solves, default BiCGSTAB and plain
+    multigrid; a hierarchy of another frequency is refused."""
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx, hx[:12]], (-hx.sum() / 2, -hx.sum() / 2, -300.))
+    rng = np.random.default_rng(11)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells),
+                        property_z=10 ** rng.uniform(0, 0.5, grid.shape_cells))
+    sfields = [emg3d.get_source_field(grid, (x, 5., -100., 10., 5.), 0.7) for x in (-60., 0., 45.)]
+    hier = solver.Hierarchy(emg3d.models.VolumeModel(model, sfields[0]))
+    for kw in (dict(sslsolver=False), dict()):
+        for sf in sfields:
+            e1, i1 = emg3d.solve(model, sf, return_info=True, tol=1e-9, **kw)
+            e2, i2 = emg3d.solve(model, sf, return_info=True, tol=1e-9, hierarchy=hier, **kw)
+            assert i1['exit'] == 0 and i1['it_mg'] == i2['it_mg'] and i1['it_ssl'] == i2['it_ssl']
+            assert np.array_equal(e1.field, e2.field)
+    other = emg3d.get_source_field(grid, (0., 0., -100., 0., 0.), 2.0)
+    with pytest.raises(ValueError, match='hierarchy'):
+        emg3d.solve(model, other, hierarchy=hier)
 
 
 def test_rccl_single_rank_model_broadcast():
