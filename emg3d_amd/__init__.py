@@ -18,12 +18,12 @@ Surveys, simulations, gridding, I/O, CLI and inversion of the reference are out 
 device entry points raise.
 """
 from emg3d_amd import core, fields, meshes, models, solver
-from emg3d_amd.fields import Field, get_source_field
+from emg3d_amd.fields import Field, get_source_field, get_magnetic_field, get_receiver
 from emg3d_amd.meshes import TensorMesh
 from emg3d_amd.models import Model
 from emg3d_amd.solver import solve, solve_source
 
 __all__ = ['core', 'fields', 'meshes', 'models', 'solver', 'Field', 'Model', 'TensorMesh',
-           'get_source_field', 'solve', 'solve_source']
+           'get_source_field', 'get_magnetic_field', 'get_receiver', 'solve', 'solve_source']
 
 __version__ = '0.1.0'

@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIBDIR = os.path.join(_HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libemg3d_amd.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'emg3d_amd.h')
-SOURCES = [os.path.join(CSRC, f) for f in ('kernels.hip', 'stencil.h', 'launch.h', 'cplx.h')] + [HEADER]
+SOURCES = [os.path.join(CSRC, f) for f in ('kernels.hip', 'stencil.h', 'launch.h', 'cplx.h', 'receivers.h')] + [HEADER]
 
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
 
@@ -73,6 +73,10 @@ SIGNATURES = {
     'emg3d_dev_prolong': (_ci, [_vp] * 12 + [_ci] * 5 + [_vp]),
     'emg3d_dev_restrict_param': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'emg3d_dev_pec_zero': (_ci, [_vp] * 3 + [_ci] * 4 + [_vp]),
+    'emg3d_dev_magnetic_field': (_ci, [_ci] * 4 + [_vp] * 7 + [ctypes.c_double] * 2 + [_vp] * 4),
+    'emg3d_dev_spline_filter': (_ci, [_vp] + [_ci] * 4 + [_vp]),
+    'emg3d_dev_spline_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _ci, _vp, _vp]),
+    'emg3d_dev_linear_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _vp, _ci, _vp, _vp]),
 }
 
 _lib = None

@@ -1310,3 +1310,5 @@ int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex)
 }
 
 }  // extern "C"
+
+#include "receivers.h"

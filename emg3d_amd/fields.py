@@ -15,7 +15,7 @@ import numpy as np
 
 from emg3d_amd import meshes
 
-__all__ = ['Field', 'get_source_field', 'MU_0', 'EPSILON_0']
+__all__ = ['Field', 'get_source_field', 'get_magnetic_field', 'get_receiver', 'MU_0', 'EPSILON_0']
 
 # scipy 1.15.3 CODATA-2022 values (the reference takes them from scipy.constants;
 # SURVEY.md section 0 item 8). Hard-coded so that results do not move with scipy.
@@ -27,8 +27,6 @@ class Field:
     """A 3-D electric field on the edges of a tensor mesh."""
 
     def __init__(self, grid, data=None, frequency=None, dtype=None, electric=True):
-        if not electric:
-            raise NotImplementedError("emg3d_amd: only electric (edge) fields are supported.")
         if frequency is not None:
             if frequency > 0:
                 dtype = np.complex128
@@ -45,40 +43,47 @@ class Field:
 
         self.grid = grid
         self._frequency = frequency
-        self.electric = True
+        self.electric = bool(electric)
+        # electric fields live on the edges, magnetic fields on the faces (emg3d/fields.py:88-119)
+        if self.electric:
+            self._shapes = (grid.shape_edges_x, grid.shape_edges_y, grid.shape_edges_z)
+        else:
+            self._shapes = (grid.shape_faces_x, grid.shape_faces_y, grid.shape_faces_z)
+        self._sizes = tuple(int(np.prod(sh)) for sh in self._shapes)
+        n = sum(self._sizes)
         if data is None:
-            self._field = np.zeros(grid.n_edges, dtype=dtype)
+            self._field = np.zeros(n, dtype=dtype)
         else:
             self._field = np.asarray(data, dtype=dtype)
-            if self._field.shape != (grid.n_edges,):
-                raise ValueError(f"Field data must have shape ({grid.n_edges},); "
+            if self._field.shape != (n,):
+                raise ValueError(f"Field data must have shape ({n},); "
                                  f"provided: {self._field.shape}.")
         self._sval = None
         self._smu0 = None
 
     def __repr__(self):
-        return (f"{self.__class__.__name__}: electric; {self.grid.shape_cells[0]} x "
+        return (f"{self.__class__.__name__}: {['magnetic', 'electric'][self.electric]}; {self.grid.shape_cells[0]} x "
                 f"{self.grid.shape_cells[1]} x {self.grid.shape_cells[2]}; "
                 f"{self.field.size:,}")
 
     def __eq__(self, field):
         """Same comparison as the reference (rtol 1e-10, emg3d/fields.py:128-136)."""
         equal = isinstance(field, Field) and self.grid == field.grid
-        equal = equal and self._frequency == field._frequency
+        equal = equal and self._frequency == field._frequency and self.electric == field.electric
         return bool(equal and np.allclose(self._field, field._field, atol=0, rtol=1e-10))
 
     def copy(self):
-        return Field(self.grid, self._field.copy(), frequency=self._frequency)
+        return Field(self.grid, self._field.copy(), frequency=self._frequency, electric=self.electric)
 
     def to_dict(self, copy=False):
         return {'__class__': 'Field', 'grid': self.grid.to_dict(copy),
                 'data': self._field.copy() if copy else self._field,
-                'frequency': self._frequency, 'electric': True}
+                'frequency': self._frequency, 'electric': self.electric}
 
     @classmethod
     def from_dict(cls, inp):
         return cls(meshes.TensorMesh.from_dict(inp['grid']), inp['data'],
-                   frequency=inp.get('frequency'))
+                   frequency=inp.get('frequency'), electric=inp.get('electric', True))
 
     # -- buffer and views --------------------------------------------------------------
     @property
@@ -90,35 +95,44 @@ class Field:
     def field(self, value):
         self._field[:] = value
 
+    def _component(self, c):
+        i0 = sum(self._sizes[:c])
+        return self._field[i0:i0 + self._sizes[c]].reshape(self._shapes[c], order='F')
+
+    def _set_component(self, c, value):
+        i0 = sum(self._sizes[:c])
+        self._field[i0:i0 + self._sizes[c]] = np.asarray(value).ravel('F')
+
     @property
     def fx(self):
-        """x-directed field, shape (nx, ny+1, nz+1), Fortran-ordered view."""
-        return self._field[:self.grid.n_edges_x].reshape(self.grid.shape_edges_x, order='F')
+        """x-directed field, Fortran-ordered view: (nx, ny+1, nz+1) on edges, (nx+1, ny, nz) on faces."""
+        return self._component(0)
 
     @fx.setter
     def fx(self, value):
-        self._field[:self.grid.n_edges_x] = np.asarray(value).ravel('F')
+        self._set_component(0, value)
 
     @property
     def fy(self):
-        """y-directed field, shape (nx+1, ny, nz+1), Fortran-ordered view."""
-        i0 = self.grid.n_edges_x
-        return self._field[i0:i0 + self.grid.n_edges_y].reshape(self.grid.shape_edges_y, order='F')
+        """y-directed field, Fortran-ordered view: (nx+1, ny, nz+1) on edges, (nx, ny+1, nz) on faces."""
+        return self._component(1)
 
     @fy.setter
     def fy(self, value):
-        i0 = self.grid.n_edges_x
-        self._field[i0:i0 + self.grid.n_edges_y] = np.asarray(value).ravel('F')
+        self._set_component(1, value)
 
     @property
     def fz(self):
-        """z-directed field, shape (nx+1, ny+1, nz), Fortran-ordered view."""
-        i0 = self.grid.n_edges_x + self.grid.n_edges_y
-        return self._field[i0:].reshape(self.grid.shape_edges_z, order='F')
+        """z-directed field, Fortran-ordered view: (nx+1, ny+1, nz) on edges, (nx, ny, nz+1) on faces."""
+        return self._component(2)
 
     @fz.setter
     def fz(self, value):
-        self._field[self.grid.n_edges_x + self.grid.n_edges_y:] = np.asarray(value).ravel('F')
+        self._set_component(2, value)
+
+    def get_receiver(self, receiver, method='cubic'):
+        """Field at receiver positions (``get_receiver``)."""
+        return get_receiver(self, receiver, method)
 
     # -- frequency ---------------------------------------------------------------------
     @property
@@ -254,3 +268,133 @@ def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs
     sfield._field[index] = values
     sfield._sparse = (index, values)     # valid only while the field is not modified (parallel.solve)
     return sfield
+
+
+# ---------------------------------------------------------------------------------------
+# After a solve: magnetic field and receiver responses, computed
+# on the device. The reference does both on the host with NumPy / SciPy.
+def _device_tools():
+    import torch
+    from emg3d_amd import _lib
+    from emg3d_amd._device import _ptr, _stream
+    _lib.require_gpu()
+    return torch, _lib, _ptr, _stream, torch.device('cuda', torch.cuda.current_device())
+
+
+def get_magnetic_field(model, efield):
+    r"""Magnetic field H on the faces from the electric field on the edges with Faraday's law,
+    :math:`\nabla \times \mathbf{E} = \rm{i}\omega\mu\mathbf{H}`; same call and result as the
+    reference's ``emg3d.get_magnetic_field`` (emg3d/fields.py:617-659, kernel
+    ``_edge_curl_factor`` :941-1009), computed by ``emg3d_dev_magnetic_field``."""
+    torch, _lib, _ptr, _stream, dev = _device_tools()
+    grid = efield.grid
+    nx, ny, nz = grid.shape_cells
+    hfield = Field(grid, frequency=efield._frequency, dtype=efield.field.dtype, electric=False)
+    mu_r = getattr(model, 'mu_r', None)
+    vol = grid.cell_volumes
+    zeta = vol if mu_r is None else vol / np.asarray(mu_r, dtype=float).ravel('F')     # models.py:688-691
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                   # noqa: E731
+    e = up(efield.field)
+    m = torch.empty(hfield.field.size, dtype=e.dtype, device=dev)
+    z, hx, hy, hz = up(np.asarray(zeta, dtype=np.float64)), up(grid.h[0]), up(grid.h[1]), up(grid.h[2])
+    eo = np.cumsum([0] + list(efield._sizes))          # element offsets of the components
+    mo = np.cumsum([0] + list(hfield._sizes))
+    smu0 = complex(efield.smu0)
+    _lib.check(_lib.lib().emg3d_dev_magnetic_field(
+        nx, ny, nz, int(e.is_complex()), _ptr(e, int(eo[0])), _ptr(e, int(eo[1])), _ptr(e, int(eo[2])),
+        _ptr(z), _ptr(hx), _ptr(hy), _ptr(hz), smu0.real, smu0.imag,
+        _ptr(m, int(mo[0])), _ptr(m, int(mo[1])), _ptr(m, int(mo[2])), _stream()), 'emg3d_dev_magnetic_field')
+    torch.from_numpy(hfield.field).copy_(m)
+    return hfield
+
+
+def _rotation(azimuth, elevation):
+    """Direction cosines of (azimuth, elevation) in degrees (emg3d/electrodes.py:825-872)."""
+    from scipy.special import cosdg, sindg
+    return np.array([cosdg(azimuth) * cosdg(elevation), sindg(azimuth) * cosdg(elevation),
+                     sindg(elevation)])
+
+
+def _component_points(grid, shape):
+    """Coordinates of the values of one field component per dimension (emg3d/maps.py:439-459):
+    as many as nodes -> the nodes, as many as cells -> the cell centres."""
+    pts = []
+    for d, c in enumerate('xyz'):
+        on_nodes = shape[d] == grid.shape_nodes[d]
+        pts.append(getattr(grid, ('nodes_' if on_nodes else 'cell_centers_') + c))
+    return pts
+
+
+def get_receiver(field, receiver, method='cubic'):
+    """Field (response) at receiver coordinates; same call and result as the reference's
+    ``emg3d.fields.get_receiver`` (emg3d/fields.py:522-614): ``receiver`` is an object with
+    ``.coordinates``, a list of such, or a tuple ``(x, y, z, azimuth, elevation)``; ``method``
+    'cubic' (cubic B-spline in index space, the reference's ``maps.interp_spline_3d``) or
+    'linear'. Receivers outside the grid or in its outermost cells give NaN.
+
+    The interpolation runs on the device: the spline prefilter of a component is three passes
+    of a recursive filter over the whole array -- ~0.2 s per 128^3 component with
+    ``scipy.ndimage`` on the host, well under a millisecond here."""
+    if hasattr(receiver, 'coordinates'):
+        coordinates = receiver.coordinates
+    elif hasattr(tuple(receiver)[0], 'coordinates'):
+        coordinates = tuple(np.array([r.coordinates for r in receiver], dtype=float).T)
+    else:
+        coordinates = receiver
+        if len(coordinates) != 5:
+            raise ValueError("`receiver` needs to be in the form (x, y, z, azimuth, elevation). "
+                             f"Length of provided `receiver`: {len(coordinates)}.")
+    if method not in ('cubic', 'linear'):
+        raise ValueError(f"Method {method!r} is not defined; 'cubic' or 'linear'.")
+    torch, _lib, _ptr, _stream, dev = _device_tools()
+    grid = field.grid
+    x, y, z = np.broadcast_arrays(*[np.asarray(c, dtype=float) for c in coordinates[:3]])
+    shape = x.shape
+    xi = np.stack([x.ravel('F'), y.ravel('F'), z.ravel('F')], axis=1)
+    npts = xi.shape[0]
+    factors = _rotation(np.asarray(coordinates[3], dtype=float), np.asarray(coordinates[4], dtype=float))
+    factors = [np.broadcast_to(f, shape).ravel('F') for f in factors]
+    resp = np.zeros(npts, dtype=field.field.dtype)
+    is_complex = int(np.iscomplexobj(resp))
+    lib = _lib.lib()
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                   # noqa: E731
+    for c in range(3):
+        if not np.any(abs(factors[c]) > 1e-10):
+            continue
+        values = field._component(c)
+        n0, n1, n2 = values.shape
+        pts = _component_points(grid, values.shape)
+        dvals = up(values.ravel('F'))
+        out = torch.empty(npts, dtype=dvals.dtype, device=dev)
+        if method == 'cubic':
+            from scipy.interpolate import interp1d
+            coords = np.empty((3, npts))
+            for d in range(3):          # metres -> index space, as maps.interp_spline_3d (maps.py:545-550)
+                coords[d] = interp1d(pts[d], np.arange(len(pts[d])), kind='cubic', bounds_error=False,
+                                     fill_value='extrapolate')(xi[:, d])
+            dcoords = up(coords)
+            _lib.check(lib.emg3d_dev_spline_filter(_ptr(dvals), n0, n1, n2, is_complex, _stream()),
+                       'emg3d_dev_spline_filter')
+            _lib.check(lib.emg3d_dev_spline_eval(_ptr(dvals), n0, n1, n2, is_complex, _ptr(dcoords), npts,
+                                                 _ptr(out), _stream()), 'emg3d_dev_spline_eval')
+        else:
+            idx = np.empty((3, npts), dtype=np.int32)
+            w = np.empty((3, npts))
+            for d in range(3):          # scipy RegularGridInterpolator._find_indices
+                g = pts[d]
+                i = np.searchsorted(g, xi[:, d]) - 1
+                i[i < 0] = 0
+                i[i > g.size - 2] = g.size - 2
+                w[d] = (xi[:, d] - g[i]) / (g[i + 1] - g[i])
+                inside = (xi[:, d] >= g[0]) & (xi[:, d] <= g[-1])
+                idx[d] = np.where(inside, i, -1)
+            didx, dw = up(idx), up(w)
+            _lib.check(lib.emg3d_dev_linear_eval(_ptr(dvals), n0, n1, n2, is_complex, _ptr(didx), _ptr(dw),
+                                                 npts, _ptr(out), _stream()), 'emg3d_dev_linear_eval')
+        resp += factors[c] * out.cpu().numpy()
+    # PEC: receivers in the outermost cells are set to NaN (fields.py:604-610)
+    ind = ((xi[:, 0] < grid.nodes_x[1]) | (xi[:, 0] > grid.nodes_x[-2]) |
+           (xi[:, 1] < grid.nodes_y[1]) | (xi[:, 1] > grid.nodes_y[-2]) |
+           (xi[:, 2] < grid.nodes_z[1]) | (xi[:, 2] > grid.nodes_z[-2]))
+    resp[ind] = np.nan
+    return resp.reshape(shape, order='F')

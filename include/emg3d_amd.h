@@ -180,6 +180,33 @@ int emg3d_dev_restrict_param(void *out, const void *in, int nx, int ny, int nz, 
 int emg3d_dev_pec_zero(void *ex, void *ey, void *ez, int nx, int ny, int nz, int is_complex,
                        void *stream);
 
+/* ---- after a solve: magnetic field and receiver responses ------------
+ * fields.get_magnetic_field / _edge_curl_factor (emg3d/fields.py:617-659, 941-1009):
+ * m = curl(e) * (zeta / (s mu0)) averaged over the two cells of a face, on the faces
+ * mx (nx+1,ny,nz), my (nx,ny+1,nz), mz (nx,ny,nz+1); boundary faces stay 0. zeta = V / mu_r
+ * (nx,ny,nz) doubles, hx/hy/hz cell widths -- all device pointers; s mu0 = smu0_re + i smu0_im
+ * (real fields: smu0_im ignored). */
+int emg3d_dev_magnetic_field(int nx, int ny, int nz, int is_complex, const void *ex, const void *ey,
+                             const void *ez, const double *zeta, const double *hx, const double *hy,
+                             const double *hz, double smu0_re, double smu0_im, void *mx, void *my,
+                             void *mz, void *stream);
+
+/* fields.get_receiver -> maps.interpolate (emg3d/fields.py:522-614, emg3d/maps.py:232-368).
+ * method 'cubic' = maps.interp_spline_3d (maps.py:500-552) = scipy.ndimage.map_coordinates(
+ * order=3, mode='constant', cval=nan): emg3d_dev_spline_filter turns the n0 x n1 x n2 array
+ * (x fastest) IN PLACE into cubic B-spline coefficients (scipy.ndimage.spline_filter, mirror);
+ * emg3d_dev_spline_eval evaluates them at npts index-space coordinates coords[0..npts) = x,
+ * [npts..2npts) = y, [2npts..3npts) = z (the host maps metres to index space with the same 1-D
+ * cubic interpolant as the reference); points outside [0, n-1] give NaN. */
+int emg3d_dev_spline_filter(void *data, int n0, int n1, int n2, int is_complex, void *stream);
+int emg3d_dev_spline_eval(const void *coef, int n0, int n1, int n2, int is_complex,
+                          const double *coords, int npts, void *out, void *stream);
+/* method 'linear' = scipy RegularGridInterpolator(fill_value=nan): idx (3 x npts, int32) is the
+ * lower corner of the cell holding each point (any entry < 0: outside, NaN), w (3 x npts) the
+ * weights of the upper corner. */
+int emg3d_dev_linear_eval(const void *values, int n0, int n1, int n2, int is_complex,
+                          const int32_t *idx, const double *w, int npts, void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,3 +30,8 @@ def golden_solves():
 @pytest.fixture(scope='session')
 def golden_regression():
     return np.load(os.path.join(GOLDEN, 'regression_small.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_receivers():
+    return np.load(os.path.join(GOLDEN, 'receivers.npz'), allow_pickle=False)

@@ -759,3 +759,64 @@ def test_randomised_smoother_parity(seed):
         getattr(core, fn)(b.fx, b.fy, b.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
                           vm.zeta, *grid.h, nu)
         assert relerr(b.field, a.field) < 1e-10, (shape, case, freq, nu, fn)
+
+
+def test_magnetic_field_and_receivers_vs_reference_vectors(golden_receivers):
+    """SURVEY.md 8f rank 2 on the device: get_magnetic_field (emg3d/fields.py:617-659) and
+    get_receiver (emg3d/fields.py:522-614; cubic and linear) against the reference's outputs
+    for random fields: electric and magnetic, frequency and Laplace domain; receivers on
+    nodes, inside, in the outermost cells (NaN) and outside (NaN)."""
+    g = golden_receivers
+    grid = emg3d.TensorMesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    model = emg3d.Model(grid, property_x=g['property_x'], mu_r=g['mu_r'])
+    rec = (g['rec_x'], g['rec_y'], g['rec_z'], g['rec_azimuth'], g['rec_elevation'])
+    for tag in ('f', 's'):
+        efield = emg3d.Field(grid, data=g[tag + '_efield'], frequency=float(g[tag + '_frequency']))
+        hfield = emg3d.get_magnetic_field(model, efield)
+        assert not hfield.electric and hfield.fx.shape == grid.shape_faces_x
+        assert hfield.field.dtype == g[tag + '_hfield'].dtype
+        assert relerr(hfield.field, g[tag + '_hfield']) < 1e-13
+        assert np.all(hfield.fx[0] == 0) and np.all(hfield.fz[:, :, -1] == 0)      # boundary faces
+        for kind, fld in (('e', efield), ('h', hfield)):
+            for method in ('cubic', 'linear'):
+                got = fld.get_receiver(rec, method=method)
+                want = g[f'{tag}_{kind}_{method}']
+                m = np.isnan(want)
+                assert got.shape == want.shape and got.dtype == want.dtype
+                assert np.array_equal(m, np.isnan(got)), (tag, kind, method)
+                assert np.abs(got[~m] - want[~m]).max() <= 1e-11 * np.abs(want[~m]).max(), (tag, kind, method)
+    # scalar coordinates -> 0-d result; bad input
+    one = efield.get_receiver((float(rec[0][8]), float(rec[1][8]), float(rec[2][8]), 0., 0.))
+    assert one.shape == () and np.isfinite(one)
+    with pytest.raises(ValueError, match='receiver'):
+        emg3d.get_receiver(efield, (1., 2., 3.))
+
+
+def test_spline_and_linear_device_kernels_vs_scipy():
+    """The device spline prefilter / evaluation and the trilinear kernel against SciPy itself on a
+    96 x 70 x 50 array (complex and real), coordinates up to and beyond the edges."""
+    import scipy.ndimage as ndi
+    from emg3d_amd._device import _ptr, _stream
+    rng = np.random.default_rng(3)
+    shape = (96, 70, 50)
+    n = 500
+    coords = np.array([rng.uniform(-2, s + 1, n) for s in shape])
+    coords[:, :4] = np.array([[0, 0, 0], [95, 69, 49], [0.01, 68.99, 25], [94.5, 0.5, 48.7]]).T
+    dev = torch.device('cuda')
+    lib = _lib.lib()
+    for dtype in (complex, float):
+        v = rng.standard_normal(shape) + (1j * rng.standard_normal(shape) if dtype is complex else 0)
+        v = np.asfortranarray(v.astype(dtype))
+        ref = ndi.map_coordinates(v, coords, order=3, mode='constant', cval=np.nan)
+        d = torch.from_numpy(v.ravel('F').copy()).to(dev)
+        dc = torch.from_numpy(coords.copy()).to(dev)
+        out = torch.empty(n, dtype=d.dtype, device=dev)
+        _lib.check(lib.emg3d_dev_spline_filter(_ptr(d), *shape, int(dtype is complex), _stream()))
+        coef = ndi.spline_filter(v.real, order=3, mode='constant')
+        got_coef = d.cpu().numpy().reshape(shape, order='F')
+        assert np.abs(got_coef.real - coef).max() < 1e-12
+        _lib.check(lib.emg3d_dev_spline_eval(_ptr(d), *shape, int(dtype is complex), _ptr(dc), n, _ptr(out), _stream()))
+        got = out.cpu().numpy()
+        m = np.isnan(ref)
+        assert np.array_equal(m, np.isnan(got)) and 0 < m.sum() < n
+        assert np.abs(got[~m] - ref[~m]).max() < 1e-12

@@ -205,3 +205,77 @@ def test_solver_vs_reference_regression_file(golden_regression):
     e, info = mg_ref.solve(vm, s, semicoarsening=123, linerelaxation=456, tol=1e-4, maxit=4,
                            nu_init=2, nu_pre=2, nu_coarse=1, nu_post=2, clevel=10)
     assert relerr(e.field, g['reg2_result']) < 1e-8
+
+
+def test_spline_restatement_vs_scipy():
+    """oracle/interp_ref.py (cubic B-spline prefilter + evaluation, trilinear) against SciPy
+    itself -- the algorithm of the reference's 'cubic' / 'linear' receiver interpolation lives
+    in scipy.ndimage / scipy.interpolate (emg3d/maps.py:500-552, 359-361)."""
+    import scipy.ndimage as ndi
+    import scipy.interpolate as si
+    from oracle import interp_ref as R
+    rng = np.random.default_rng(0)
+    for shape in [(7, 5, 9), (4, 12, 6), (2, 3, 4)]:
+        v = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+        n = 40
+        coords = np.array([rng.uniform(-1, s, n) for s in shape])
+        coords[:, 0] = 0
+        coords[:, 1] = [s - 1 for s in shape]
+        coords[:, 2] = [s - 1.2 for s in shape]
+        ref = ndi.map_coordinates(v, coords, order=3, mode='constant', cval=np.nan)
+        got = R.map_coordinates_cubic(v, coords)
+        m = np.isnan(ref)
+        assert np.array_equal(m, np.isnan(got)) and 0 < m.sum() < n
+        assert np.abs(ref[~m] - got[~m]).max() < 1e-13
+        assert np.abs(ndi.spline_filter(v.real, order=3, mode='constant') - R.spline_filter(v.real)).max() < 1e-12
+        pts = [np.sort(rng.uniform(0, 100, s)) for s in shape]
+        xi = np.array([rng.uniform(p[0] - 5, p[-1] + 5, n) for p in pts]).T
+        ref = si.RegularGridInterpolator(pts, v, method='linear', bounds_error=False, fill_value=np.nan)(xi)
+        got = R.interp_linear(pts, v, xi)
+        m = np.isnan(ref)
+        assert np.array_equal(m, np.isnan(got))
+        assert np.abs(ref[~m] - got[~m]).max() < 1e-13
+
+
+def test_receiver_restatement_vs_reference_vectors(golden_receivers):
+    """The same restatement, driven like fields.get_receiver (emg3d/fields.py:522-614), against
+    the reference's own outputs in tests/golden/receivers.npz (electric and magnetic field,
+    frequency and Laplace domain, cubic and linear, NaN outside / in the outermost cells)."""
+    from scipy.interpolate import interp1d
+    from scipy.special import cosdg, sindg
+    from oracle import interp_ref as R
+    g = golden_receivers
+    grid = mg_ref.Grid([g['hx'], g['hy'], g['hz']], g['origin'])
+    nx, ny, nz = grid.shape_cells
+    nodes = [np.r_[0., np.cumsum(h)] + o for h, o in zip((g['hx'], g['hy'], g['hz']), g['origin'])]
+    cc = [0.5 * (n[1:] + n[:-1]) for n in nodes]
+    xi = np.stack([g['rec_x'], g['rec_y'], g['rec_z']], axis=1)
+    az, el = g['rec_azimuth'], g['rec_elevation']
+    fac = [cosdg(az) * cosdg(el), sindg(az) * cosdg(el), sindg(el)]
+    shapes = {'e': [(nx, ny + 1, nz + 1), (nx + 1, ny, nz + 1), (nx + 1, ny + 1, nz)],
+              'h': [(nx + 1, ny, nz), (nx, ny + 1, nz), (nx, ny, nz + 1)]}
+    for tag in ('f', 's'):
+        for kind in ('e', 'h'):
+            data = g[f'{tag}_{kind}field']
+            comps, i0 = [], 0
+            for sh in shapes[kind]:
+                comps.append(data[i0:i0 + int(np.prod(sh))].reshape(sh, order='F'))
+                i0 += int(np.prod(sh))
+            for method in ('cubic', 'linear'):
+                resp = np.zeros(xi.shape[0], dtype=data.dtype)
+                for c, v in enumerate(comps):
+                    pts = [nodes[d] if v.shape[d] == len(nodes[d]) else cc[d] for d in range(3)]
+                    if method == 'cubic':
+                        coords = np.array([interp1d(pts[d], np.arange(len(pts[d])), kind='cubic', bounds_error=False,
+                                                    fill_value='extrapolate')(xi[:, d]) for d in range(3)])
+                        resp = resp + fac[c] * R.map_coordinates_cubic(v, coords)
+                    else:
+                        resp = resp + fac[c] * R.interp_linear(pts, v, xi)
+                ind = np.zeros(xi.shape[0], dtype=bool)
+                for d in range(3):
+                    ind |= (xi[:, d] < nodes[d][1]) | (xi[:, d] > nodes[d][-2])
+                resp[ind] = np.nan
+                want = g[f'{tag}_{kind}_{method}']
+                m = np.isnan(want)
+                assert np.array_equal(m, np.isnan(resp)) and 0 < m.sum() < m.size
+                assert np.abs(resp[~m] - want[~m]).max() <= 1e-11 * np.abs(want[~m]).max(), (tag, kind, method)

@@ -14,6 +14,8 @@ Fixtures written (each ≤ 1.5 MB):
                                         and of the solver.py wrappers on small grids
     tests/golden/solves.npz             converged reference solves (tol 1e-10) incl.
                                         per-cycle error history
+    tests/golden/receivers.npz          magnetic field and receiver responses (cubic / linear)
+                                        of the reference for random fields
 Metadata (scipy version, mu_0, seeds) is stored in every file.
 """
 import os
@@ -286,9 +288,60 @@ def solves():
     print('solves.npz written')
 
 
+def receivers():
+    """Magnetic field and receiver responses: inputs and the outputs of
+    the reference's fields.get_magnetic_field / fields.get_receiver (cubic and linear), for a
+    frequency-domain and a Laplace-domain field, receivers inside, in the outermost cell and
+    outside of the grid."""
+    rng = np.random.default_rng(2209)
+    out = dict(META)
+    out['meta_seed'] = 2209
+    hx, hy, hz = widths(6, 3, 50., 1.3), widths(4, 3, 60., 1.2), widths(4, 2, 40., 1.25)
+    origin = (-hx.sum() / 2, -hy.sum() / 2 + 13., -hz.sum() + 200.)
+    grid = emg3d.TensorMesh([hx, hy, hz], origin)
+    shp = grid.shape_cells
+    model = emg3d.Model(grid, property_x=rng.uniform(0.5, 2, shp), mu_r=rng.uniform(0.8, 1.5, shp))
+    out.update(hx=hx, hy=hy, hz=hz, origin=np.array(origin), mu_r=model.mu_r, property_x=model.property_x)
+    n = 14
+    x = rng.uniform(grid.nodes_x[2], grid.nodes_x[-3], n)
+    y = rng.uniform(grid.nodes_y[2], grid.nodes_y[-3], n)
+    z = rng.uniform(grid.nodes_z[2], grid.nodes_z[-3], n)
+    # special places: exactly on a node / centre, in the outermost cells, outside the grid
+    x[0], y[0], z[0] = grid.nodes_x[5], grid.nodes_y[4], grid.nodes_z[3]
+    x[1], y[1], z[1] = grid.cell_centers_x[6], grid.cell_centers_y[5], grid.cell_centers_z[4]
+    x[2] = 0.5 * (grid.nodes_x[0] + grid.nodes_x[1])
+    y[3] = 0.5 * (grid.nodes_y[-1] + grid.nodes_y[-2])
+    z[4] = grid.nodes_z[-1] + 10.
+    x[5] = grid.nodes_x[0] - 1.
+    x[6], y[6], z[6] = grid.nodes_x[1] + 1., grid.nodes_y[1] + 1., grid.nodes_z[1] + 1.
+    x[7], y[7], z[7] = grid.nodes_x[-2] - 1., grid.nodes_y[-2] - 1., grid.nodes_z[-2] - 1.
+    az = rng.uniform(-180, 180, n)
+    el = rng.uniform(-90, 90, n)
+    az[8], el[8] = 0., 0.
+    az[9], el[9] = 90., 0.
+    az[10], el[10] = 0., 90.
+    out.update(rec_x=x, rec_y=y, rec_z=z, rec_azimuth=az, rec_elevation=el)
+    for tag, freq, dtype in (('f', 1.2, complex), ('s', -2.0, float)):
+        data = rng.standard_normal(grid.n_edges)
+        if dtype is complex:
+            data = data + 1j * rng.standard_normal(grid.n_edges)
+        efield = emg3d.Field(grid, data=data, frequency=freq)
+        hfield = emg3d.get_magnetic_field(model, efield)
+        out[tag + '_frequency'] = freq
+        out[tag + '_efield'] = efield.field
+        out[tag + '_hfield'] = hfield.field
+        for method in ('cubic', 'linear'):
+            out[f'{tag}_e_{method}'] = np.asarray(efield.get_receiver((x, y, z, az, el), method=method))
+            out[f'{tag}_h_{method}'] = np.asarray(hfield.get_receiver((x, y, z, az, el), method=method))
+    np.savez_compressed(os.path.join(OUT, 'receivers.npz'), **out)
+    print('receivers.npz written')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['regression', 'kernels', 'solves']
+    which = sys.argv[1:] or ['regression', 'kernels', 'solves', 'receivers']
+    if 'receivers' in which:
+        receivers()
     if 'regression' in which:
         regression_small()
     if 'kernels' in which:
