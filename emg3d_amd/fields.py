@@ -325,7 +325,7 @@ def _component_points(grid, shape):
     return pts
 
 
-def get_receiver(field, receiver, method='cubic'):
+def get_receiver(field, receiver, method='cubic', device_field=None):
     """Field (response) at receiver coordinates; same call and result as the reference's
     ``emg3d.fields.get_receiver`` (emg3d/fields.py:522-614): ``receiver`` is an object with
     ``.coordinates``, a list of such, or a tuple ``(x, y, z, azimuth, elevation)``; ``method``
@@ -334,7 +334,11 @@ def get_receiver(field, receiver, method='cubic'):
 
     The interpolation runs on the device: the spline prefilter of a component is three passes
     of a recursive filter over the whole array -- ~0.2 s per 128^3 component with
-    ``scipy.ndimage`` on the host, well under a millisecond here."""
+    ``scipy.ndimage`` on the host, well under a millisecond here.
+
+    Not in the reference: ``device_field`` -- a device tensor ``[fx | fy | fz]`` that holds the
+    values (``field`` then only describes grid, dtype and kind): the field of a solve that is
+    still in HBM (``parallel.compute(receivers=...)``), no 100 MB download."""
     if hasattr(receiver, 'coordinates'):
         coordinates = receiver.coordinates
     elif hasattr(tuple(receiver)[0], 'coordinates'):
@@ -347,6 +351,7 @@ def get_receiver(field, receiver, method='cubic'):
     if method not in ('cubic', 'linear'):
         raise ValueError(f"Method {method!r} is not defined; 'cubic' or 'linear'.")
     torch, _lib, _ptr, _stream, dev = _device_tools()
+    data = field if device_field is None else device_field       # device tensor [fx | fy | fz]
     grid = field.grid
     x, y, z = np.broadcast_arrays(*[np.asarray(c, dtype=float) for c in coordinates[:3]])
     shape = x.shape
@@ -358,13 +363,16 @@ def get_receiver(field, receiver, method='cubic'):
     is_complex = int(np.iscomplexobj(resp))
     lib = _lib.lib()
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)                   # noqa: E731
+    offsets = np.cumsum([0] + list(field._sizes))
     for c in range(3):
         if not np.any(abs(factors[c]) > 1e-10):
             continue
-        values = field._component(c)
-        n0, n1, n2 = values.shape
-        pts = _component_points(grid, values.shape)
-        dvals = up(values.ravel('F'))
+        n0, n1, n2 = field._shapes[c]
+        pts = _component_points(grid, field._shapes[c])
+        if device_field is None:
+            dvals = up(field._component(c).ravel('F'))
+        else:                          # the spline filter works in place: on a copy
+            dvals = data[int(offsets[c]):int(offsets[c + 1])].clone()
         out = torch.empty(npts, dtype=dvals.dtype, device=dev)
         if method == 'cubic':
             from scipy.interpolate import interp1d

@@ -155,8 +155,25 @@ def solve(inp):
                 cache.pop(next(iter(cache)))
             hier = cache[key] = solver.Hierarchy(models.VolumeModel(model, sfield))
         opts['hierarchy'] = hier
-    return solver.solve(model=model, sfield=sfield, efield=inp.get('efield'),
-                        return_info=True, always_return=True, **opts)
+    rec = inp.get('receivers')
+    if rec is None:
+        return solver.solve(model=model, sfield=sfield, efield=inp.get('efield'),
+                            return_info=True, always_return=True, **opts)
+    # responses at the receivers, from the field while it is still in HBM when the solver keeps
+    # it there (multigrid, BiCGSTAB): without `keep_field` nothing but the responses comes back
+    on_device = (opts.get('hierarchy') is not None and inp.get('efield') is None and
+                 opts.get('sslsolver', True) in (True, False, None, 'bicgstab'))
+    if on_device and not inp.get('keep_field', True):
+        opts['_download'] = False
+    efield, info = solver.solve(model=model, sfield=sfield, efield=inp.get('efield'),
+                                return_info=True, always_return=True, **opts)
+    dev_e = opts['hierarchy'].top.e if on_device else None
+    info['responses'] = fields.get_receiver(efield, rec, inp.get('receiver_method', 'cubic'),
+                                            device_field=dev_e)
+    if opts.get('_download') is False:
+        efield = None
+    return efield, info
+
 
 
 def gather_objects(obj, dst=0):
@@ -170,13 +187,18 @@ def gather_objects(obj, dst=0):
 
 
 def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, solve_fn=None,
-            keep_fields=True, per_gpu=1, reuse=True):
+            keep_fields=True, per_gpu=1, reuse=True, receivers=None, receiver_method='cubic'):
     """Solve all source-frequency pairs, sharded over the ranks of the process group.
 
     model: on rank 0 (None elsewhere is fine; it is broadcast). sources: dict name ->
     source coordinates; frequencies: dict name -> Hz. Returns, on every rank, a dict
     {(src, freq): (efield or None, info)} for the pairs THIS rank computed; rank 0
     additionally gets key '_all_info': {(src, freq): info} gathered from all ranks.
+
+    receivers: ``(x, y, z, azimuth, elevation)`` (any form ``fields.get_receiver`` takes), or a
+    dict source name -> such; every pair's ``info['responses']`` then holds the field at the
+    receivers, interpolated on the device from the solution while it is still in HBM. With
+    ``keep_fields=False`` only the responses leave the GPU (no field download).
 
     reuse: pairs of one worker with the same frequency share one device-resident level
     hierarchy (model, coarse levels, line factorisations, graphs); results are bit-identical.
@@ -204,6 +226,10 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                'frequency': frequencies[f], 'efield': None, 'solver_opts': solver_opts or {}}
         if hierarchies is not None and solve_fn is solve:
             inp['hierarchies'] = hierarchies
+        if receivers is not None:
+            inp['receivers'] = receivers[s] if isinstance(receivers, dict) else receivers
+            inp['receiver_method'] = receiver_method
+            inp['keep_field'] = keep_fields
         if stream is None:
             efield, info = solve_fn(inp)
         else:

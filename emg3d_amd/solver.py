@@ -86,6 +86,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
         linerelaxation = False if linerelaxation is True else linerelaxation
     efield = kwargs.pop('efield', None)
     hierarchy = kwargs.pop('hierarchy', None)
+    download = bool(kwargs.pop('_download', True))     # False: the result stays in hierarchy.top.e only
     sparse_source = bool(kwargs.pop('_sparse_source', False)) and getattr(sfield, '_sparse', None) is not None
 
     var = MGParameters(sslsolver=sslsolver, semicoarsening=semicoarsening,
@@ -96,6 +97,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     var.cprint(var, 2)
 
     var.sparse_source = sparse_source
+    var.download = download
     var.l2_refe = _host_norm(sfield._sparse[1] if sparse_source else sfield.field)
     var.error_at_cycle[0] = var.l2_refe
 
@@ -287,7 +289,8 @@ def multigrid(model, sfield, efield, var, **kwargs):
     try:
         _multigrid(hier.top, var, 0, 0)
     finally:
-        hier.download(efield)
+        if getattr(var, 'download', True):
+            hier.download(efield)
 
 
 def _smooth(lv, nu, lr_dir, var):
@@ -562,7 +565,10 @@ def _bicgstab_device(hier, sfield, efield, var):
             _krylov_callback(var, true_residual_norm())
         efield._is_zero = False
         out = efield.field
-        if out.flags.c_contiguous and out.flags.writeable:
+        top.e.copy_(x)          # the hierarchy's field is the solution (not the last preconditioner output)
+        if not getattr(var, 'download', True):
+            pass
+        elif out.flags.c_contiguous and out.flags.writeable:
             torch.from_numpy(out).copy_(x)
         else:
             out[:] = x.cpu().numpy()

@@ -820,3 +820,30 @@ def test_spline_and_linear_device_kernels_vs_scipy():
         m = np.isnan(ref)
         assert np.array_equal(m, np.isnan(got)) and 0 < m.sum() < n
         assert np.abs(got[~m] - ref[~m]).max() < 1e-12
+
+
+def test_parallel_compute_responses_from_device_field():
+    """parallel.compute(receivers=...): responses interpolated from the solution while it is in
+    HBM equal get_receiver() on the downloaded fields; with keep_fields=False no field comes
+    back; multigrid and the default BiCGSTAB."""
+    from emg3d_amd import parallel
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx, hx], (-hx.sum() / 2,) * 3)
+    rng = np.random.default_rng(8)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells))
+    sources = {f'S{i}': (-40. + 30. * i, 0., 10., 0., 0.) for i in range(3)}
+    freqs = {'f1': 1.0}
+    rec = (rng.uniform(-150, 150, 9), rng.uniform(-150, 150, 9), rng.uniform(-100, 100, 9),
+           rng.uniform(-180, 180, 9), rng.uniform(-30, 30, 9))
+    for ssl in (False, True):
+        opts = {'sslsolver': ssl, 'tol': 1e-8, 'verb': 0}
+        full = parallel.compute(model, grid, sources, freqs, opts, receivers=rec)
+        lean = parallel.compute(model, grid, sources, freqs, opts, receivers=rec, keep_fields=False,
+                                receiver_method='linear')
+        for k in [k for k in full if k != '_all_info']:
+            want = full[k][0].get_receiver(rec)
+            assert np.all(np.isfinite(want))
+            assert np.array_equal(full[k][1]['responses'], want)
+            assert lean[k][0] is None
+            assert np.array_equal(lean[k][1]['responses'], full[k][0].get_receiver(rec, method='linear'))
+        assert set(full['_all_info'][('S0', 'f1')]) >= {'responses', 'it_mg'}

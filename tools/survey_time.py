@@ -30,11 +30,16 @@ def main():
     freqs = {'f1': wls[0]['frequency']}
     opts = dict(wls[0]['opts'], sslsolver=False, tol=args.tol, verb=0)
     parallel.compute(model, grid, {'S0': sources['S0']}, freqs, opts)          # warm the process
+    import numpy as np
+    rng = np.random.default_rng(1)
+    rec = (rng.uniform(-2000, 2000, 50), rng.uniform(-500, 500, 50), np.full(50, -990.), 0., 0.)
+    parallel.compute(model, grid, {'S0': sources['S0']}, freqs, opts, receivers=rec)   # imports SciPy's interpolate
     for k in [int(x) for x in args.per_gpu.split(',')]:
-        for reuse in (False, True):
+        for reuse in (False, True, 'responses only'):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = parallel.compute(model, grid, sources, freqs, opts, per_gpu=k, reuse=reuse)
+            kw = dict(receivers=rec, keep_fields=False) if reuse == 'responses only' else {}
+            out = parallel.compute(model, grid, sources, freqs, opts, per_gpu=k, reuse=bool(reuse), **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             its = sorted(v[1]['it_mg'] for kk, v in out.items() if kk != '_all_info')
