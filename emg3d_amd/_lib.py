@@ -77,6 +77,7 @@ SIGNATURES = {
     'emg3d_dev_spline_filter': (_ci, [_vp] + [_ci] * 4 + [_vp]),
     'emg3d_dev_spline_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _ci, _vp, _vp]),
     'emg3d_dev_linear_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _vp, _ci, _vp, _vp]),
+    'emg3d_dev_volume_average': (_ci, [_vp] + [_ci] * 3 + [_vp] * 10 + [_ci] * 3 + [_vp, _vp]),
 }
 
 _lib = None

@@ -12,6 +12,8 @@
 //                    prefiltered coefficients in, one thread per point
 //   k_linear_eval    RegularGridInterpolator(method='linear', fill_value=nan), cell index and
 //                    weights from the host (np.searchsorted), one thread per point
+// and what precedes it when the computational grid differs from the model grid (rank 3):
+//   k_volume_average maps.interp_volume_average (emg3d/maps.py:555-664), one thread per output cell
 #pragma once
 
 namespace {
@@ -159,9 +161,51 @@ __global__ __launch_bounds__(64) void k_linear_eval(const T *v, int n0, int n1, 
     out[p] = acc;
 }
 
+// Model re-gridding by volume averaging (maps.interp_volume_average, emg3d/maps.py:555-616):
+// every axis is cut into segments by the union of input and output nodes (host, tiny:
+// maps._volume_average_weights); the segments of output cell o along an axis are
+// [seg[o], seg[o+1]) with length w and input cell in. One thread per OUTPUT cell gathers
+// sum (wz wy) wx v in the reference's z, y, x order -- the same additions in the same order
+// as its scatter loop -- and divides by the output cell volume.
+__global__ __launch_bounds__(256) void k_volume_average(const double *v, int nx, int ny, const int32_t *sx,
+                                                        const int32_t *sy, const int32_t *sz, const double *wx,
+                                                        const double *wy, const double *wz, const int32_t *inx,
+                                                        const int32_t *iny, const int32_t *inz, const double *vol,
+                                                        int mx, int my, int mz, double *out)
+{
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const int oy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int oz = blockIdx.z;
+    if (ox >= mx || oy >= my) return;
+    double acc = 0.0;
+    for (int a = sz[oz]; a < sz[oz + 1]; ++a)
+        for (int b = sy[oy]; b < sy[oy + 1]; ++b) {
+            const double w_zy = wz[a] * wy[b];
+            const double *row = v + (size_t)nx * (iny[b] + (size_t)ny * inz[a]);
+            for (int c = sx[ox]; c < sx[ox + 1]; ++c) acc += w_zy * wx[c] * row[inx[c]];
+        }
+    const size_t o = (size_t)ox + (size_t)mx * (oy + (size_t)my * oz);
+    out[o] = acc / vol[o];
+}
+
 }  // namespace
 
 extern "C" {
+
+int emg3d_dev_volume_average(const double *values, int nx, int ny, int nz, const int32_t *segx, const int32_t *segy,
+                             const int32_t *segz, const double *wx, const double *wy, const double *wz,
+                             const int32_t *inx, const int32_t *iny, const int32_t *inz, const double *new_vol,
+                             int mx, int my, int mz, double *out, void *stream)
+{
+    if (!values || !segx || !segy || !segz || !wx || !wy || !wz || !inx || !iny || !inz || !new_vol || !out ||
+        nx < 1 || ny < 1 || nz < 1 || mx < 1 || my < 1 || mz < 1)
+        return fail(EMG3D_ERR_BADARG, "volume_average: bad argument");
+    const dim3 block(64, 4, 1), grid((mx + 63) / 64, (my + 3) / 4, mz);
+    hipLaunchKernelGGL(k_volume_average, grid, block, 0, (hipStream_t)stream, values, nx, ny, segx, segy, segz, wx, wy,
+                       wz, inx, iny, inz, new_vol, mx, my, mz, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int emg3d_dev_magnetic_field(int nx, int ny, int nz, int is_complex, const void *ex, const void *ey, const void *ez,
                              const double *zeta, const double *hx, const double *hy, const double *hz, double smu0_re,

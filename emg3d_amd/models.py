@@ -74,12 +74,78 @@ class Model:
         prop = getattr(self, name)
         return None if prop is None else _MAPS[self.mapping](prop)
 
-    def interpolate_to_grid(self, grid):
-        """Identity on the same grid (reference emg3d/models.py:346-347); re-gridding is
-        out of scope of this package."""
+    def interpolate_to_grid(self, grid, **interpolate_opts):
+        """The model on another grid; same call as the reference's
+        ``Model.interpolate_to_grid`` (emg3d/models.py:322-366): the model itself if the grids
+        are identical, else every property by volume averaging (``method='volume'``, on a
+        log10 scale unless the mapping is logarithmic already; nearest extrapolation outside
+        the model grid), computed by ``emg3d_dev_volume_average`` (maps.py:555-664)."""
         if grid == self.grid:
             return self
-        raise NotImplementedError("emg3d_amd: model re-gridding is out of scope.")
+        opts = {'method': 'volume', 'log': not self.mapping.startswith('L'), **interpolate_opts}
+        if opts.pop('method') != 'volume':
+            raise NotImplementedError("emg3d_amd: models are re-gridded with method='volume' only.")
+        log = bool(opts.pop('log'))
+        opts.pop('extrapolate', None)        # 'volume' always extrapolates with the nearest cell
+        if opts:
+            raise TypeError(f"Unexpected interpolation options: {sorted(opts)}")
+        new = {}
+        plan = _VolumeAverage(self.grid, grid)
+        for name in ('property_x', 'property_y', 'property_z', 'mu_r', 'epsilon_r'):
+            values = getattr(self, name)
+            if values is not None:
+                new[name] = plan(values, log)
+        return Model(grid, mapping=self.mapping, **new)
+
+
+def _volume_average_weights(x_i, x_o):
+    """Segments of one axis for the volume averaging (maps._volume_average_weights, reference
+    emg3d/maps.py:619-664): the union of input and output nodes cuts the axis; kept are the
+    segments whose centre lies inside the output grid, with their length, input cell (clamped
+    = nearest extrapolation) and output cell. Returned grouped by output cell: offsets (m+1),
+    lengths, input cells."""
+    xs = np.unique(np.concatenate((x_i, x_o)))
+    centre = 0.5 * (xs[:-1] + xs[1:])
+    keep = (x_o[0] <= centre) & (centre <= x_o[-1])
+    centre, w = centre[keep], np.diff(xs)[keep]
+    cell_in = np.clip(np.searchsorted(x_i[:-1], centre, side='right') - 1, 0, x_i.size - 1)
+    cell_out = np.clip(np.searchsorted(x_o[:-1], centre, side='right') - 1, 0, x_o.size - 1)
+    seg = np.searchsorted(cell_out, np.arange(x_o.size), side='left')       # cell_out is sorted
+    return seg.astype(np.int32), w, cell_in.astype(np.int32)
+
+
+class _VolumeAverage:
+    """Tables of one (grid -> new grid) pair on the device; call with a property array."""
+
+    def __init__(self, grid, new_grid):
+        import torch
+        from emg3d_amd import _lib
+        _lib.require_gpu()
+        self.dev = torch.device('cuda', torch.cuda.current_device())
+        self.shape_in, self.shape_out = grid.shape_cells, new_grid.shape_cells
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)          # noqa: E731
+        self.tabs = []
+        for a, b in ((grid.nodes_x, new_grid.nodes_x), (grid.nodes_y, new_grid.nodes_y),
+                     (grid.nodes_z, new_grid.nodes_z)):
+            self.tabs.append([up(t) for t in _volume_average_weights(a, b)])
+        self.vol = up(new_grid.cell_volumes)
+
+    def __call__(self, values, log):
+        import torch
+        from emg3d_amd import _lib
+        from emg3d_amd._device import _ptr, _stream
+        v = torch.from_numpy(np.ascontiguousarray(values.ravel('F'))).to(self.dev)
+        if log:
+            v = torch.log10(v)
+        out = torch.empty(int(np.prod(self.shape_out)), dtype=torch.float64, device=self.dev)
+        (sx, wx, ix), (sy, wy, iy), (sz, wz, iz) = self.tabs
+        _lib.check(_lib.lib().emg3d_dev_volume_average(
+            _ptr(v), *self.shape_in, _ptr(sx), _ptr(sy), _ptr(sz), _ptr(wx), _ptr(wy), _ptr(wz),
+            _ptr(ix), _ptr(iy), _ptr(iz), _ptr(self.vol), *self.shape_out, _ptr(out), _stream()),
+            'emg3d_dev_volume_average')
+        if log:
+            out = torch.pow(10.0, out)
+        return out.cpu().numpy().reshape(self.shape_out, order='F')
 
 
 class VolumeModel:

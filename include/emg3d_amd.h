@@ -207,6 +207,18 @@ int emg3d_dev_spline_eval(const void *coef, int n0, int n1, int n2, int is_compl
 int emg3d_dev_linear_eval(const void *values, int n0, int n1, int n2, int is_complex,
                           const int32_t *idx, const double *w, int npts, void *out, void *stream);
 
+/* ---- before a solve: model re-gridding -------------------------------
+ * maps.interp_volume_average (emg3d/maps.py:555-616) behind Model.interpolate_to_grid
+ * (emg3d/models.py:322-366). values (nx,ny,nz) -> out (mx,my,mz), doubles, x fastest. Per axis
+ * the host supplies maps._volume_average_weights (maps.py:619-664) grouped by output cell:
+ * seg* (m+1 offsets), w* (segment lengths), in* (input cell of each segment); new_vol = output
+ * cell volumes. Same additions in the same order as the reference: bit-identical. */
+int emg3d_dev_volume_average(const double *values, int nx, int ny, int nz, const int32_t *segx,
+                             const int32_t *segy, const int32_t *segz, const double *wx,
+                             const double *wy, const double *wz, const int32_t *inx,
+                             const int32_t *iny, const int32_t *inz, const double *new_vol, int mx,
+                             int my, int mz, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,41 @@ def interp_linear(points, values, xi, fill=np.nan):
                     acc = acc + wt * values[idx[0] + a, idx[1] + b, idx[2] + c]
         out[p] = acc
     return out
+
+
+# ---- model re-gridding: volume averaging (emg3d/maps.py:555-664) -------------------------
+def volume_average_weights(x_i, x_o):
+    """maps._volume_average_weights (maps.py:619-664): the union of input and output nodes cuts
+    the axis into segments; kept are the segments whose centre lies inside the OUTPUT grid, each
+    with its length, the input cell (clamped: nearest extrapolation) and the output cell."""
+    xs = np.unique(np.concatenate((x_i, x_o)))
+    n1, n2 = len(x_i), len(x_o)
+    w, ii, io = [], [], []
+    i1 = i2 = 0
+    for i in range(len(xs) - 1):
+        center = 0.5 * (xs[i] + xs[i + 1])
+        if x_o[0] <= center <= x_o[n2 - 1]:
+            while i1 < n1 - 1 and center >= x_i[i1]:
+                i1 += 1
+            while i2 < n2 - 1 and center >= x_o[i2]:
+                i2 += 1
+            w.append(xs[i + 1] - xs[i])
+            ii.append(min(max(i1 - 1, 0), n1 - 1))
+            io.append(min(max(i2 - 1, 0), n2 - 1))
+    return np.array(w), np.array(ii, dtype=np.int32), np.array(io, dtype=np.int32)
+
+
+def volume_average(nodes, values, new_nodes):
+    """maps.interp_volume_average (maps.py:555-616): sum of (wz wy) wx v over the segments of
+    every output cell, in the reference's z, y, x order, divided by the output cell volume."""
+    (wx, ixi, ixo), (wy, iyi, iyo), (wz, izi, izo) = [volume_average_weights(a, b) for a, b in zip(nodes, new_nodes)]
+    shape = tuple(len(n) - 1 for n in new_nodes)
+    out = np.zeros(shape)
+    for a, w_z in enumerate(wz):
+        for b, w_y in enumerate(wy):
+            w_zy = w_z * w_y
+            for c, w_x in enumerate(wx):
+                out[ixo[c], iyo[b], izo[a]] += w_zy * w_x * values[ixi[c], iyi[b], izi[a]]
+    vol = (np.diff(new_nodes[0])[:, None, None] * np.diff(new_nodes[1])[None, :, None] *
+           np.diff(new_nodes[2])[None, None, :])
+    return out / vol

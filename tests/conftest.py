@@ -35,3 +35,8 @@ def golden_regression():
 @pytest.fixture(scope='session')
 def golden_receivers():
     return np.load(os.path.join(GOLDEN, 'receivers.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_gridding():
+    return np.load(os.path.join(GOLDEN, 'gridding.npz'), allow_pickle=False)

@@ -847,3 +847,33 @@ def test_parallel_compute_responses_from_device_field():
             assert lean[k][0] is None
             assert np.array_equal(lean[k][1]['responses'], full[k][0].get_receiver(rec, method='linear'))
         assert set(full['_all_info'][('S0', 'f1')]) >= {'responses', 'it_mg'}
+
+
+def test_model_regridding_vs_reference_vectors(golden_gridding):
+    """Model.interpolate_to_grid (volume averaging on the device) against
+    models re-gridded by the reference; the same grid returns the model itself; a solve on the
+    re-gridded model runs."""
+    g = golden_gridding
+    mesh = lambda t: emg3d.TensorMesh([g[f'{t}_hx'], g[f'{t}_hy'], g[f'{t}_hz']], g[f'{t}_origin'])   # noqa: E731
+    grid = mesh('in')
+    for mapping in ('Resistivity', 'Conductivity', 'LgConductivity'):
+        props = {p: g[f'{mapping}_in_{p}'] for p in ('property_x', 'property_z', 'mu_r', 'epsilon_r')}
+        model = emg3d.Model(grid, mapping=mapping, **props)
+        assert model.interpolate_to_grid(mesh('in')) is model
+        for t in ('fine', 'coarse', 'same_nodes'):
+            new = model.interpolate_to_grid(mesh(t))
+            assert new.mapping == mapping and new.case == 'VTI' and new.property_y is None
+            for p in props:
+                want = g[f'{mapping}_{t}_{p}']
+                got = getattr(new, p)
+                assert got.shape == want.shape
+                assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (mapping, t, p)
+    with pytest.raises(NotImplementedError):
+        model.interpolate_to_grid(mesh('fine'), method='cubic')
+    # the worker path: model on one grid, computation on another
+    from emg3d_amd import parallel
+    model = emg3d.Model(grid, property_x=g['Resistivity_in_property_x'])
+    comp = emg3d.TensorMesh([np.full(16, 80.), np.full(16, 90.), np.full(8, 100.)], (-640., -720., -700.))
+    e, info = parallel.solve({'model': model, 'grid': comp, 'source': (0., 0., -300., 0., 0.), 'frequency': 1.0,
+                              'efield': None, 'solver_opts': {'tol': 1e-6}})
+    assert info['exit'] == 0 and e.grid == comp

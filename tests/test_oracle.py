@@ -279,3 +279,34 @@ def test_receiver_restatement_vs_reference_vectors(golden_receivers):
                 m = np.isnan(want)
                 assert np.array_equal(m, np.isnan(resp)) and 0 < m.sum() < m.size
                 assert np.abs(resp[~m] - want[~m]).max() <= 1e-11 * np.abs(want[~m]).max(), (tag, kind, method)
+
+
+def _nodes(g, tag):
+    return [np.r_[0., np.cumsum(g[f'{tag}_h{c}'])] + g[f'{tag}_origin'][d] for d, c in enumerate('xyz')]
+
+
+def test_volume_average_restatement_vs_reference_vectors(golden_gridding):
+    """oracle/interp_ref.volume_average (maps.interp_volume_average, emg3d/maps.py:555-664) and
+    the host's vectorised segment tables against models re-gridded by the reference: finer,
+    coarser + larger (nearest extrapolation) and node-aligned target grids; with and without the
+    log10 scale of Model.interpolate_to_grid (emg3d/models.py:322-366)."""
+    from oracle import interp_ref as R
+    from emg3d_amd.models import _volume_average_weights
+    g = golden_gridding
+    nin = _nodes(g, 'in')
+    for t in ('fine', 'coarse', 'same_nodes'):
+        nout = _nodes(g, t)
+        for a, b in zip(nin, nout):
+            w, ii, io = R.volume_average_weights(a, b)
+            seg, w2, ii2 = _volume_average_weights(a, b)
+            assert np.array_equal(w, w2) and np.array_equal(ii, ii2)
+            assert np.array_equal(np.searchsorted(io, np.arange(b.size)), seg)
+        for mapping in ('Resistivity', 'Conductivity', 'LgConductivity'):
+            for prop in ('property_x', 'property_z', 'mu_r', 'epsilon_r'):
+                v = g[f'{mapping}_in_{prop}']
+                log = not mapping.startswith('L')
+                got = R.volume_average(nin, np.log10(v) if log else v, nout)
+                got = 10 ** got if log else got
+                want = g[f'{mapping}_{t}_{prop}']
+                assert got.shape == want.shape
+                assert np.abs(got - want).max() <= 1e-14 * np.abs(want).max(), (t, mapping, prop)

@@ -16,6 +16,7 @@ Fixtures written (each ≤ 1.5 MB):
                                         per-cycle error history
     tests/golden/receivers.npz          magnetic field and receiver responses (cubic / linear)
                                         of the reference for random fields
+    tests/golden/gridding.npz           models re-gridded by the reference (volume averaging)
 Metadata (scipy version, mu_0, seeds) is stored in every file.
 """
 import os
@@ -337,9 +338,50 @@ def receivers():
     print('receivers.npz written')
 
 
+def gridding():
+    """Model re-gridding: Model.interpolate_to_grid (volume averaging on a
+    log10 scale, emg3d/models.py:322-366 -> maps.interp_volume_average, maps.py:555-664) from a
+    model grid to computational grids that are finer, coarser, shifted and larger (nearest
+    extrapolation), for the mappings with and without log scale."""
+    rng = np.random.default_rng(1107)
+    out = dict(META)
+    out['meta_seed'] = 1107
+    hx, hy, hz = widths(6, 2, 100., 1.3), widths(4, 2, 120., 1.2), widths(4, 1, 80., 1.5)
+    origin = np.array([-hx.sum() / 2, -hy.sum() / 2, -hz.sum() + 100.])
+    grid = emg3d.TensorMesh([hx, hy, hz], origin)
+    shp = grid.shape_cells
+    out.update(in_hx=hx, in_hy=hy, in_hz=hz, in_origin=origin)
+    targets = {
+        'fine': ([np.full(24, 40.), np.full(20, 45.), np.full(12, 50.)], origin + np.array([55., 30., 20.])),
+        'coarse': ([widths(2, 2, 300., 1.4), widths(2, 1, 350., 1.3), np.array([200., 150., 100., 150.])],
+                   origin - np.array([400., 300., 150.])),
+        'same_nodes': ([hx[1:-1], hy, hz[:-1]], origin + np.array([hx[0], 0., 0.])),
+    }
+    for t, (h, o) in targets.items():
+        out.update({f'{t}_hx': h[0], f'{t}_hy': h[1], f'{t}_hz': h[2], f'{t}_origin': np.asarray(o)})
+    props = {'property_x': rng.uniform(0.3, 30., shp), 'property_z': rng.uniform(0.5, 50., shp),
+             'mu_r': rng.uniform(0.9, 1.6, shp), 'epsilon_r': rng.uniform(1., 9., shp)}
+    for mapping in ('Resistivity', 'Conductivity', 'LgConductivity'):
+        p = dict(props)
+        if mapping.startswith('L'):
+            p['property_x'] = np.log10(p['property_x'])
+            p['property_z'] = np.log10(p['property_z'])
+        model = emg3d.Model(grid, mapping=mapping, **p)
+        for k, v in p.items():
+            out[f'{mapping}_in_{k}'] = v
+        for t, (h, o) in targets.items():
+            new = model.interpolate_to_grid(emg3d.TensorMesh(h, o))
+            for k in p:
+                out[f'{mapping}_{t}_{k}'] = getattr(new, k)
+    np.savez_compressed(os.path.join(OUT, 'gridding.npz'), **out)
+    print('gridding.npz written')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['regression', 'kernels', 'solves', 'receivers']
+    which = sys.argv[1:] or ['regression', 'kernels', 'solves', 'receivers', 'gridding']
+    if 'gridding' in which:
+        gridding()
     if 'receivers' in which:
         receivers()
     if 'regression' in which:
