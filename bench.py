@@ -32,6 +32,10 @@ import time
 
 import numpy as np
 
+# the host driver of these boxes supports dmabuf IPC only: RCCL / device-tensor sharing across
+# processes needs it (already exported there; kept for any environment built from here)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -19,6 +19,8 @@ import os
 
 import numpy as np
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC for RCCL on these hosts
+
 __all__ = ['init', 'finalize', 'srcfreq_pairs', 'shard', 'broadcast_model', 'solve',
            'compute', 'gather_objects']
 
