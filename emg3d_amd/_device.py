@@ -96,8 +96,9 @@ class Workspace:
 class DeviceLevel:
     """One grid level resident in HBM."""
 
-    def __init__(self, grid, case, eta_x, eta_y, eta_z, zeta, dtype, work, device):
+    def __init__(self, grid, case, eta_x, eta_y, eta_z, zeta, dtype, work, device, batch=1):
         self.grid = grid
+        self.batch = int(batch)     # right-hand sides that share this level's model and factors
         self.case = case
         self.device = device
         self.work = work
@@ -108,8 +109,9 @@ class DeviceLevel:
         nh = np.cumsum([0] + [len(h) for h in grid.h])
         self.ih = [ihall[nh[d]:nh[d + 1]] for d in range(3)]      # one upload, three views
         n = grid.n_edges
-        self.e = torch.zeros(n, dtype=dtype, device=device)
-        self.s = torch.zeros(n, dtype=dtype, device=device)
+        # batch > 1: the buffers of the right-hand sides one behind the other (source b at b * n)
+        self.e = torch.zeros(n * self.batch, dtype=dtype, device=device)
+        self.s = torch.zeros(n * self.batch, dtype=dtype, device=device)
         self._r = None
         self.children = {}
         self._factors = {}
@@ -122,23 +124,25 @@ class DeviceLevel:
             _ptr(self.e), _ptr(self.e, self._o1), _ptr(self.e, self._o2),
             _ptr(self.s), _ptr(self.s, self._o1), _ptr(self.s, self._o2),
             _ptr(eta_x), _ptr(eta_y), _ptr(eta_z), _ptr(zeta),
-            _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]))
+            _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]), self.batch, 0, n)
         self._cref = ctypes.byref(self._c)
-        work.need_ws(_lib.lib().emg3d_residual_ws_len(nx, ny, nz))
+        work.need_ws(_lib.lib().emg3d_residual_ws_len(nx, ny, nz) * self.batch)
+        if self.batch > 1 and work.sumsq.numel() < self.batch:
+            work.sumsq = torch.zeros(self.batch, dtype=torch.float64, device=device)
 
     # ---------------------------------------------------------------------------------
     @classmethod
-    def from_host(cls, vmodel, device, work=None):
+    def from_host(cls, vmodel, device, work=None, batch=1):
         """Upload a host ``VolumeModel`` (finest level)."""
         work = work or Workspace(device)
         if hasattr(vmodel, 'device_arrays'):
             # emg3d_amd.models.VolumeModel: form eta / zeta in HBM from the conductivities
             ex, ey, ez, zeta = vmodel.device_arrays(device)
             top = cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case, ex, ey, ez,
-                      zeta, ex.dtype, work, device)
+                      zeta, ex.dtype, work, device, batch)
             nx, ny, nz = top.grid.shape_cells
-            work.need_gs(max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
-                             for lr in (1, 2, 3)))
+            work.need_gs(batch * max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
+                                     for lr in (1, 2, 3)))
             return top
         cplx = np.iscomplexobj(vmodel.eta_x)
         dtype = torch.complex128 if cplx else torch.float64
@@ -152,16 +156,16 @@ class DeviceLevel:
             return up[key]
         top = cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case,
                   upload(vmodel.eta_x, ndt), upload(vmodel.eta_y, ndt), upload(vmodel.eta_z, ndt),
-                  upload(vmodel.zeta, np.float64), dtype, work, device)
+                  upload(vmodel.zeta, np.float64), dtype, work, device, batch)
         nx, ny, nz = top.grid.shape_cells
-        work.need_gs(max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
-                         for lr in (1, 2, 3)))
+        work.need_gs(batch * max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
+                                 for lr in (1, 2, 3)))
         return top
 
     @property
     def r(self):
         if self._r is None:
-            self._r = torch.empty(self.grid.n_edges, dtype=self.dtype, device=self.device)
+            self._r = torch.empty(self.grid.n_edges * self.batch, dtype=self.dtype, device=self.device)
         return self._r
 
     def parts(self, t):
@@ -214,7 +218,7 @@ class DeviceLevel:
         if lr:
             f, lf = self.line_factors(lr)
             fac, lfac = _ptr(f), _ptr(lf)
-            nbytes = lib.emg3d_gs_scratch_bytes(lr, nx, ny, nz, self.is_complex)
+            nbytes = lib.emg3d_gs_scratch_bytes(lr, nx, ny, nz, self.is_complex) * self.batch
             self.work.need_gs(nbytes)
             scr = _ptr(self.work.gs_scratch)
         _lib.check(lib.emg3d_dev_gauss_seidel(self._cref, lr, nu, fac, lfac, scr, nbytes, _stream()),
@@ -228,8 +232,10 @@ class DeviceLevel:
         _lib.check(lib.emg3d_dev_residual(self._cref, rx, ry, rz, _ptr(w.ws), w.ws.numel(),
                                           _ptr(w.sumsq) if norm else None, _stream()),
                    'emg3d_dev_residual')
+        if norm and self.batch > 1:
+            return np.sqrt(w.sumsq[:self.batch].cpu().numpy())      # one norm per right-hand side
         if norm:
-            return float(np.sqrt(w.sumsq.item()))
+            return float(np.sqrt(w.sumsq[0].item()))
         return None
 
     def apply_A(self, x, out):
@@ -280,7 +286,7 @@ class DeviceLevel:
                   if self.case in ('VTI', 'triaxial') else ceta_x)
         czeta = restrict_param(self.zeta, 0, torch.float64)
         clevel = DeviceLevel(cgrid, self.case, ceta_x, ceta_y, ceta_z, czeta, self.dtype,
-                             self.work, self.device)
+                             self.work, self.device, self.batch)
 
         # restriction weights (only for coarsened directions; others are never read) and
         # prolongation tables: all 1-D arrays of the link go up in ONE float64 and ONE int32
@@ -320,9 +326,9 @@ class DeviceLevel:
         link = self.child(sc_dir)
         c = link['level']
         nx, ny, nz = self.grid.shape_cells
-        _lib.check(_lib.lib().emg3d_dev_restrict(
+        _lib.check(_lib.lib().emg3d_dev_restrict_batch(
             *c.parts(c.s), *self.parts(self.r), *link['wptr'], nx, ny, nz, sc_dir,
-            self.is_complex, _stream()), 'emg3d_dev_restrict')
+            self.is_complex, self.batch, self.grid.n_edges, c.grid.n_edges, _stream()), 'emg3d_dev_restrict')
         c.e.zero_()
         return c
 
@@ -331,7 +337,7 @@ class DeviceLevel:
         link = self.children[sc_dir]
         c = link['level']
         nx, ny, nz = self.grid.shape_cells
-        _lib.check(_lib.lib().emg3d_dev_prolong(
+        _lib.check(_lib.lib().emg3d_dev_prolong_batch(
             *self.parts(self.e), *c.parts(c.e), *link['ilptr'], *link['pwptr'], nx, ny, nz, sc_dir,
-            self.is_complex, _stream()),
+            self.is_complex, self.batch, self.grid.n_edges, c.grid.n_edges, _stream()),
             'emg3d_dev_prolong')

@@ -45,7 +45,8 @@ class Level(ctypes.Structure):
                 ('ex', _vp), ('ey', _vp), ('ez', _vp),
                 ('sx', _vp), ('sy', _vp), ('sz', _vp),
                 ('eta_x', _vp), ('eta_y', _vp), ('eta_z', _vp),
-                ('zeta', _vp), ('ihx', _vp), ('ihy', _vp), ('ihz', _vp)]
+                ('zeta', _vp), ('ihx', _vp), ('ihy', _vp), ('ihz', _vp),
+                ('batch', ctypes.c_int32), ('reserved', ctypes.c_int32), ('batch_stride', ctypes.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/emg3d_amd.h
@@ -71,6 +72,8 @@ SIGNATURES = {
     'emg3d_dev_residual': (_ci, [ctypes.POINTER(Level), _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'emg3d_dev_restrict': (_ci, [_vp] * 15 + [_ci] * 5 + [_vp]),
     'emg3d_dev_prolong': (_ci, [_vp] * 12 + [_ci] * 5 + [_vp]),
+    'emg3d_dev_restrict_batch': (_ci, [_vp] * 15 + [_ci] * 6 + [_sz, _sz, _vp]),
+    'emg3d_dev_prolong_batch': (_ci, [_vp] * 12 + [_ci] * 6 + [_sz, _sz, _vp]),
     'emg3d_dev_restrict_param': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'emg3d_dev_pec_zero': (_ci, [_vp] * 3 + [_ci] * 4 + [_vp]),
     'emg3d_dev_magnetic_field': (_ci, [_ci] * 4 + [_vp] * 7 + [ctypes.c_double] * 2 + [_vp] * 4),

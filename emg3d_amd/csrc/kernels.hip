@@ -47,6 +47,8 @@ template <class T> emg::Level<T> to_level(const emg3d_level *lv)
     L.eta_x = (const T *)lv->eta_x; L.eta_y = (const T *)lv->eta_y; L.eta_z = (const T *)lv->eta_z;
     L.zeta = lv->zeta;
     L.ihx = lv->ihx; L.ihy = lv->ihy; L.ihz = lv->ihz;
+    L.batch = lv->batch > 1 ? lv->batch : 1;
+    L.bstride = lv->batch > 1 ? (size_t)lv->batch_stride : 0;
     return L;
 }
 
@@ -82,10 +84,12 @@ int g_line_lpw = 0;
 // Point smoother, one colour. colour = ((ix+iz)&1) | (((iy+iz)&1)<<1).
 // pst: eta edge sums from k_point_setup, or nullptr (formed on the fly).
 template <class T>
-__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, const T *pst, int colour, int iz0)
+__global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, const T *pst, int colour, int iz0, int izn)
 {
-    emg::gs_point_thread<T>(L, pst, colour, iz0, blockIdx.x * blockDim.x + threadIdx.x,
-                            blockIdx.y * blockDim.y + threadIdx.y, blockIdx.z);
+    // grid.z = planes x right-hand sides
+    const int b = blockIdx.z / izn, z = blockIdx.z - b * izn;
+    emg::gs_point_thread<T>(emg::source_level(L, b), pst, colour, iz0, blockIdx.x * blockDim.x + threadIdx.x,
+                            blockIdx.y * blockDim.y + threadIdx.y, z);
 }
 
 // eta edge sums of a level (stencil.h: point_setup_cell), one thread per extended cell
@@ -105,15 +109,24 @@ __device__ __forceinline__ void lds_barrier()
 // Point smoother, tiled schedule (launch.h): one workgroup = one tile of one tile colour;
 // the tile's edges live in LDS while the four node colours run on it. The model/source
 // inputs of the next colour's node are fetched while the current node is solved.
-template <class T, class TB, bool ST>
-__global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const T *pst, int tc, int colours)
+template <class T, class TB, bool ST, bool BATCH>
+__global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const T *pst, int tc, int colours,
+                                                                  int gz)
 {
+    // BATCH: grid.z = tiles x right-hand sides (a separate instantiation: the single-source
+    // kernel keeps its register count)
+    int bz = blockIdx.z;
+    if (BATCH) {
+        const int bsrc = blockIdx.z / gz;
+        bz -= bsrc * gz;
+        L = emg::source_level(L, bsrc);
+    }
     extern __shared__ double2 tile_smem[];
     T *lds = reinterpret_cast<T *>(tile_smem);
     using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
     const int x0 = 1 + ((tc & 1) + 2 * blockIdx.x) * TB::BX;
     const int y0 = 1 + (((tc >> 1) & 1) + 2 * blockIdx.y) * TB::BY;
-    const int z0 = 1 + (((tc >> 2) & 1) + 2 * blockIdx.z) * TB::BZ;
+    const int z0 = 1 + (((tc >> 2) & 1) + 2 * bz) * TB::BZ;
     const int t = threadIdx.x;
     emg::tile_load<T, TB>(L, lds, x0, y0, z0, t);
     lds_barrier();
@@ -613,11 +626,18 @@ constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves +
 // (16 x n0p x 64 B), slot 4 in the global scratch -- for lines too long for mode 1 (128
 // blocks: 166 KB). The launcher picks the first mode that fits. In LDS the records never leave
 // the CU: no HBM/L2 round trips between the three phases.
-template <class T, int DIR, int VMODE>
+template <class T, int DIR, int VMODE, bool BATCH>
 __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                             int lpw, const T *fac, const double *lfac, T *vec,
-                                                            T *dummy)
+                                                            T *dummy, size_t vstride)
 {
+    // BATCH: grid.y = right-hand side (Level::batch): same factors, own field / source / scratch
+    // (a separate instantiation: the single-source kernel keeps its register count)
+    if (BATCH) {
+        L = emg::source_level(L, blockIdx.y);
+        vec += blockIdx.y * vstride;
+        dummy += blockIdx.y * vstride;
+    }
     // lpw = lines per workgroup (16, 8 or 4): the chain phases cost the same however full
     // the two waves are, but the right-hand-side phase is spread over more CUs when the
     // colour class has fewer than 16 x 256 lines
@@ -670,11 +690,16 @@ __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int
 
 // Residual + per-block partial sums of |r|^2.
 template <class T>
-__global__ __launch_bounds__(256) void k_residual(emg::Level<T> L, T *rx, T *ry, T *rz, double *partial)
+__global__ __launch_bounds__(256) void k_residual(emg::Level<T> L0, T *rx, T *ry, T *rz, double *partial, int nzp)
 {
+    // grid.z = planes x right-hand sides; the residual buffers are stacked like the fields, and
+    // source b owns the partial sums [b nblk, (b+1) nblk) (blockIdx.z runs over both)
+    const int b = blockIdx.z / nzp;
+    const emg::Level<T> L = emg::source_level(L0, b);
+    if (rx) { rx += b * L0.bstride; ry += b * L0.bstride; rz += b * L0.bstride; }
     const int ix = blockIdx.x * blockDim.x + threadIdx.x;
     const int iy = blockIdx.y * blockDim.y + threadIdx.y;
-    const int iz = blockIdx.z;
+    const int iz = blockIdx.z - b * nzp;
     double acc = 0.0;
     if (ix <= L.nx && iy <= L.ny) acc = emg::residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
     if (partial) {
@@ -694,6 +719,8 @@ __global__ __launch_bounds__(256) void k_residual(emg::Level<T> L, T *rx, T *ry,
 // Deterministic final reduction of the partial sums (single workgroup).
 __global__ __launch_bounds__(256) void k_reduce_sum(const double *partial, int n, double *out)
 {
+    partial += (size_t)blockIdx.x * n;      // one workgroup per right-hand side
+    out += blockIdx.x;
     __shared__ double sm[256];
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
@@ -710,8 +737,10 @@ template <class T> __global__ __launch_bounds__(256) void k_restrict(emg::Restri
 {
     const int cix = blockIdx.x * blockDim.x + threadIdx.x;
     const int ciy = blockIdx.y * blockDim.y + threadIdx.y;
-    const int ciz = blockIdx.z;
+    const int b = blockIdx.z / R.cnzn, ciz = blockIdx.z - b * R.cnzn;    // grid.z = planes x right-hand sides
     if (cix >= R.cnxn || ciy >= R.cnyn) return;
+    R.rx += b * R.fstride; R.ry += b * R.fstride; R.rz += b * R.fstride;
+    R.crx += b * R.cstride; R.cry += b * R.cstride; R.crz += b * R.cstride;
     emg::restrict_node<T>(R, cix, ciy, ciz);
 }
 
@@ -719,8 +748,10 @@ template <class T> __global__ __launch_bounds__(256) void k_prolong(emg::Prolong
 {
     const int ix = blockIdx.x * blockDim.x + threadIdx.x;
     const int iy = blockIdx.y * blockDim.y + threadIdx.y;
-    const int iz = blockIdx.z;
+    const int b = blockIdx.z / (P.nz + 1), iz = blockIdx.z - b * (P.nz + 1);   // planes x right-hand sides
     if (ix > P.nx || iy > P.ny) return;
+    P.ex += b * P.fstride; P.ey += b * P.fstride; P.ez += b * P.fstride;
+    P.cex += b * P.cstride; P.cey += b * P.cstride; P.cez += b * P.cstride;
     emg::prolong_cell<T>(P, ix, iy, iz);
 }
 
@@ -775,7 +806,8 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 qb = d3(emg::linequad_block());
     const emg::Dim3 q1 = emg::linequad_grid(lc);
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
-    const size_t dummy_off = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz) - emg::LINE_DUMMY;
+    const size_t vstride = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz);    // scratch of one right-hand side
+    const size_t dummy_off = vstride - emg::LINE_DUMMY;
     if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
         // lines per workgroup: as few as keeps the workgroup count within one per CU
         int lpw = 16;
@@ -792,31 +824,47 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         const size_t smem2 = ((size_t)lpw * lc.n0p * 4 + emg::LINE_DUMMY) * sizeof(T);
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
             attr = true;
         }
+#define LC_LAUNCH(VM, SMEM)                                                                                              \
+    do {                                                                                                                 \
+        if (L.batch > 1)                                                                                                 \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, true>), dim3(nwg, L.batch), dim3(LC_THREADS), SMEM, st, L, c,   \
+                               lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                     \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, false>), dim3(nwg), dim3(LC_THREADS), SMEM, st, L, c, lc.cntp,  \
+                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                              \
+    } while (0)
         if (fits(smem1))
-            hipLaunchKernelGGL((k_line_colour<T, DIR, 1>), dim3(nwg), dim3(LC_THREADS), smem1, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off);
+            LC_LAUNCH(1, smem1);
         else if (fits(smem2))
-            hipLaunchKernelGGL((k_line_colour<T, DIR, 2>), dim3(nwg), dim3(LC_THREADS), smem2, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off);
+            LC_LAUNCH(2, smem2);
         else
-            hipLaunchKernelGGL((k_line_colour<T, DIR, 0>), dim3(nwg), dim3(LC_THREADS), 0, st, L, c, lc.cntp,
-                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off);
+            LC_LAUNCH(0, 0);
+#undef LC_LAUNCH
         return;
     }
-    if (DIR == 0)
-        hipLaunchKernelGGL(k_line_rhs_xt<T>, dim3(cdiv(lc.cntp, 16), lc.cntq, cdiv(lc.n0p, 16)), dim3(256), 0, st,
-                           L, c, lc.cntp, lc.cntq, lc.n0p, vec);
-    else
-        hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, L, c, lc.cntp, lc.cntq, vec);
-    hipLaunchKernelGGL(k_line_forward<T>, qg2, qb, 0, st, lc.n0, lc.n0p, lc.lines, f, lf, vec, vec + dummy_off);
-    hipLaunchKernelGGL((k_line_backward<T, DIR>), qg2, qb, 0, st, L, c, lc.cntp, lc.cntq, lc.n0p, f, lf,
-                       (const T *)vec, vec + dummy_off);
+    // separate launches (option line_fuse = 0): the right-hand sides one after the other
+    for (int b = 0; b < L.batch; ++b) {
+        const emg::Level<T> Lb = emg::source_level(L, b);
+        T *const vb = vec + (size_t)b * vstride;
+        if (DIR == 0)
+            hipLaunchKernelGGL(k_line_rhs_xt<T>, dim3(cdiv(lc.cntp, 16), lc.cntq, cdiv(lc.n0p, 16)), dim3(256), 0, st,
+                               Lb, c, lc.cntp, lc.cntq, lc.n0p, vb);
+        else
+            hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, Lb, c, lc.cntp, lc.cntq, vb);
+        hipLaunchKernelGGL(k_line_forward<T>, qg2, qb, 0, st, lc.n0, lc.n0p, lc.lines, f, lf, vb, vb + dummy_off);
+        hipLaunchKernelGGL((k_line_backward<T, DIR>), qg2, qb, 0, st, Lb, c, lc.cntp, lc.cntq, lc.n0p, f, lf,
+                           (const T *)vb, vb + dummy_off);
+    }
 }
 
 template <class T>
@@ -828,7 +876,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
     if (nx < 2 || ny < 2 || nz < 2) return fail(EMG3D_ERR_BADARG, "gauss_seidel: need >= 2 cells per direction");
     if (lr != 0) {
         if (!fac || !lfac) return fail(EMG3D_ERR_BADARG, "gauss_seidel: line factors missing (emg3d_dev_line_setup)");
-        if (!scratch || scratch_bytes < emg3d_gs_scratch_bytes(lr, nx, ny, nz, lv->is_complex))
+        if (!scratch || scratch_bytes < (size_t)L.batch * emg3d_gs_scratch_bytes(lr, nx, ny, nz, lv->is_complex))
             return fail(EMG3D_ERR_SCRATCH, "gauss_seidel: scratch buffer too small");
     }
     const bool tiled = emg::point_tiled(nx, ny, nz, g_point_tile_min);
@@ -842,9 +890,13 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             const size_t smem = E::LDS_BYTES;
             static bool attr_set = false;
             if (!attr_set) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, true>),
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, true, false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, false>),
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, false, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, true, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, false, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 attr_set = true;
             }
@@ -853,12 +905,15 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
                 const int tc = emg::tile_colour_at(iback, t8);
                 const emg::Dim3 g = emg::tile_grid<TB>(nx, ny, nz, tc);
                 if (g.x <= 0 || g.y <= 0 || g.z <= 0) continue;
-                if (pst)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true>), d3(g), dim3(TB::THREADS), smem, st, L, pst, tc,
-                                       colours);
+                const dim3 gb(g.x, g.y, g.z * L.batch), tb(TB::THREADS);
+                if (pst && L.batch > 1)
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, true>), gb, tb, smem, st, L, pst, tc, colours, g.z);
+                else if (pst)
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, false>), gb, tb, smem, st, L, pst, tc, colours, g.z);
+                else if (L.batch > 1)
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, true>), gb, tb, smem, st, L, pst, tc, colours, g.z);
                 else
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false>), d3(g), dim3(TB::THREADS), smem, st, L, pst, tc,
-                                       colours);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, false>), gb, tb, smem, st, L, pst, tc, colours, g.z);
             }
             continue;
         }
@@ -866,7 +921,8 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
                 const emg::Dim3 g = emg::gs_point_grid(nx, ny, izn);
                 if (g.x > 0 && g.y > 0 && g.z > 0)
-                    hipLaunchKernelGGL(k_gs_point<T>, d3(g), d3(emg::gs_point_block()), 0, st, L, pst, c, iz0);
+                    hipLaunchKernelGGL(k_gs_point<T>, dim3(g.x, g.y, g.z * L.batch), d3(emg::gs_point_block()), 0, st, L,
+                                       pst, c, iz0, g.z);
             });
             continue;
         }
@@ -911,23 +967,27 @@ int launch_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double 
     emg::Level<T> L = to_level<T>(lv);
     const dim3 block = d3(emg::cell_block());
     const dim3 grid = d3(emg::cell_grid(L.nx + 1, L.ny + 1, L.nz + 1));
-    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
-    if (sumsq && (ws == nullptr || ws_len < nblk)) return fail(EMG3D_ERR_SCRATCH, "residual: workspace too small");
-    hipLaunchKernelGGL(k_residual<T>, grid, block, 0, st, L, (T *)rx, (T *)ry, (T *)rz, sumsq ? ws : nullptr);
-    if (sumsq) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, ws, (int)nblk, sumsq);
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;       // per right-hand side
+    if (sumsq && (ws == nullptr || ws_len < nblk * L.batch)) return fail(EMG3D_ERR_SCRATCH, "residual: workspace too small");
+    hipLaunchKernelGGL(k_residual<T>, dim3(grid.x, grid.y, grid.z * L.batch), block, 0, st, L, (T *)rx, (T *)ry, (T *)rz,
+                       sumsq ? ws : nullptr, (int)grid.z);
+    if (sumsq) hipLaunchKernelGGL(k_reduce_sum, dim3(L.batch), dim3(256), 0, st, ws, (int)nblk, sumsq);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 template <class T>
 int launch_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry, const void *rz,
-                    const double *const w[9], int nx, int ny, int nz, int sc_dir, hipStream_t st)
+                    const double *const w[9], int nx, int ny, int nz, int sc_dir, hipStream_t st, int batch = 1,
+                    size_t fstride = 0, size_t cstride = 0)
 {
     const ScDirs f = sc_flags(sc_dir);
     if ((f.cx && nx % 2) || (f.cy && ny % 2) || (f.cz && nz % 2))
         return fail(EMG3D_ERR_BADARG, "restrict: odd cell count in a coarsened direction");
-    const emg::Restrict<T> R = emg::make_restrict<T>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir);
-    hipLaunchKernelGGL(k_restrict<T>, d3(emg::cell_grid(R.cnxn, R.cnyn, R.cnzn)), d3(emg::cell_block()), 0, st, R);
+    emg::Restrict<T> R = emg::make_restrict<T>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir);
+    R.batch = batch > 1 ? batch : 1; R.fstride = fstride; R.cstride = cstride;
+    const emg::Dim3 g = emg::cell_grid(R.cnxn, R.cnyn, R.cnzn);
+    hipLaunchKernelGGL(k_restrict<T>, dim3(g.x, g.y, g.z * R.batch), d3(emg::cell_block()), 0, st, R);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -935,11 +995,14 @@ int launch_restrict(void *crx, void *cry, void *crz, const void *rx, const void 
 template <class T>
 int launch_prolong(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,
                    const int32_t *ilx, const int32_t *ily, const int32_t *ilz, const double *wx,
-                   const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir, hipStream_t st)
+                   const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir, hipStream_t st,
+                   int batch = 1, size_t fstride = 0, size_t cstride = 0)
 {
-    const emg::Prolong<T> P =
+    emg::Prolong<T> P =
         emg::make_prolong<T>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz, sc_dir);
-    hipLaunchKernelGGL(k_prolong<T>, d3(emg::cell_grid(nx + 1, ny + 1, nz + 1)), d3(emg::cell_block()), 0, st, P);
+    P.batch = batch > 1 ? batch : 1; P.fstride = fstride; P.cstride = cstride;
+    const emg::Dim3 g = emg::cell_grid(nx + 1, ny + 1, nz + 1);
+    hipLaunchKernelGGL(k_prolong<T>, dim3(g.x, g.y, g.z * P.batch), d3(emg::cell_block()), 0, st, P);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1150,6 +1213,32 @@ int emg3d_dev_prolong(void *ex, void *ey, void *ez, const void *cex, const void 
                                                sc_dir, (hipStream_t)stream);
 }
 
+int emg3d_dev_restrict_batch(void *crx, void *cry, void *crz, const void *rx, const void *ry, const void *rz,
+                             const double *wxl, const double *wx0, const double *wxr, const double *wyl,
+                             const double *wy0, const double *wyr, const double *wzl, const double *wz0,
+                             const double *wzr, int nx, int ny, int nz, int sc_dir, int is_complex, int batch,
+                             size_t fine_stride, size_t coarse_stride, void *stream)
+{
+    if (sc_dir < 0 || sc_dir > 6) return fail(EMG3D_ERR_BADARG, "restrict: sc_dir must be 0..6");
+    const double *const w[9] = {wxl, wx0, wxr, wyl, wy0, wyr, wzl, wz0, wzr};
+    return is_complex ? launch_restrict<cplx>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir, (hipStream_t)stream, batch,
+                                              fine_stride, coarse_stride)
+                      : launch_restrict<double>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir, (hipStream_t)stream,
+                                                batch, fine_stride, coarse_stride);
+}
+
+int emg3d_dev_prolong_batch(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,
+                            const int32_t *ilx, const int32_t *ily, const int32_t *ilz, const double *wx,
+                            const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir, int is_complex,
+                            int batch, size_t fine_stride, size_t coarse_stride, void *stream)
+{
+    if (sc_dir < 0 || sc_dir > 6) return fail(EMG3D_ERR_BADARG, "prolong: sc_dir must be 0..6");
+    return is_complex ? launch_prolong<cplx>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz, sc_dir,
+                                             (hipStream_t)stream, batch, fine_stride, coarse_stride)
+                      : launch_prolong<double>(ex, ey, ez, cex, cey, cez, ilx, ily, ilz, wx, wy, wz, nx, ny, nz, sc_dir,
+                                               (hipStream_t)stream, batch, fine_stride, coarse_stride);
+}
+
 int emg3d_dev_restrict_param(void *out, const void *in, int nx, int ny, int nz, int sc_dir, int is_complex,
                              void *stream)
 {
@@ -1186,7 +1275,7 @@ int emg3d_core_amat_x(void *rx, void *ry, void *rz, const void *ex, const void *
     HIP_TRY(eta.up(eta_x, eta_y, eta_z, S.ncc * S.esz));
     HIP_TRY(dz.up(zeta, S.ncc * 8));
     HIP_TRY(upload_inverse(dhx, hx, nx)); HIP_TRY(upload_inverse(dhy, hy, ny)); HIP_TRY(upload_inverse(dhz, hz, nz));
-    emg3d_level lv;
+    emg3d_level lv = {};
     lv.nx = nx; lv.ny = ny; lv.nz = nz; lv.is_complex = is_complex;
     lv.ex = dex.d; lv.ey = dey.d; lv.ez = dez.d;
     lv.sx = drx.d; lv.sy = dry.d; lv.sz = drz.d;   // r -= A e  ==  r = r_in - A e, in place
@@ -1222,7 +1311,7 @@ int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx
     HIP_TRY(dfac.alloc(lr ? emg3d_line_fac_bytes(lr, nx, ny, nz, is_complex)
                           : emg3d_point_fac_bytes(nx, ny, nz, is_complex)));
     HIP_TRY(dlfac.alloc(emg3d_line_lfac_bytes(lr, nx, ny, nz)));
-    emg3d_level lv;
+    emg3d_level lv = {};
     lv.nx = nx; lv.ny = ny; lv.nz = nz; lv.is_complex = is_complex;
     lv.ex = dex.d; lv.ey = dey.d; lv.ez = dez.d;
     lv.sx = dsx.d; lv.sy = dsy.d; lv.sz = dsz.d;

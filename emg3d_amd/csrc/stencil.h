@@ -27,7 +27,24 @@ template <class T> struct Level {
     const T *eta_x, *eta_y, *eta_z;    // -s mu0 sigma V   (field dtype)
     const double *zeta;                // V / mu_r
     const double *ihx, *ihy, *ihz;     // inverse cell widths 1/h
+    // several right-hand sides that share the model (sources of one frequency): source b's
+    // field and source buffers start b * bstride elements behind source 0's. One launch then
+    // serves all of them (one more grid dimension): the coarse levels, whose launches are
+    // latency-bound whatever they carry, cost the same for `batch` sources as for one.
+    int batch = 1;
+    size_t bstride = 0;
 };
+template <class T> EMG_HD Level<T> source_level(Level<T> L, int b)
+{
+    size_t o = (size_t)b * L.bstride;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the offset is uniform over the workgroup: keep it (and the shifted pointers) in scalar registers
+    o = ((size_t)__builtin_amdgcn_readfirstlane((unsigned)(o >> 32)) << 32) | (size_t)__builtin_amdgcn_readfirstlane((unsigned)o);
+#endif
+    L.ex += o; L.ey += o; L.ez += o;
+    L.sx += o; L.sy += o; L.sz += o;
+    return L;
+}
 
 // ---------------------------------------------------------------------------------------
 // Axis-permuted accessors. DIR = 0,1,2 selects the "line" axis a0 = x,y,z; (a1,a2) follow
@@ -1209,6 +1226,8 @@ template <class T> struct Restrict {
     const T *rx, *ry, *rz;       // fine residual
     T *crx, *cry, *crz;          // coarse source
     const double *wx[3], *wy[3], *wz[3];
+    int batch = 1;               // right-hand sides (Level::batch); strides in elements
+    size_t fstride = 0, cstride = 0;
 };
 
 template <class T> EMG_HD void restrict_node(const Restrict<T> &R, int cix, int ciy, int ciz)
@@ -1283,6 +1302,8 @@ template <class T> struct Prolong {
     const T *cex, *cey, *cez;    // coarse field
     const int *ilx, *ily, *ilz;  // lower coarse node per fine node
     const double *wx, *wy, *wz;  // weight of upper coarse node per fine node
+    int batch = 1;               // right-hand sides (Level::batch); strides in elements
+    size_t fstride = 0, cstride = 0;
 };
 
 // Fine "extended cell" (ix,iy,iz): updates ex[ix,iy,iz], ey[ix,iy,iz], ez[ix,iy,iz] when

@@ -27,7 +27,7 @@ import torch
 from emg3d_amd import _lib, fields, models
 from emg3d_amd._device import DeviceLevel
 
-__all__ = ['solve', 'solve_source', 'multigrid', 'krylov', 'smoothing', 'restriction',
+__all__ = ['solve', 'solve_batch', 'solve_source', 'multigrid', 'krylov', 'smoothing', 'restriction',
            'prolongation', 'residual', 'MGParameters', 'RegularGridProlongator']
 
 
@@ -182,22 +182,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
         var.cprint(f"* WARNING :: {var.exit_message}", -1)
 
     if var.return_info:
-        info_dict = {
-            'exit': exit_status,
-            'exit_message': var.exit_message,
-            'abs_error': var.l2,
-            'rel_error': var.l2 / var.l2_refe,
-            'ref_error': var.l2_refe,
-            'tol': var.tol,
-            'it_mg': var.it,
-            'it_ssl': var.ssl_it,
-            'time': var.runtime_at_cycle[-1],
-            'runtime_at_cycle': var.runtime_at_cycle,
-            'error_at_cycle': var.error_at_cycle,
-            'log': var.log_message,
-            # additions of this package (not in the reference):
-            'smoother_cell_sweeps': var.smoother_cell_sweeps,
-        }
+        info_dict = _info_dict(var)
 
     if var.do_return and var.return_info:
         return efield, info_dict
@@ -205,6 +190,143 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
         return efield
     elif var.return_info:
         return info_dict
+
+
+def _info_dict(var):
+    """The info dict of ``solve`` (emg3d/solver.py:416-432)."""
+    return {
+        'exit': int(var.exit_message != 'CONVERGED'),
+        'exit_message': var.exit_message,
+        'abs_error': var.l2,
+        'rel_error': var.l2 / var.l2_refe,
+        'ref_error': var.l2_refe,
+        'tol': var.tol,
+        'it_mg': var.it,
+        'it_ssl': var.ssl_it,
+        'time': var.runtime_at_cycle[-1],
+        'runtime_at_cycle': var.runtime_at_cycle,
+        'error_at_cycle': var.error_at_cycle,
+        'log': var.log_message,
+        # additions of this package (not in the reference):
+        'smoother_cell_sweeps': var.smoother_cell_sweeps,
+    }
+
+
+def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0, **kwargs):
+    """Several sources of ONE frequency on one model, solved together by multigrid.
+
+    Not in the reference (which solves every source-frequency pair separately,
+    emg3d/simulations.py:1453-1464): the sources share the model, hence the coarse models, the
+    line factorisations and every kernel launch -- the smoothers, residuals and transfers take
+    the right-hand sides as one more grid dimension (``emg3d_level::batch``). The launches of
+    the coarse levels cost what they cost for one source, and the factors are read once.
+    Every source gets exactly the iterates, cycle count and field of its own
+    ``solve(model, sfield, sslsolver=False, ...)``: a source that meets the tolerance is copied
+    out at that cycle while the others carry on.
+
+    Returns a list of ``(efield, info_dict)``. Keyword arguments as ``solve`` (multigrid only).
+    """
+    if kwargs.pop('sslsolver', False):
+        raise ValueError("solve_batch: multigrid only (sslsolver=False).")
+    if kwargs.pop('plain', False):
+        semicoarsening = linerelaxation = False
+    for k in ('efield', 'return_info', 'always_return'):
+        kwargs.pop(k, None)
+    sfields = list(sfields)
+    nb = len(sfields)
+    if nb == 0:
+        return []
+    first = sfields[0]
+    for sf in sfields:
+        if sf.frequency is None:
+            raise ValueError("Source field is missing frequency information.")
+        if sf.grid != first.grid or sf._frequency != first._frequency or sf.field.dtype != first.field.dtype:
+            raise ValueError("solve_batch: all sources must share grid and frequency.")
+    vmodel = models.VolumeModel(model, first)
+    vars_ = [MGParameters(sslsolver=False, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
+                          shape_cells=model.shape, verb=verb, **kwargs) for _ in sfields]
+    var = vars_[0]
+    if nb == 1 or var.clevel[var.sc_dir] == 0:
+        return [solve(model, sf, sslsolver=False, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
+                      verb=verb, return_info=True, always_return=True, **kwargs) for sf in sfields]
+    hier = Hierarchy(vmodel, batch=nb)
+    top = hier.top
+    n = top.grid.n_edges
+    efields = []
+    for b, (sf, v) in enumerate(zip(sfields, vars_)):
+        sparse = getattr(sf, '_sparse', None) is not None and bool(getattr(sf, '_trust_sparse', False))
+        v.l2_refe = _host_norm(sf._sparse[1] if sparse else sf.field)
+        v.error_at_cycle[0] = v.l2_refe
+        hier.put_source(sf, top.s[b * n:(b + 1) * n], sparse)
+        efields.append(fields.Field(model.grid, dtype=sf.field.dtype, frequency=sf._frequency))
+    top.e.zero_()
+    done = _multigrid_batch(top, vars_)
+    out = []
+    for b, (ef, v) in enumerate(zip(efields, vars_)):
+        if v.l2_refe < 100 * np.finfo(float).tiny:        # zero source: zero field (solver.py:372-379)
+            v.exit_message = "CONVERGED"
+        else:
+            torch.from_numpy(ef.field).copy_(done[b])
+        out.append((ef, _info_dict(v)))
+    return out
+
+
+def _multigrid_batch(lv, vars_):
+    """Level 0 of ``_multigrid`` for ``lv.batch`` right-hand sides in lock step: the structure
+    of the cycle (sc/lr cycling, cycmax) does not depend on the data, so one recursion serves
+    all; norms, stagnation buffers and termination are per source. Returns the solution of
+    every source as it was when that source terminated (device tensors)."""
+    nb = lv.batch
+    n = lv.grid.n_edges
+    var = vars_[0]                       # carries the structure of the cycle
+    cycmax = var.cycmax
+    it = 0
+    l2_last = lv.residual(store=False, norm=True)
+    l2_stag = np.ones((nb, var.maxcycle)) * l2_last[:, None]
+    active = [v.l2_refe >= 100 * np.finfo(float).tiny for v in vars_]
+    done = [None] * nb
+    final_sweeps = [0.0] * nb
+    if var.nu_init > 0:
+        _smooth(lv, var.nu_init, var.lr_dir, var)
+    while any(active):
+        l2_prev = l2_last.copy()
+        l2_stag[:, (it - 1) % var.maxcycle] = l2_last
+        if var.nu_pre > 0:
+            _smooth(lv, var.nu_pre, var.lr_dir, var)
+        sc_dir = _current_sc_dir(var.sc_dir, lv.grid)
+        lv.residual(store=True, norm=False)
+        clv = lv.restrict_to(sc_dir)
+        if var.verb < 5 and _USE_GRAPHS and _CONCURRENT == 0:
+            _coarse_correction_graphed(clv, var, cycmax)
+        else:
+            _multigrid(clv, var, 1, cycmax)
+        lv.prolong_from(sc_dir)
+        if var.nu_post > 0:
+            _smooth(lv, var.nu_post, var.lr_dir, var)
+        it += 1
+        l2_last = lv.residual(store=False, norm=True)
+        sc_now, lr_now = var.sc_dir, var.lr_dir
+        sc_new = next(var.sc_cycle) if var.sc_cycle else var.sc_dir
+        lr_new = next(var.lr_cycle) if var.lr_cycle else var.lr_dir
+        sweeps = var.smoother_cell_sweeps
+        for b, v in enumerate(vars_):
+            if not active[b]:
+                continue
+            v.it = it
+            v.smoother_cell_sweeps = sweeps
+            v.sc_dir, v.lr_dir = sc_now, lr_now           # what the log line of this cycle shows
+            _print_cycle_info(v, float(l2_last[b]), float(l2_prev[b]))
+            v.sc_dir, v.lr_dir = sc_new, lr_new
+            if _terminate(v, float(l2_last[b]), float(l2_stag[b, (it - 1) % var.maxcycle]), it):
+                active[b] = False
+                v.l2 = float(l2_last[b])
+                final_sweeps[b] = sweeps
+                done[b] = lv.e[b * n:(b + 1) * n].clone()
+        var.sc_dir, var.lr_dir = sc_new, lr_new           # the structure moves on even if source 0 is done
+        var.smoother_cell_sweeps = sweeps
+    for b, v in enumerate(vars_):
+        v.smoother_cell_sweeps = final_sweeps[b]
+    return done
 
 
 def _host_norm(x):
@@ -236,9 +358,9 @@ def _device():
 class Hierarchy:
     """Level 0 on the device for one (model, frequency): upload once, cycle many times."""
 
-    def __init__(self, vmodel, device=None):
+    def __init__(self, vmodel, device=None, batch=1):
         self.device = device or _device()
-        self.top = DeviceLevel.from_host(vmodel, self.device)
+        self.top = DeviceLevel.from_host(vmodel, self.device, batch=batch)
         self.shape = tuple(vmodel.grid.shape_cells)
         self.sval = complex(vmodel._sval)
 

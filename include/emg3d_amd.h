@@ -67,6 +67,13 @@ typedef struct emg3d_level {
     const void *eta_x, *eta_y, *eta_z;
     const double *zeta;
     const double *ihx, *ihy, *ihz; /* INVERSE cell widths 1/h (device) */
+    /* Several right-hand sides that share the model (the sources of one frequency,
+     * emg3d/simulations.py:1453-1464): batch > 1 of them are smoothed / reduced / transferred by
+     * the same launches. Source b's buffers [ex|ey|ez] and [sx|sy|sz] start b * batch_stride
+     * ELEMENTS behind source 0's (the pointers above). 0 or 1: a single source. */
+    int32_t batch;
+    int32_t reserved;
+    int64_t batch_stride;
 } emg3d_level;
 
 int emg3d_version(void);
@@ -142,7 +149,9 @@ int emg3d_dev_point_setup(const emg3d_level *lv, void *fac, void *stream);
 
 /* nu sweeps of the smoother lr (0 point, 1/2/3 line along x/y/z) on level lv.
  * fac/lfac: from emg3d_dev_line_setup for the same level and lr; for lr = 0 fac is the
- * buffer of emg3d_dev_point_setup or NULL, lfac is ignored. */
+ * buffer of emg3d_dev_point_setup or NULL, lfac is ignored. With lv->batch > 1 all right-hand
+ * sides are swept by the same launches (the factors are shared); scratch must then hold
+ * batch x emg3d_gs_scratch_bytes. */
 int emg3d_dev_gauss_seidel(const emg3d_level *lv, int lr, int nu, const void *fac, const double *lfac,
                            void *scratch, size_t scratch_bytes, void *stream);
 
@@ -152,7 +161,8 @@ size_t emg3d_residual_ws_len(int nx, int ny, int nz);
 /* solver.residual (emg3d/solver.py:1022-1070): r = s - A e for the whole buffer
  * (rx/ry/rz may be NULL: norm only; they may alias lv->s*: in-place core.amat_x form).
  * If sumsq != NULL, *sumsq (device double) receives sum |r|^2 over all entries
- * (deterministic two-stage reduction through ws). */
+ * (deterministic two-stage reduction through ws). With lv->batch > 1: r buffers stacked like
+ * the fields (batch_stride), ws of batch x emg3d_residual_ws_len doubles, sumsq[batch]. */
 int emg3d_dev_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double *ws,
                        size_t ws_len, double *sumsq, void *stream);
 
@@ -170,6 +180,21 @@ int emg3d_dev_prolong(void *ex, void *ey, void *ez, const void *cex, const void 
                       const int32_t *ilx, const int32_t *ily, const int32_t *ilz, const double *wx,
                       const double *wy, const double *wz, int nx, int ny, int nz, int sc_dir,
                       int is_complex, void *stream);
+
+/* The two transfers for `batch` right-hand sides stacked like emg3d_level::batch describes:
+ * source b's fine buffers start b * fine_stride elements behind source 0's, its coarse buffers
+ * b * coarse_stride; one launch serves all of them. */
+int emg3d_dev_restrict_batch(void *crx, void *cry, void *crz, const void *rx, const void *ry,
+                             const void *rz, const double *wxl, const double *wx0, const double *wxr,
+                             const double *wyl, const double *wy0, const double *wyr, const double *wzl,
+                             const double *wz0, const double *wzr, int nx, int ny, int nz, int sc_dir,
+                             int is_complex, int batch, size_t fine_stride, size_t coarse_stride,
+                             void *stream);
+int emg3d_dev_prolong_batch(void *ex, void *ey, void *ez, const void *cex, const void *cey,
+                            const void *cez, const int32_t *ilx, const int32_t *ily, const int32_t *ilz,
+                            const double *wx, const double *wy, const double *wz, int nx, int ny, int nz,
+                            int sc_dir, int is_complex, int batch, size_t fine_stride,
+                            size_t coarse_stride, void *stream);
 
 /* solver._restrict_model_parameters (emg3d/solver.py:1667-1718): coarse = sum of the
  * 2/4/8 fine cells; is_complex refers to the parameter dtype (eta: field dtype, zeta: 0). */

@@ -877,3 +877,31 @@ def test_model_regridding_vs_reference_vectors(golden_gridding):
     e, info = parallel.solve({'model': model, 'grid': comp, 'source': (0., 0., -300., 0., 0.), 'frequency': 1.0,
                               'efield': None, 'solver_opts': {'tol': 1e-6}})
     assert info['exit'] == 0 and e.grid == comp
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(cycle='W', linerelaxation=False), dict(plain=True, cycle='V'),
+                                dict(semicoarsening=False, linerelaxation=2)])
+def test_solve_batch_equals_separate_solves(kw):
+    """solve_batch: several sources of one frequency through the same launches (emg3d_level::batch)
+    give, source by source, the field, cycle count and error history of separate solves -- also
+    when the sources need different numbers of cycles."""
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx[:12], hx], (-hx.sum() / 2, -330., -hx.sum() / 2))
+    rng = np.random.default_rng(21)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells),
+                        property_z=10 ** rng.uniform(0, 0.7, grid.shape_cells))
+    srcs = [(-120., 20., -40., 0., 0.), (30., -60., 10., 45., 10.), (0., 0., 0., 90., 0.),
+            ([-200., 150.], [-100., 90.], [-30., 60.])]
+    sfields = [emg3d.get_source_field(grid, s if len(s) == 5 else np.array(s).T, 0.9) for s in srcs]
+    sfields[2]._field *= 1e-3          # a weaker source: same relative tolerance, other history
+    sfields[2]._sparse = None
+    sep = [emg3d.solve(model, sf, sslsolver=False, tol=1e-7, return_info=True, **kw) for sf in sfields]
+    bat = emg3d.solve_batch(model, sfields, tol=1e-7, **kw)
+    assert len(bat) == len(sep)
+    for (e1, i1), (e2, i2) in zip(sep, bat):
+        assert i1['exit'] == i2['exit'] == 0 and i1['it_mg'] == i2['it_mg']
+        assert np.array_equal(i1['error_at_cycle'], i2['error_at_cycle'])
+        assert i1['smoother_cell_sweeps'] == i2['smoother_cell_sweeps']
+        assert np.array_equal(e1.field, e2.field)
+    with pytest.raises(ValueError, match='share grid and frequency'):
+        emg3d.solve_batch(model, [sfields[0], emg3d.get_source_field(grid, srcs[0], 2.0)])
