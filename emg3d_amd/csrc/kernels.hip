@@ -512,12 +512,16 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 // every lane writes entry 4. Entries that do not exist (padding blocks, surplus quads) go to
 // the dummy area through an address select -- no predicate, no branch. The top half also
 // writes the middle block.
-template <class T, int DIR, int HALF>
+// MIDFIRST: the middle block is solved BEFORE the register ring is filled (its ~70 registers
+// and the ring's 160 are then not live together: the batched kernel must stay under 256
+// registers so that two workgroups share a CU); otherwise the ring fetch is in flight while
+// the middle block is solved.
+template <class T, int DIR, int HALF, bool MIDFIRST = false>
 __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
                                               int qline, int qend, int j, const T *fac, const double *lfac,
-                                              const VecRef<T> V, T *dummy)
+                                              const VecRef<T> V, T *dummy, size_t boff = 0)
 {
-    const emg::Axes<T, DIR> A(L);
+    const emg::Axes<T, DIR> A(L, boff);
     const int n0 = A.n0();
     const HalfWalk<HALF> W(n0, n0p);
     const int mk = W.mk;
@@ -542,8 +546,10 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     auto fetch = [&](QuadRow<T> &q, int i) {
         q.load(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));   // a half without blocks still prefetches
     };
+    if (!MIDFIRST) {
 #pragma unroll
-    for (int d = 0; d < QD; ++d) fetch(ring[d], d);
+        for (int d = 0; d < QD; ++d) fetch(ring[d], d);
+    }
     // coupling to the middle: B_m (top) / U_{m+1} (bottom)
     QuadRow<T> qm;
     qm.load_b(lfac, (size_t)(HALF ? mk + 1 : mk) * nlines + line, j);
@@ -551,6 +557,11 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     // x_Q: this lane's entry j (xa) and entry 4 (even lanes) / 5 (odd lanes) (xb)
     T xa, xb;
     quad_middle<T>(n0, n0p, nlines, line, j, fac, lfac, V, xa, xb);
+    if (MIDFIRST) {
+        asm volatile("" ::: "memory");       // keep the ring fetch behind the middle block
+#pragma unroll
+        for (int d = 0; d < QD; ++d) fetch(ring[d], d);
+    }
     const T xq0 = quad_bcast<0>(xa), xq4 = quad_bcast<0>(xb), xq5 = quad_bcast<1>(xb);
     if (HALF == 0) {
         // lane j writes entry j of x_Q (E0(m), t(m+1)_1..3), lane 0 also entry 4, lane 1
@@ -627,14 +638,15 @@ constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves +
 // blocks: 166 KB). The launcher picks the first mode that fits. In LDS the records never leave
 // the CU: no HBM/L2 round trips between the three phases.
 template <class T, int DIR, int VMODE, bool BATCH>
-__global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+__global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                             int lpw, const T *fac, const double *lfac, T *vec,
                                                             T *dummy, size_t vstride)
 {
     // BATCH: grid.y = right-hand side (Level::batch): same factors, own field / source / scratch
     // (a separate instantiation: the single-source kernel keeps its register count)
+    size_t boff = 0;
     if (BATCH) {
-        L = emg::source_level(L, blockIdx.y);
+        boff = blockIdx.y * L.bstride;
         vec += blockIdx.y * vstride;
         dummy += blockIdx.y * vstride;
     }
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int
     // the two waves are, but the right-hand-side phase is spread over more CUs when the
     // colour class has fewer than 16 x 256 lines
     extern __shared__ double2 lc_smem[];
-    const emg::Axes<T, DIR> A(L);
+    const emg::Axes<T, DIR> A(L, boff);
     const int nlines = cntp * cntq;
     const int line0 = blockIdx.x * lpw;
     const int nl = min(lpw, nlines - line0);
@@ -684,8 +696,8 @@ __global__ __launch_bounds__(LC_THREADS) void k_line_colour(emg::Level<T> L, int
     __syncthreads();
     // the backward pass stores into the FIELD; its dummy slots must be global memory too, or
     // the address select mixes address spaces and the stores become flat instructions
-    if (half == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy);
-    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy);
+    if (half == 0) quad_backward<T, DIR, 0, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
+    else quad_backward<T, DIR, 1, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
 // Residual + per-block partial sums of |r|^2.
@@ -812,8 +824,8 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         // lines per workgroup: as few as keeps the workgroup count within one per CU
         int lpw = 16;
         if (g_line_lpw > 0) lpw = g_line_lpw;
-        else if (cdiv(lc.lines, 4) <= 256) lpw = 4;
-        else if (cdiv(lc.lines, 8) <= 256) lpw = 8;
+        else if (cdiv(lc.lines, 4) * L.batch <= 256) lpw = 4;      // all right-hand sides count
+        else if (cdiv(lc.lines, 8) * L.batch <= 256) lpw = 8;
         const unsigned nwg = cdiv(lc.lines, lpw);
         // records in LDS if they fit (+ the dummy slots) and every workgroup gets a CU
         const size_t lds_cu = 160 * 1024;

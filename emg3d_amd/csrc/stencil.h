@@ -53,7 +53,11 @@ template <class T> EMG_HD Level<T> source_level(Level<T> L, int b)
 // ---------------------------------------------------------------------------------------
 template <class T, int DIR> struct Axes {
     const Level<T> &L;
-    EMG_HD Axes(const Level<T> &l) : L(l) {}
+    // element offset of the right-hand side this thread works on (Level::batch): added to the
+    // field / source pointers AFTER the component is selected. (Shifting the pointers inside a
+    // copy of the Level makes the compiler index that copy in scratch memory.)
+    size_t boff;
+    EMG_HD Axes(const Level<T> &l, size_t off = 0) : L(l), boff(off) {}
 
     EMG_HD int n0() const { return DIR == 0 ? L.nx : DIR == 1 ? L.ny : L.nz; }
     EMG_HD int n1() const { return DIR == 0 ? L.ny : DIR == 1 ? L.nz : L.nx; }
@@ -82,12 +86,12 @@ template <class T, int DIR> struct Axes {
     EMG_HD T *E(int c) const
     {
         const int phys = (c + DIR) % 3;
-        return phys == 0 ? L.ex : phys == 1 ? L.ey : L.ez;
+        return (phys == 0 ? L.ex : phys == 1 ? L.ey : L.ez) + boff;
     }
     EMG_HD const T *S(int c) const
     {
         const int phys = (c + DIR) % 3;
-        return phys == 0 ? L.sx : phys == 1 ? L.sy : L.sz;
+        return (phys == 0 ? L.sx : phys == 1 ? L.sy : L.sz) + boff;
     }
     EMG_HD const T *ETA(int c) const
     {
