@@ -189,7 +189,7 @@ def gather_objects(obj, dst=0):
 
 
 def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, solve_fn=None,
-            keep_fields=True, per_gpu=1, reuse=True, receivers=None, receiver_method='cubic'):
+            keep_fields=True, per_gpu=1, reuse=True, receivers=None, receiver_method='cubic', batch=1):
     """Solve all source-frequency pairs, sharded over the ranks of the process group.
 
     model: on rank 0 (None elsewhere is fine; it is broadcast). sources: dict name ->
@@ -201,6 +201,10 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
     dict source name -> such; every pair's ``info['responses']`` then holds the field at the
     receivers, interpolated on the device from the solution while it is still in HBM. With
     ``keep_fields=False`` only the responses leave the GPU (no field download).
+
+    batch > 1: up to that many of the rank's pairs that share a frequency are solved TOGETHER by
+    ``solver.solve_batch`` (right-hand sides as one more grid dimension of every launch:
+    bit-identical fields; multigrid only, i.e. ``solver_opts`` must have ``sslsolver=False``).
 
     reuse: pairs of one worker with the same frequency share one device-resident level
     hierarchy (model, coarse levels, line factorisations, graphs); results are bit-identical.
@@ -241,7 +245,31 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                 stream.synchronize()
         return (s, f), (efield if keep_fields else None, info)
 
-    if per_gpu <= 1 or len(mine) <= 1:
+    if batch > 1 and solve_fn is solve:
+        from emg3d_amd import fields as _fields, solver as _solver
+        opts = dict(solver_opts or {})
+        if opts.pop('sslsolver', True):
+            raise ValueError("compute(batch > 1) needs solver_opts['sslsolver'] = False (multigrid).")
+        by_freq = {}
+        for i in mine:
+            by_freq.setdefault(pairs[i][1], []).append(i)
+        the_model = model.interpolate_to_grid(the_grid)
+        for f, idx in by_freq.items():
+            for i0 in range(0, len(idx), batch):
+                chunk = idx[i0:i0 + batch]
+                sfs = []
+                for i in chunk:
+                    sf = _fields.get_source_field(the_grid, sources[pairs[i][0]], frequencies[f])
+                    sf._trust_sparse = True
+                    sfs.append(sf)
+                rec = None
+                if receivers is not None:
+                    rec = [receivers[pairs[i][0]] if isinstance(receivers, dict) else receivers for i in chunk]
+                res = _solver.solve_batch(the_model, sfs, receivers=rec, receiver_method=receiver_method,
+                                          keep_fields=keep_fields, **opts)
+                for i, (ef, info) in zip(chunk, res):
+                    out[pairs[i]] = (ef, info)
+    elif per_gpu <= 1 or len(mine) <= 1:
         hierarchies = {} if reuse else None
         for i in mine:
             k, v = job(i, None, hierarchies)

@@ -224,7 +224,10 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     ``solve(model, sfield, sslsolver=False, ...)``: a source that meets the tolerance is copied
     out at that cycle while the others carry on.
 
-    Returns a list of ``(efield, info_dict)``. Keyword arguments as ``solve`` (multigrid only).
+    Returns a list of ``(efield, info_dict)``. Keyword arguments as ``solve`` (multigrid only),
+    plus ``receivers`` (one ``(x, y, z, azimuth, elevation)`` for all sources or a list with
+    one per source: ``info['responses']``, interpolated on the device), ``receiver_method`` and
+    ``keep_fields`` (False: no field download, ``efield`` is None).
     """
     if kwargs.pop('sslsolver', False):
         raise ValueError("solve_batch: multigrid only (sslsolver=False).")
@@ -232,6 +235,9 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         semicoarsening = linerelaxation = False
     for k in ('efield', 'return_info', 'always_return'):
         kwargs.pop(k, None)
+    receivers = kwargs.pop('receivers', None)            # one tuple for all, or one per source
+    receiver_method = kwargs.pop('receiver_method', 'cubic')
+    keep_fields = kwargs.pop('keep_fields', True)
     sfields = list(sfields)
     nb = len(sfields)
     if nb == 0:
@@ -246,9 +252,21 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     vars_ = [MGParameters(sslsolver=False, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
                           shape_cells=model.shape, verb=verb, **kwargs) for _ in sfields]
     var = vars_[0]
+    def rec_of(b):
+        if receivers is None:
+            return None
+        return receivers[b] if isinstance(receivers, list) else receivers
+
     if nb == 1 or var.clevel[var.sc_dir] == 0:
-        return [solve(model, sf, sslsolver=False, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
-                      verb=verb, return_info=True, always_return=True, **kwargs) for sf in sfields]
+        out = []
+        for b, sf in enumerate(sfields):
+            ef, info = solve(model, sf, sslsolver=False, semicoarsening=semicoarsening,
+                             linerelaxation=linerelaxation, verb=verb, return_info=True, always_return=True,
+                             **kwargs)
+            if rec_of(b) is not None:
+                info['responses'] = fields.get_receiver(ef, rec_of(b), receiver_method)
+            out.append((ef if keep_fields else None, info))
+        return out
     hier = Hierarchy(vmodel, batch=nb)
     top = hier.top
     n = top.grid.n_edges
@@ -263,11 +281,16 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     done = _multigrid_batch(top, vars_)
     out = []
     for b, (ef, v) in enumerate(zip(efields, vars_)):
-        if v.l2_refe < 100 * np.finfo(float).tiny:        # zero source: zero field (solver.py:372-379)
+        zero = v.l2_refe < 100 * np.finfo(float).tiny     # zero source: zero field (solver.py:372-379)
+        if zero:
             v.exit_message = "CONVERGED"
-        else:
+        elif keep_fields:
             torch.from_numpy(ef.field).copy_(done[b])
-        out.append((ef, _info_dict(v)))
+        info = _info_dict(v)
+        if rec_of(b) is not None:     # from the solution while it is in HBM
+            info['responses'] = fields.get_receiver(ef, rec_of(b), receiver_method,
+                                                    device_field=None if zero else done[b])
+        out.append((ef if keep_fields else None, info))
     return out
 
 

@@ -905,3 +905,30 @@ def test_solve_batch_equals_separate_solves(kw):
         assert np.array_equal(e1.field, e2.field)
     with pytest.raises(ValueError, match='share grid and frequency'):
         emg3d.solve_batch(model, [sfields[0], emg3d.get_source_field(grid, srcs[0], 2.0)])
+
+
+def test_parallel_compute_batched_pairs():
+    """parallel.compute(batch=4): the pairs of one frequency go through solve_batch; fields,
+    cycle counts and device-side responses equal the pair-by-pair run; two frequencies and a
+    ragged last batch."""
+    from emg3d_amd import parallel
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx, hx], (-hx.sum() / 2,) * 3)
+    rng = np.random.default_rng(5)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells))
+    sources = {f'S{i}': (-160. + 70. * i, 20. * i, 10., 15. * i, 0.) for i in range(5)}
+    freqs = {'f1': 1.0, 'f2': 3.0}
+    rec = (rng.uniform(-150, 150, 6), rng.uniform(-150, 150, 6), rng.uniform(-100, 100, 6), 0., 0.)
+    opts = {'sslsolver': False, 'tol': 1e-8, 'verb': 0}
+    seq = parallel.compute(model, grid, sources, freqs, opts, receivers=rec, reuse=False)
+    bat = parallel.compute(model, grid, sources, freqs, opts, receivers=rec, batch=4)
+    lean = parallel.compute(model, grid, sources, freqs, opts, receivers=rec, batch=3, keep_fields=False)
+    keys = sorted(k for k in seq if k != '_all_info')
+    assert sorted(k for k in bat if k != '_all_info') == keys and len(keys) == 10
+    for k in keys:
+        assert bat[k][1]['exit'] == 0 and bat[k][1]['it_mg'] == seq[k][1]['it_mg']
+        assert np.array_equal(bat[k][0].field, seq[k][0].field), k
+        assert np.array_equal(bat[k][1]['responses'], seq[k][1]['responses'])
+        assert lean[k][0] is None and np.array_equal(lean[k][1]['responses'], seq[k][1]['responses'])
+    with pytest.raises(ValueError, match='sslsolver'):
+        parallel.compute(model, grid, sources, freqs, {'tol': 1e-6}, batch=2)

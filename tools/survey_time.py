@@ -4,7 +4,8 @@ x-dipoles, 1 Hz), every pair a complete solve (upload, setup, cycles to tol, dow
     python tools/survey_time.py [--per-gpu 1,3] [--tol 1e-6]
 
 Compares separate hierarchies per pair (what the reference's process pool does) with one
-hierarchy per frequency shared by the pairs of a worker (parallel.compute(reuse=True)).
+hierarchy per frequency shared by the pairs of a worker (parallel.compute(reuse=True)), with
+only the receiver responses leaving the GPU, and with the pairs solved together (batch=4, 8).
 """
 import argparse
 import os
@@ -42,10 +43,21 @@ def main():
             out = parallel.compute(model, grid, sources, freqs, opts, per_gpu=k, reuse=bool(reuse), **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            its = sorted(v[1]['it_mg'] for kk, v in out.items() if kk != '_all_info')
-            work = sum(v[1]['smoother_cell_sweeps'] for kk, v in out.items() if kk != '_all_info')
-            print(f"8 sources, per_gpu={k}, reuse={reuse}: {dt * 1e3:8.1f} ms  ({dt / 8 * 1e3:6.1f} ms per source, "
-                  f"{work / dt / 1e6:7.1f} Mcell-sweeps/s, cycles {its})", flush=True)
+            report(f"per_gpu={k}, reuse={reuse}", out, dt)
+    for nb in (4, 8):
+        for kw, tag in ((dict(), 'fields'), (dict(receivers=rec, keep_fields=False), 'responses only')):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = parallel.compute(model, grid, sources, freqs, opts, batch=nb, **kw)
+            torch.cuda.synchronize()
+            report(f"batch={nb}, {tag}", out, time.perf_counter() - t0)
+
+
+def report(tag, out, dt):
+    its = sorted(v[1]['it_mg'] for kk, v in out.items() if kk != '_all_info')
+    work = sum(v[1]['smoother_cell_sweeps'] for kk, v in out.items() if kk != '_all_info')
+    print(f"8 sources, {tag}: {dt * 1e3:8.1f} ms  ({dt / 8 * 1e3:6.1f} ms per source, "
+          f"{work / dt / 1e6:7.1f} Mcell-sweeps/s, cycles {its})", flush=True)
 
 
 if __name__ == '__main__':
