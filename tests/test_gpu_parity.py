@@ -932,3 +932,27 @@ def test_parallel_compute_batched_pairs():
         assert lean[k][0] is None and np.array_equal(lean[k][1]['responses'], seq[k][1]['responses'])
     with pytest.raises(ValueError, match='sslsolver'):
         parallel.compute(model, grid, sources, freqs, {'tol': 1e-6}, batch=2)
+
+
+@pytest.mark.parametrize('option,value', [('point_tile_min', 1), ('line_fuse', 0), ('line_lds', 0)])
+def test_solve_batch_other_kernel_paths(option, value):
+    """The batched instantiations that the default options do not reach on small grids: the
+    tiled point smoother (forced by point_tile_min), the separate line launches (line_fuse = 0)
+    and the fused line kernel with its records in the global scratch (line_lds = 0)."""
+    lib = _lib.lib()
+    old = lib.emg3d_get_option(option.encode())
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx[:12], hx], (-hx.sum() / 2, -330., -hx.sum() / 2))
+    rng = np.random.default_rng(4)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells))
+    sfields = [emg3d.get_source_field(grid, (x, 10., -20., az, 0.), 1.1) for x, az in ((-90., 0.), (40., 60.), (0., 90.))]
+    kw = dict(plain=True) if option == 'point_tile_min' else {}
+    try:
+        lib.emg3d_set_option(option.encode(), value)
+        sep = [emg3d.solve(model, sf, sslsolver=False, tol=1e-7, return_info=True, **kw) for sf in sfields]
+        bat = emg3d.solve_batch(model, sfields, tol=1e-7, **kw)
+    finally:
+        lib.emg3d_set_option(option.encode(), old)
+    for (e1, i1), (e2, i2) in zip(sep, bat):
+        assert i1['exit'] == i2['exit'] == 0 and i1['it_mg'] == i2['it_mg']
+        assert np.array_equal(e1.field, e2.field)
