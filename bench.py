@@ -235,6 +235,39 @@ def smoothers_256(device, n=256, nu=2, reps=5):
             'bytes_per_cell_sweep': BYTES_PER_CELL_SWEEP['triaxial'], 'peak': HBM_PEAK_GBS, 'smoothers': out}
 
 
+def survey_8(device):
+    """BASELINE.json config 4 on ONE GPU: the 8 sources of the 128^3 marine model (1 Hz) as whole
+    solves to tol 1e-6 -- one after the other, and solved together (solver.solve_batch: the
+    right-hand sides as one more grid dimension of every launch; identical fields). Reported for
+    information; the judged `value` above is the single-source cycle."""
+    import torch
+    import emg3d_amd as emg3d
+    wls = [workload('marine128', source_index=i) for i in range(8)]
+    grid = emg3d.TensorMesh(wls[0]['h'], wls[0]['origin'])
+    model = emg3d.Model(grid, **wls[0]['res'])
+    opts = {k: v for k, v in wls[0]['opts'].items() if k != 'sslsolver'}
+    opts.update(tol=1e-6, verb=0)
+    out = {'workload': 'config 4: 8 x-dipoles, 128^3 marine model, 1 Hz, whole solves to tol 1e-6'}
+    for tag, nb in (('one_by_one', 1), ('solved_together', 8)):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        its, work = [], 0.0
+        for i0 in range(0, 8, nb):
+            sfs = [emg3d.get_source_field(grid, w['source'], w['frequency']) for w in wls[i0:i0 + nb]]
+            if nb == 1:
+                res = [emg3d.solve(model, sfs[0], sslsolver=False, return_info=True, **opts)]
+            else:
+                res = emg3d.solve_batch(model, sfs, **opts)
+            for _, info in res:
+                its.append(int(info['it_mg']))
+                work += info['smoother_cell_sweeps']
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out[tag] = {'seconds': dt, 'ms_per_source': dt / 8 * 1e3, 'Mcell_sweeps_per_s': work / dt / 1e6,
+                    'cycles': its}
+    return out
+
+
 def pmc_traffic(workload_name, kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary
     (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
@@ -351,6 +384,12 @@ def run_gpu(args, rank, world):
         del b
         torch.cuda.empty_cache()
         out['smoothers_256'] = smoothers_256(device)
+    if rank == 0 and world == 1 and not args.no_survey:
+        torch.cuda.empty_cache()
+        try:
+            out['survey_8_sources'] = survey_8(device)
+        except Exception as exc:        # informational block: never takes the bench line down
+            out['survey_8_sources'] = {'error': repr(exc)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -389,6 +428,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--opt', action='append', default=[],
                     help='library tuning option name=value (emg3d_set_option), for experiments')
+    ap.add_argument('--no-survey', action='store_true', help='skip the 8-source survey block')
     ap.add_argument('--no-256', action='store_true',
                     help="skip the separate 256^3 smoother measurement ('smoothers_256')")
     args = ap.parse_args()
