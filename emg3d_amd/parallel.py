@@ -204,7 +204,8 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
 
     batch > 1: up to that many of the rank's pairs that share a frequency are solved TOGETHER by
     ``solver.solve_batch`` (right-hand sides as one more grid dimension of every launch:
-    bit-identical fields; multigrid only, i.e. ``solver_opts`` must have ``sslsolver=False``).
+    bit-identical fields). Batched solves are multigrid solves (``solver_opts['sslsolver'] =
+    False``); with a Krylov solver asked for, the pairs are solved one by one as without `batch`.
 
     reuse: pairs of one worker with the same frequency share one device-resident level
     hierarchy (model, coarse levels, line factorisations, graphs); results are bit-identical.
@@ -245,11 +246,12 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                 stream.synchronize()
         return (s, f), (efield if keep_fields else None, info)
 
-    if batch > 1 and solve_fn is solve:
+    # batched solves are multigrid solves; with a Krylov solver asked for (the default of `solve`)
+    # the pairs are solved one by one on the shared hierarchy instead
+    if batch > 1 and solve_fn is solve and not dict(solver_opts or {}).get('sslsolver', True):
         from emg3d_amd import fields as _fields, solver as _solver
         opts = dict(solver_opts or {})
-        if opts.pop('sslsolver', True):
-            raise ValueError("compute(batch > 1) needs solver_opts['sslsolver'] = False (multigrid).")
+        opts.pop('sslsolver', None)
         by_freq = {}
         for i in mine:
             by_freq.setdefault(pairs[i][1], []).append(i)

@@ -930,8 +930,12 @@ def test_parallel_compute_batched_pairs():
         assert np.array_equal(bat[k][0].field, seq[k][0].field), k
         assert np.array_equal(bat[k][1]['responses'], seq[k][1]['responses'])
         assert lean[k][0] is None and np.array_equal(lean[k][1]['responses'], seq[k][1]['responses'])
-    with pytest.raises(ValueError, match='sslsolver'):
-        parallel.compute(model, grid, sources, freqs, {'tol': 1e-6}, batch=2)
+    # a Krylov solver asked for (the default): pair by pair, as without `batch`
+    two = {k: sources[k] for k in ('S0', 'S1')}
+    a = parallel.compute(model, grid, two, {'f1': 1.0}, {'tol': 1e-6}, batch=2)
+    b = parallel.compute(model, grid, two, {'f1': 1.0}, {'tol': 1e-6})
+    for k in (('S0', 'f1'), ('S1', 'f1')):
+        assert a[k][1]['it_ssl'] == b[k][1]['it_ssl'] > 0 and np.array_equal(a[k][0].field, b[k][0].field)
 
 
 @pytest.mark.parametrize('option,value', [('point_tile_min', 1), ('line_fuse', 0), ('line_lds', 0)])
