@@ -243,11 +243,12 @@ class DeviceLevel:
         emg3d/solver.py:686-702: core.amat_x into a zero field, negated)."""
         lib = _lib.lib()
         if getattr(self, '_zero', None) is None:
-            self._zero = torch.zeros(self.grid.n_edges, dtype=self.dtype, device=self.device)
+            self._zero = torch.zeros(self.grid.n_edges * self.batch, dtype=self.dtype, device=self.device)
         nx, ny, nz = self.grid.shape_cells
         c = _lib.Level(nx, ny, nz, self.is_complex, *self.parts(x), *self.parts(self._zero),
                        _ptr(self.eta_x), _ptr(self.eta_y), _ptr(self.eta_z), _ptr(self.zeta),
-                       _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]))
+                       _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]),
+                       self.batch, 0, self.grid.n_edges)
         _lib.check(lib.emg3d_dev_residual(ctypes.byref(c), *self.parts(out), None, 0, None,
                                           _stream()), 'emg3d_dev_residual')
         out.neg_()

@@ -204,8 +204,8 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
 
     batch > 1: up to that many of the rank's pairs that share a frequency are solved TOGETHER by
     ``solver.solve_batch`` (right-hand sides as one more grid dimension of every launch:
-    bit-identical fields). Batched solves are multigrid solves (``solver_opts['sslsolver'] =
-    False``); with a Krylov solver asked for, the pairs are solved one by one as without `batch`.
+    multigrid: bit-identical fields; BiCGSTAB + multigrid: the Krylov iteration of every source
+    with shared preconditioner / operator applications). cgs / gcrotmk: pair by pair.
 
     reuse: pairs of one worker with the same frequency share one device-resident level
     hierarchy (model, coarse levels, line factorisations, graphs); results are bit-identical.
@@ -246,12 +246,14 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                 stream.synchronize()
         return (s, f), (efield if keep_fields else None, info)
 
-    # batched solves are multigrid solves; with a Krylov solver asked for (the default of `solve`)
-    # the pairs are solved one by one on the shared hierarchy instead
-    if batch > 1 and solve_fn is solve and not dict(solver_opts or {}).get('sslsolver', True):
+    # batched: multigrid, or BiCGSTAB + multigrid (the default of `solve`); cgs / gcrotmk run on
+    # the host through SciPy, pair by pair
+    if (batch > 1 and solve_fn is solve and
+            dict(solver_opts or {}).get('sslsolver', True) in (True, False, None, 'bicgstab') and
+            dict(solver_opts or {}).get('cycle', 'F') is not None):
         from emg3d_amd import fields as _fields, solver as _solver
         opts = dict(solver_opts or {})
-        opts.pop('sslsolver', None)
+        opts.setdefault('sslsolver', True)
         by_freq = {}
         for i in mine:
             by_freq.setdefault(pairs[i][1], []).append(i)

@@ -213,7 +213,10 @@ def _info_dict(var):
 
 
 def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0, **kwargs):
-    """Several sources of ONE frequency on one model, solved together by multigrid.
+    """Several sources of ONE frequency on one model, solved together: by multigrid
+    (``sslsolver=False``, the default here) or by BiCGSTAB with multigrid as preconditioner
+    (``sslsolver=True`` / ``'bicgstab'``: every source runs its own Krylov iteration, the
+    preconditioner and operator applications are shared, see ``_bicgstab_batch``).
 
     Not in the reference (which solves every source-frequency pair separately,
     emg3d/simulations.py:1453-1464): the sources share the model, hence the coarse models, the
@@ -229,10 +232,10 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     one per source: ``info['responses']``, interpolated on the device), ``receiver_method`` and
     ``keep_fields`` (False: no field download, ``efield`` is None).
     """
-    if kwargs.pop('sslsolver', False):
-        raise ValueError("solve_batch: multigrid only (sslsolver=False).")
+    sslsolver = kwargs.pop('sslsolver', False)
     if kwargs.pop('plain', False):
         semicoarsening = linerelaxation = False
+        sslsolver = False if sslsolver is True else sslsolver
     for k in ('efield', 'return_info', 'always_return'):
         kwargs.pop(k, None)
     receivers = kwargs.pop('receivers', None)            # one tuple for all, or one per source
@@ -249,9 +252,13 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         if sf.grid != first.grid or sf._frequency != first._frequency or sf.field.dtype != first.field.dtype:
             raise ValueError("solve_batch: all sources must share grid and frequency.")
     vmodel = models.VolumeModel(model, first)
-    vars_ = [MGParameters(sslsolver=False, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
-                          shape_cells=model.shape, verb=verb, **kwargs) for _ in sfields]
-    var = vars_[0]
+    def new_var():
+        return MGParameters(sslsolver=sslsolver, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
+                            shape_cells=model.shape, verb=verb, **kwargs)
+    vars_ = [new_var() for _ in sfields]
+    var = svar = new_var()             # carries the structure of the cycle, shared by all sources
+    if var.sslsolver not in (None, False, 'bicgstab') or (var.sslsolver and not var.cycle):
+        raise ValueError("solve_batch: multigrid, or BiCGSTAB with multigrid as preconditioner.")
     def rec_of(b):
         if receivers is None:
             return None
@@ -260,7 +267,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     if nb == 1 or var.clevel[var.sc_dir] == 0:
         out = []
         for b, sf in enumerate(sfields):
-            ef, info = solve(model, sf, sslsolver=False, semicoarsening=semicoarsening,
+            ef, info = solve(model, sf, sslsolver=sslsolver, semicoarsening=semicoarsening,
                              linerelaxation=linerelaxation, verb=verb, return_info=True, always_return=True,
                              **kwargs)
             if rec_of(b) is not None:
@@ -278,77 +285,211 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         hier.put_source(sf, top.s[b * n:(b + 1) * n], sparse)
         efields.append(fields.Field(model.grid, dtype=sf.field.dtype, frequency=sf._frequency))
     top.e.zero_()
-    done = _multigrid_batch(top, vars_)
+    nonzero = [v.l2_refe >= 100 * np.finfo(float).tiny for v in vars_]
+    if var.sslsolver:
+        done = _bicgstab_batch(hier, svar, vars_, nonzero)
+    else:
+        done, _ = _multigrid_batch(top, svar, vars_, nonzero)
     out = []
     for b, (ef, v) in enumerate(zip(efields, vars_)):
         zero = v.l2_refe < 100 * np.finfo(float).tiny     # zero source: zero field (solver.py:372-379)
         if zero:
             v.exit_message = "CONVERGED"
-        elif keep_fields:
+        elif keep_fields and done[b] is not None:
             torch.from_numpy(ef.field).copy_(done[b])
         info = _info_dict(v)
         if rec_of(b) is not None:     # from the solution while it is in HBM
             info['responses'] = fields.get_receiver(ef, rec_of(b), receiver_method,
-                                                    device_field=None if zero else done[b])
+                                                    device_field=None if zero or done[b] is None else done[b])
         out.append((ef if keep_fields else None, info))
     return out
 
 
-def _multigrid_batch(lv, vars_):
+def _multigrid_batch(lv, svar, vars_, active=None):
     """Level 0 of ``_multigrid`` for ``lv.batch`` right-hand sides in lock step: the structure
-    of the cycle (sc/lr cycling, cycmax) does not depend on the data, so one recursion serves
-    all; norms, stagnation buffers and termination are per source. Returns the solution of
-    every source as it was when that source terminated (device tensors)."""
+    of the cycle (sc/lr cycling, cycmax; carried by ``svar``) does not depend on the data, so one
+    recursion serves all; norms, stagnation buffers, counters and termination are per source
+    (``vars_``). Returns (done, failed): the solution of every source as it was when that source
+    terminated (device tensors; None for sources that were not active), and which sources
+    ended with a ``_ConvergenceError`` (multigrid as preconditioner: diverged / stagnated)."""
     nb = lv.batch
     n = lv.grid.n_edges
-    var = vars_[0]                       # carries the structure of the cycle
-    cycmax = var.cycmax
+    cycmax = svar.cycmax
     it = 0
     l2_last = lv.residual(store=False, norm=True)
-    l2_stag = np.ones((nb, var.maxcycle)) * l2_last[:, None]
-    active = [v.l2_refe >= 100 * np.finfo(float).tiny for v in vars_]
+    l2_stag = np.ones((nb, svar.maxcycle)) * l2_last[:, None]
+    active = [True] * nb if active is None else list(active)
     done = [None] * nb
-    final_sweeps = [0.0] * nb
-    if var.nu_init > 0:
-        _smooth(lv, var.nu_init, var.lr_dir, var)
+    failed = [False] * nb
+    base = [v.smoother_cell_sweeps for v in vars_]
+    s0 = svar.smoother_cell_sweeps
+    if svar.nu_init > 0:
+        _smooth(lv, svar.nu_init, svar.lr_dir, svar)
     while any(active):
         l2_prev = l2_last.copy()
-        l2_stag[:, (it - 1) % var.maxcycle] = l2_last
-        if var.nu_pre > 0:
-            _smooth(lv, var.nu_pre, var.lr_dir, var)
-        sc_dir = _current_sc_dir(var.sc_dir, lv.grid)
+        l2_stag[:, (it - 1) % svar.maxcycle] = l2_last
+        if svar.nu_pre > 0:
+            _smooth(lv, svar.nu_pre, svar.lr_dir, svar)
+        sc_dir = _current_sc_dir(svar.sc_dir, lv.grid)
         lv.residual(store=True, norm=False)
         clv = lv.restrict_to(sc_dir)
-        if var.verb < 5 and _USE_GRAPHS and _CONCURRENT == 0:
-            _coarse_correction_graphed(clv, var, cycmax)
+        if svar.verb < 5 and _USE_GRAPHS and _CONCURRENT == 0:
+            _coarse_correction_graphed(clv, svar, cycmax)
         else:
-            _multigrid(clv, var, 1, cycmax)
+            _multigrid(clv, svar, 1, cycmax)
         lv.prolong_from(sc_dir)
-        if var.nu_post > 0:
-            _smooth(lv, var.nu_post, var.lr_dir, var)
+        if svar.nu_post > 0:
+            _smooth(lv, svar.nu_post, svar.lr_dir, svar)
         it += 1
         l2_last = lv.residual(store=False, norm=True)
-        sc_now, lr_now = var.sc_dir, var.lr_dir
-        sc_new = next(var.sc_cycle) if var.sc_cycle else var.sc_dir
-        lr_new = next(var.lr_cycle) if var.lr_cycle else var.lr_dir
-        sweeps = var.smoother_cell_sweeps
+        sc_now, lr_now = svar.sc_dir, svar.lr_dir
+        if svar.sc_cycle:
+            svar.sc_dir = next(svar.sc_cycle)
+        if svar.lr_cycle:
+            svar.lr_dir = next(svar.lr_cycle)
         for b, v in enumerate(vars_):
             if not active[b]:
                 continue
-            v.it = it
-            v.smoother_cell_sweeps = sweeps
+            v.it += 1
+            v.smoother_cell_sweeps = base[b] + (svar.smoother_cell_sweeps - s0)
             v.sc_dir, v.lr_dir = sc_now, lr_now           # what the log line of this cycle shows
             _print_cycle_info(v, float(l2_last[b]), float(l2_prev[b]))
-            v.sc_dir, v.lr_dir = sc_new, lr_new
-            if _terminate(v, float(l2_last[b]), float(l2_stag[b, (it - 1) % var.maxcycle]), it):
+            v.sc_dir, v.lr_dir = svar.sc_dir, svar.lr_dir
+            try:
+                finished = _terminate(v, float(l2_last[b]), float(l2_stag[b, (it - 1) % svar.maxcycle]), it)
+            except _ConvergenceError:
+                finished = failed[b] = True
+            if finished:
                 active[b] = False
                 v.l2 = float(l2_last[b])
-                final_sweeps[b] = sweeps
                 done[b] = lv.e[b * n:(b + 1) * n].clone()
-        var.sc_dir, var.lr_dir = sc_new, lr_new           # the structure moves on even if source 0 is done
-        var.smoother_cell_sweeps = sweeps
+    return done, failed
+
+
+def _bicgstab_batch(hier, svar, vars_, nonzero):
+    """``_bicgstab_device`` for the right-hand sides of a batch. The vector algebra of every
+    source is the single-source code (same 1-D tensor operations on that source's rows, its own
+    scalars, breakdown checks and stopping rule); what is shared are the two preconditioner
+    applications (multigrid cycles on all sources at once, ``_multigrid_batch``) and the two
+    operator applications per iteration. Identical to separate solves as long as the sources
+    run the same number of cycles inside every preconditioner call (the rule: ``maxit`` cycles;
+    a source may stop earlier on convergence) -- otherwise the sc/lr cycling of the shared
+    structure and of a separate solve drift apart, and the fields agree to the tolerance only.
+    Returns the solutions (device tensors; None for zero sources / failed solves)."""
+    top = hier.top
+    nb, n = top.batch, top.grid.n_edges
+    rows = lambda t, b: t[b * n:(b + 1) * n]           # noqa: E731
+    B = top.s.clone()
+    X = torch.zeros_like(B)
+    R, V, T, P, PHAT, SHAT = (torch.empty_like(B) for _ in range(6))
+
+    def norm(t):
+        return float(torch.linalg.vector_norm(t).item())
+
+    def dot(u, w):
+        return complex(torch.vdot(u, w).item()) if top.is_complex else float(torch.dot(u, w).item())
+
+    live = list(nonzero)                   # still iterating
+    failed = [False] * nb
+
+    def psolve(VEC, OUT):
+        top.s.copy_(VEC)
+        top.e.zero_()
+        done, bad = _multigrid_batch(top, svar, vars_, live)
+        for b in range(nb):
+            if live[b]:
+                rows(OUT, b).copy_(done[b])
+                if bad[b]:
+                    failed[b] = True
+                    live[b] = False
+
+    def apply_A(XIN, OUT):
+        top.apply_A(XIN, OUT)
+
+    def true_residual_norms():
+        top.s.copy_(B)
+        top.e.copy_(X)
+        return top.residual(store=False, norm=True)
+
+    eps = np.finfo(np.float64).eps
+    rhotol = omegatol = eps ** 2
+    atol = [max(1e-30, v.tol * norm(rows(B, b))) if live[b] else 0.0 for b, v in enumerate(vars_)]
+    apply_A(X, R)
+    torch.sub(B, R, out=R)
+    RT = R.clone()
+    rho_prev = [1.0] * nb
+    omega = [1.0] * nb
+    alpha = [1.0] * nb
+    rho = [1.0] * nb
+    code = [v.ssl_maxit for v in vars_]
+    for iteration in range(svar.ssl_maxit):
+        for b in range(nb):                              # ---- up to the first preconditioner call
+            if not live[b]:
+                continue
+            r, p, v = rows(R, b), rows(P, b), rows(V, b)
+            if norm(r) < atol[b]:
+                code[b], live[b] = 0, False
+                continue
+            rho[b] = dot(rows(RT, b), r)
+            if abs(rho[b]) < rhotol:
+                code[b], live[b] = -10, False
+                continue
+            if iteration > 0:
+                if abs(omega[b]) < omegatol:
+                    code[b], live[b] = -11, False
+                    continue
+                beta = (rho[b] / rho_prev[b]) * (alpha[b] / omega[b])
+                p.sub_(v, alpha=omega[b]).mul_(beta).add_(r)
+            else:
+                p.copy_(r)
+        if not any(live):
+            break
+        psolve(P, PHAT)
+        apply_A(PHAT, V)
+        for b in range(nb):                              # ---- between the two calls
+            if not live[b]:
+                continue
+            r = rows(R, b)
+            rv = dot(rows(RT, b), rows(V, b))
+            if rv == 0:
+                code[b], live[b] = -11, False
+                continue
+            alpha[b] = rho[b] / rv
+            r.sub_(rows(V, b), alpha=alpha[b])
+            if norm(r) < atol[b]:
+                rows(X, b).add_(rows(PHAT, b), alpha=alpha[b])
+                code[b], live[b] = 0, False
+        if not any(live):
+            break
+        psolve(R, SHAT)
+        apply_A(SHAT, T)
+        for b in range(nb):                              # ---- after the second call
+            if not live[b]:
+                continue
+            r, t = rows(R, b), rows(T, b)
+            omega[b] = dot(t, r) / dot(t, t)
+            rows(X, b).add_(rows(PHAT, b), alpha=alpha[b]).add_(rows(SHAT, b), alpha=omega[b])
+            r.sub_(t, alpha=omega[b])
+            rho_prev[b] = rho[b]
+        l2 = true_residual_norms()
+        for b, v in enumerate(vars_):
+            if live[b]:
+                _krylov_callback(v, float(l2[b]))
+    done = [None] * nb
     for b, v in enumerate(vars_):
-        v.smoother_cell_sweeps = final_sweeps[b]
+        if not nonzero[b]:
+            continue
+        i = -1 if failed[b] else code[b]
+        if failed[b]:
+            v.exit_message += " (returned field is zero)"
+        elif i < 0 and v.exit_message == '':
+            v.exit_message = f"Error in {v.sslsolver} ({i})"
+        elif i > 0:
+            v.exit_message = "MAX. ITERATION REACHED, NOT CONVERGED"
+        elif i == 0:
+            v.exit_message = "CONVERGED"
+        if not failed[b]:
+            done[b] = rows(X, b)
     return done
 
 

@@ -930,12 +930,36 @@ def test_parallel_compute_batched_pairs():
         assert np.array_equal(bat[k][0].field, seq[k][0].field), k
         assert np.array_equal(bat[k][1]['responses'], seq[k][1]['responses'])
         assert lean[k][0] is None and np.array_equal(lean[k][1]['responses'], seq[k][1]['responses'])
-    # a Krylov solver asked for (the default): pair by pair, as without `batch`
+    # the default solver (BiCGSTAB + multigrid) in batches, and one that is not batched (gcrotmk)
     two = {k: sources[k] for k in ('S0', 'S1')}
-    a = parallel.compute(model, grid, two, {'f1': 1.0}, {'tol': 1e-6}, batch=2)
-    b = parallel.compute(model, grid, two, {'f1': 1.0}, {'tol': 1e-6})
-    for k in (('S0', 'f1'), ('S1', 'f1')):
-        assert a[k][1]['it_ssl'] == b[k][1]['it_ssl'] > 0 and np.array_equal(a[k][0].field, b[k][0].field)
+    for o in ({'tol': 1e-7}, {'tol': 1e-7, 'sslsolver': 'cgs'}):
+        a = parallel.compute(model, grid, two, {'f1': 1.0}, o, batch=2)
+        b = parallel.compute(model, grid, two, {'f1': 1.0}, o)
+        for k in (('S0', 'f1'), ('S1', 'f1')):
+            assert a[k][1]['exit'] == b[k][1]['exit'] and a[k][1]['it_ssl'] == b[k][1]['it_ssl'] > 0
+            assert 'sslsolver' in o or a[k][1]['exit'] == 0
+            assert np.allclose(a[k][0].field, b[k][0].field, rtol=1e-6, atol=1e-6 * np.abs(b[k][0].field).max())
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(cycle='V', linerelaxation=False), dict(semicoarsening=False)])
+def test_solve_batch_bicgstab(kw):
+    """solve_batch(sslsolver=True): BiCGSTAB per source with shared multigrid preconditioner and
+    operator applications -- same iteration counts and fields as separate solves (bit-identical
+    while all sources run the same number of cycles per preconditioner call)."""
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx[:12], hx], (-hx.sum() / 2, -330., -hx.sum() / 2))
+    rng = np.random.default_rng(31)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells),
+                        property_z=10 ** rng.uniform(0, 0.7, grid.shape_cells))
+    sfields = [emg3d.get_source_field(grid, s, 0.9) for s in
+               ((-120., 20., -40., 0., 0.), (30., -60., 10., 45., 10.), (0., 0., 0., 90., 0.))]
+    sep = [emg3d.solve(model, sf, tol=1e-8, return_info=True, **kw) for sf in sfields]
+    bat = emg3d.solve_batch(model, sfields, sslsolver=True, tol=1e-8, **kw)
+    for (e1, i1), (e2, i2) in zip(sep, bat):
+        assert i1['exit'] == i2['exit'] == 0
+        assert (i1['it_ssl'], i1['it_mg']) == (i2['it_ssl'], i2['it_mg'])
+        assert np.allclose(i1['error_at_cycle'], i2['error_at_cycle'], rtol=1e-10)
+        assert relerr(e2.field, e1.field) < 1e-12
 
 
 @pytest.mark.parametrize('option,value', [('point_tile_min', 1), ('line_fuse', 0), ('line_lds', 0)])

@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--batch', default='1,2,4,8')
     ap.add_argument('--tol', type=float, default=1e-6)
     ap.add_argument('--opt', action='append', default=[])
+    ap.add_argument('--ssl', action='store_true', help='BiCGSTAB + multigrid (the default of solve) instead of multigrid')
     args = ap.parse_args()
     for o in args.opt:
         k, v = o.split('=')
@@ -29,7 +30,7 @@ def main():
     grid = emg3d.TensorMesh(wls[0]['h'], wls[0]['origin'])
     model = emg3d.Model(grid, **wls[0]['res'])
     opts = {k: v for k, v in wls[0]['opts'].items() if k != 'sslsolver'}
-    opts.update(tol=args.tol, verb=0)
+    opts.update(tol=args.tol, verb=0, sslsolver=bool(args.ssl))
     emg3d.solve_batch(model, [emg3d.get_source_field(grid, wls[0]['source'], wls[0]['frequency'])] * 2, **opts)
     for nb in [int(x) for x in args.batch.split(',')]:
         torch.cuda.synchronize()
