@@ -254,7 +254,7 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
         from emg3d_amd import fields as _fields, solver as _solver
         opts = dict(solver_opts or {})
         opts.setdefault('sslsolver', True)
-        by_freq = {}
+        by_freq, hiers = {}, {}
         for i in mine:
             by_freq.setdefault(pairs[i][1], []).append(i)
         the_model = model.interpolate_to_grid(the_grid)
@@ -269,8 +269,13 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                 rec = None
                 if receivers is not None:
                     rec = [receivers[pairs[i][0]] if isinstance(receivers, dict) else receivers for i in chunk]
+                hkey = (f, len(chunk))
+                if reuse and hkey not in hiers:
+                    hiers.clear()                 # one frequency / batch size at a time stays resident
+                    from emg3d_amd import models as _models
+                    hiers[hkey] = _solver.Hierarchy(_models.VolumeModel(the_model, sfs[0]), batch=len(chunk))
                 res = _solver.solve_batch(the_model, sfs, receivers=rec, receiver_method=receiver_method,
-                                          keep_fields=keep_fields, **opts)
+                                          keep_fields=keep_fields, hierarchy=hiers.get(hkey), **opts)
                 for i, (ef, info) in zip(chunk, res):
                     out[pairs[i]] = (ef, info)
     elif per_gpu <= 1 or len(mine) <= 1:

@@ -230,7 +230,8 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     Returns a list of ``(efield, info_dict)``. Keyword arguments as ``solve`` (multigrid only),
     plus ``receivers`` (one ``(x, y, z, azimuth, elevation)`` for all sources or a list with
     one per source: ``info['responses']``, interpolated on the device), ``receiver_method`` and
-    ``keep_fields`` (False: no field download, ``efield`` is None).
+    ``keep_fields`` (False: no field download, ``efield`` is None), ``hierarchy`` (a
+    ``Hierarchy(vmodel, batch=len(sfields))`` of an earlier batch of the same frequency).
     """
     sslsolver = kwargs.pop('sslsolver', False)
     if kwargs.pop('plain', False):
@@ -241,6 +242,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     receivers = kwargs.pop('receivers', None)            # one tuple for all, or one per source
     receiver_method = kwargs.pop('receiver_method', 'cubic')
     keep_fields = kwargs.pop('keep_fields', True)
+    hierarchy = kwargs.pop('hierarchy', None)            # a Hierarchy(vmodel, batch=len(sfields)) to reuse
     sfields = list(sfields)
     nb = len(sfields)
     if nb == 0:
@@ -274,7 +276,11 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
                 info['responses'] = fields.get_receiver(ef, rec_of(b), receiver_method)
             out.append((ef if keep_fields else None, info))
         return out
-    hier = Hierarchy(vmodel, batch=nb)
+    if hierarchy is not None and hierarchy.top.batch == nb:
+        hierarchy.check(vmodel)
+        hier = hierarchy
+    else:
+        hier = Hierarchy(vmodel, batch=nb)
     top = hier.top
     n = top.grid.n_edges
     efields = []
