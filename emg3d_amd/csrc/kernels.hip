@@ -110,17 +110,22 @@ __device__ __forceinline__ void lds_barrier()
 // the tile's edges live in LDS while the four node colours run on it. The model/source
 // inputs of the next colour's node are fetched while the current node is solved.
 template <class T, class TB, bool ST, bool BATCH>
-__global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const T *pst, int tc, int colours,
-                                                                  int gz)
+__global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const T *pst, emg::TilePair P,
+                                                                  int colours)
 {
-    // BATCH: grid.z = tiles x right-hand sides (a separate instantiation: the single-source
-    // kernel keeps its register count)
+    // grid.z = (tiles of colour P.tc[0], then of P.tc[1]) [x right-hand sides if BATCH: a
+    // separate instantiation, the single-source kernel keeps its register count]
+    const int gz = P.gz[0] + P.gz[1];
     int bz = blockIdx.z;
     if (BATCH) {
         const int bsrc = blockIdx.z / gz;
         bz -= bsrc * gz;
         L = emg::source_level(L, bsrc);
     }
+    const int which = bz >= P.gz[0] ? 1 : 0;
+    bz -= which ? P.gz[0] : 0;
+    if ((int)blockIdx.x >= P.gx[which] || (int)blockIdx.y >= P.gy[which]) return;
+    const int tc = P.tc[which];
     extern __shared__ double2 tile_smem[];
     T *lds = reinterpret_cast<T *>(tile_smem);
     using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
@@ -913,19 +918,20 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
                 attr_set = true;
             }
             const int colours = emg::sweep_colours_packed(iback);
-            for (int t8 = 0; t8 < 8; ++t8) {
-                const int tc = emg::tile_colour_at(iback, t8);
-                const emg::Dim3 g = emg::tile_grid<TB>(nx, ny, nz, tc);
-                if (g.x <= 0 || g.y <= 0 || g.z <= 0) continue;
-                const dim3 gb(g.x, g.y, g.z * L.batch), tb(TB::THREADS);
+            for (int p = 0; p < 4; ++p) {          // two complementary tile colours per launch
+                const emg::TilePair P = emg::tile_pair<TB>(nx, ny, nz, iback, p);
+                const int gz = P.gz[0] + P.gz[1];
+                if (gz <= 0) continue;
+                const dim3 gb(P.gx[0] > P.gx[1] ? P.gx[0] : P.gx[1], P.gy[0] > P.gy[1] ? P.gy[0] : P.gy[1], gz * L.batch);
+                const dim3 tb(TB::THREADS);
                 if (pst && L.batch > 1)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, true>), gb, tb, smem, st, L, pst, tc, colours, g.z);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, true>), gb, tb, smem, st, L, pst, P, colours);
                 else if (pst)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, false>), gb, tb, smem, st, L, pst, tc, colours, g.z);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, false>), gb, tb, smem, st, L, pst, P, colours);
                 else if (L.batch > 1)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, true>), gb, tb, smem, st, L, pst, tc, colours, g.z);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, true>), gb, tb, smem, st, L, pst, P, colours);
                 else
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, false>), gb, tb, smem, st, L, pst, tc, colours, g.z);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, false>), gb, tb, smem, st, L, pst, P, colours);
             }
             continue;
         }

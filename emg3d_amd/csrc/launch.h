@@ -83,8 +83,8 @@ template <class F> inline void gs_point_schedule(int nz, int slab, int iback, F 
 // workgroup stages a tile's edges (+ the one-edge halo) in LDS, runs the four colour
 // classes on it back to back, and writes the tile's edges out -- one pass over the field
 // per sweep. Tiles that run concurrently must not touch: the tiles are coloured
-// (tx&1)|((ty&1)<<1)|((tz&1)<<2) and a sweep is eight launches, one per tile colour (forward
-// 0..7, backward 7..0). The result is a Gauss-Seidel sweep in the order "tile colour, then
+// (tx&1)|((ty&1)<<1)|((tz&1)<<2), visited in the order 0,7,1,6,2,5,3,4 (backward: reversed); a
+// sweep is four launches of two complementary colours each (tile_colour_at). The result is a Gauss-Seidel sweep in the order "tile colour, then
 // node colour inside every tile" -- a different, equally valid ordering than the plain
 // schedule's (the oracle restates it: oracle/core_generic.h, order 2).
 template <int BX_, int BY_, int BZ_> struct TileBox {
@@ -110,7 +110,29 @@ inline bool point_tiled(int nx, int ny, int nz, int tile_min)
 {
     return tile_min > 0 && (long long)(nx - 1) * (ny - 1) * (nz - 1) >= tile_min;
 }
-inline int tile_colour_at(int iback, int t8) { return iback ? 7 - t8 : t8; }
+// Tile colours in visiting order: 0,7,1,6,2,5,3,4 (backward: reversed). Consecutive pairs are
+// complementary colours (c, 7-c): their tiles differ in the parity of ALL three tile indices,
+// so they are at least corner-diagonal -- they share no edge either of them writes or reads --
+// and one launch runs both (four launches per sweep, each with twice the tiles: a smaller
+// share of the launch is its last, partly filled round of workgroups).
+inline int tile_colour_at(int iback, int t8)
+{
+    const int seq[8] = {0, 7, 1, 6, 2, 5, 3, 4};
+    return seq[iback ? 7 - t8 : t8];
+}
+// the two colours of launch p (0..3) of a sweep and their grids
+struct TilePair { int tc[2], gx[2], gy[2], gz[2]; };
+template <class TB> inline TilePair tile_pair(int nx, int ny, int nz, int iback, int p)
+{
+    TilePair P;
+    for (int h = 0; h < 2; ++h) {
+        P.tc[h] = tile_colour_at(iback, 2 * p + h);
+        const Dim3 g = tile_grid<TB>(nx, ny, nz, P.tc[h]);
+        const bool any = g.x > 0 && g.y > 0 && g.z > 0;
+        P.gx[h] = any ? g.x : 0; P.gy[h] = any ? g.y : 0; P.gz[h] = any ? g.z : 0;
+    }
+    return P;
+}
 // the four node colours of a sweep packed two bits each, first-visited in the low bits
 inline int sweep_colours_packed(int iback)
 {

@@ -36,8 +36,9 @@
  *     Point smoother on LARGE levels -- (nx-1)(ny-1)(nz-1) >= option "point_tile_min"
  *     (default 2^20) -- the interior nodes are cut into tiles of 32 x 4 x 6 nodes (tile t
  *     along an axis = nodes 1 + t*B .. (t+1)*B) which are coloured
- *     (tx&1)|((ty&1)<<1)|((tz&1)<<2); a forward sweep visits the tile colours 0..7 (backward
- *     7..0) and, inside every tile, the four node colours as above. This is the order in
+ *     (tx&1)|((ty&1)<<1)|((tz&1)<<2); a forward sweep visits the tile colours in the order
+ *     0,7,1,6,2,5,3,4 (backward: reversed; complementary colours are independent of each other
+ *     and share a launch) and, inside every tile, the four node colours as above. This is the order in
  *     which one workgroup can keep a tile in LDS for all four node colours (one pass over
  *     the field per sweep instead of four); it is a Gauss-Seidel sweep like the others and
  *     converges alike. The oracle restates all of these orders.

@@ -30,7 +30,7 @@ void oracle_set_colour_order(int a, int b, int c, int d)
 /* order 2 of the point smoother: tile extents in nodes and the sequence of the eight tile
  * colours of a FORWARD sweep (backward = reversed). */
 int oracle_tile[3] = {32, 4, 6};
-int oracle_tile_order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+int oracle_tile_order[8] = {0, 7, 1, 6, 2, 5, 3, 4};   /* complementary colours next to each other (launch.h) */
 void oracle_set_tile(int bx, int by, int bz) { oracle_tile[0] = bx; oracle_tile[1] = by; oracle_tile[2] = bz; }
 void oracle_set_tile_order(const int *o) { int i; for (i = 0; i < 8; i++) oracle_tile_order[i] = o[i]; }
 
