@@ -147,6 +147,8 @@ class Bench:
                                        tol=0.0, maxit=10 ** 9, **wl['opts'])
         self.var.l2_refe = float(np.linalg.norm(self.sfield.field))
         self.events = []          # (lr, nu, start_event, end_event) of level-0 smoother calls
+        from emg3d_amd import _lib
+        self.skip_repeat = bool(_lib.lib().emg3d_get_option(b'skip_repeat'))
         self._instrument()
 
     def _instrument(self):
@@ -177,7 +179,10 @@ class Bench:
         for lr, nu, a, b in self.events:
             ms = a.elapsed_time(b)
             st = stats.setdefault(lr, {'launches': 0, 'ms': 0.0})
-            st['launches'] += 4 * nu
+            # colour passes actually launched: consecutive sweeps meet at one colour class, and the
+            # library does not repeat that pass (it would reproduce the same values; option
+            # skip_repeat) -- nu sweeps = 4 nu - (nu - 1) launches
+            st['launches'] += 4 * nu - ((nu - 1) if self.skip_repeat else 0)
             st['ms'] += ms
         return stats
 
@@ -232,6 +237,10 @@ def smoothers_256(device, n=256, nu=2, reps=5):
         lv._factors.pop(lr, None)               # 15 GB of line factors per direction: free them
         torch.cuda.empty_cache()
     return {'level': f'{n}^3 tri-axial, complex fp64, {nu} sweeps per call',
+            'note': ('line smoothers / plain point smoother: a call of nu sweeps launches 4 nu - (nu - 1) colour '
+                     'passes -- the pass that would repeat the previous sweep\'s last colour class reproduces the '
+                     'same values bit by bit and is not launched (option skip_repeat); the tiled point smoother '
+                     'launches all of its passes'),
             'bytes_per_cell_sweep': BYTES_PER_CELL_SWEEP['triaxial'], 'peak': HBM_PEAK_GBS, 'smoothers': out}
 
 

@@ -75,6 +75,8 @@ int g_line_fuse = 2;
 int g_line_fuse_max = 1 << 30;
 // fused line kernel: keep the right-hand-side / solution records of a workgroup's lines in
 // LDS when they fit into this many bytes (0 = never)
+// skip the colour pass that repeats the previous sweep's last one (bit-identical results)
+int g_skip_repeat = 1;
 int g_line_lds = 1;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
@@ -936,7 +938,12 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             continue;
         }
         if (lr == 0) {
+            // (same redundancy for the node classes; only the unslabbed schedule is a plain
+            // sequence of whole colour passes)
+            const bool unslabbed = g_point_slab <= 0 || g_point_slab >= nz - 1;
+            const int skip = (g_skip_repeat && it > 0 && unslabbed) ? emg::sweep_colour(iback, 0) : -1;
             emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
+                if (c == skip) return;
                 const emg::Dim3 g = emg::gs_point_grid(nx, ny, izn);
                 if (g.x > 0 && g.y > 0 && g.z > 0)
                     hipLaunchKernelGGL(k_gs_point<T>, dim3(g.x, g.y, g.z * L.batch), d3(emg::gs_point_block()), 0, st, L,
@@ -946,6 +953,11 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
         }
         for (int cc = 0; cc < 4; ++cc) {
             const int c = emg::sweep_colour(iback, cc);
+            // A sweep ends with the colour class the next one (opposite direction) starts with.
+            // A line solve depends on the edges NOT on the line only, and lines of one class do not
+            // see each other: solving the class again right away reproduces the same values bit by
+            // bit. (The reference's sequential sweeps have the same redundant first line.)
+            if (g_skip_repeat && it > 0 && cc == 0) continue;
             if (lr == 1) launch_line_colour<T, 0>(L, c, (const T *)fac, lfac, (T *)scratch, st);
             else if (lr == 2) launch_line_colour<T, 1>(L, c, (const T *)fac, lfac, (T *)scratch, st);
             else launch_line_colour<T, 2>(L, c, (const T *)fac, lfac, (T *)scratch, st);
@@ -1116,6 +1128,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "point_tile_min")) { g_point_tile_min = value; return 0; }
     if (!std::strcmp(name, "line_fuse")) { g_line_fuse = value; return 0; }
     if (!std::strcmp(name, "line_fuse_max")) { g_line_fuse_max = value; return 0; }
+    if (!std::strcmp(name, "skip_repeat")) { g_skip_repeat = value; return 0; }
     if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
     if (!std::strcmp(name, "line_lpw")) {
         if (value != 0 && value != 4 && value != 8 && value != 16) return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8 or 16");
@@ -1131,6 +1144,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "point_tile_min")) return g_point_tile_min;
     if (name && !std::strcmp(name, "line_fuse")) return g_line_fuse;
     if (name && !std::strcmp(name, "line_fuse_max")) return g_line_fuse_max;
+    if (name && !std::strcmp(name, "skip_repeat")) return g_skip_repeat;
     if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
     if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
     return -1;

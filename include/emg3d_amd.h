@@ -89,7 +89,9 @@ int emg3d_device_count(void);
  * line launch (4, 8, 16; 0 = automatic). "line_fuse":
  * 0 three launches per colour and line direction (rhs, forward, backward), 1 one fused
  * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines (default:
- * no limit -- the fused launch is the faster one at every size measured). */
+ * no limit -- the fused launch is the faster one at every size measured). "skip_repeat": 1
+ * (default) does not launch the colour pass that repeats the last colour class of the previous
+ * sweep of the same call (it reproduces the same values bit by bit); 0 launches every pass. */
 int emg3d_set_option(const char *name, int value);
 int emg3d_get_option(const char *name);
 

@@ -984,3 +984,39 @@ def test_solve_batch_other_kernel_paths(option, value):
     for (e1, i1), (e2, i2) in zip(sep, bat):
         assert i1['exit'] == i2['exit'] == 0 and i1['it_mg'] == i2['it_mg']
         assert np.array_equal(e1.field, e2.field)
+
+
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_repeated_colour_pass_is_redundant(dtype):
+    """Consecutive sweeps (backward, forward, ...) meet at one colour class; the second pass over
+    it reproduces the values of the first bit by bit (its inputs, the edges off the lines / off
+    the nodes, have not changed), so the library skips it (option skip_repeat = 1, default).
+    All four smoothers, nu = 2, 3 and 4, with and without the pass: identical bits."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(12)
+    shape = (12, 10, 14)
+    h = [widths(s - 4, 2, 30. + 7 * d, 1.3) for d, s in enumerate(shape)]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    n = grid.n_cells
+    sval = 2j * np.pi * 1.1 if dtype is complex else -1.7
+    vol = (h[0][:, None, None] * h[1][None, :, None] * h[2][None, None, :])
+    eta = [np.asfortranarray(-sval * 1.25663706127e-06 * vol * 10 ** rng.uniform(-1, 1, shape)).astype(dtype)
+           for _ in range(3)]
+    zeta = np.asfortranarray(vol)
+    ne = grid.n_edges
+    e0 = rng.standard_normal(ne) + (1j * rng.standard_normal(ne) if dtype is complex else 0)
+    s0 = rng.standard_normal(ne) + (1j * rng.standard_normal(ne) if dtype is complex else 0)
+    try:
+        for name in SMOOTHERS:
+            for nu in (2, 3, 4):
+                out = []
+                for skip in (1, 0):
+                    lib.emg3d_set_option(b'skip_repeat', skip)
+                    e = mg_ref.Field(grid, e0.astype(dtype).copy())
+                    sf = mg_ref.Field(grid, s0.astype(dtype).copy())
+                    getattr(core, name)(e.fx, e.fy, e.fz, sf.fx, sf.fy, sf.fz, eta[0], eta[1], eta[2], zeta,
+                                        h[0], h[1], h[2], nu)
+                    out.append(e.field.copy())
+                assert np.array_equal(out[0], out[1]), (name, nu)
+    finally:
+        lib.emg3d_set_option(b'skip_repeat', 1)
