@@ -77,6 +77,8 @@ int g_line_fuse_max = 1 << 30;
 // LDS when they fit into this many bytes (0 = never)
 // skip the colour pass that repeats the previous sweep's last one (bit-identical results)
 int g_skip_repeat = 1;
+// tiled point smoother: the tiles where two consecutive sweeps meet run both on one LDS copy
+int g_tile_fuse = 1;
 int g_line_lds = 1;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void lds_barrier()
 // inputs of the next colour's node are fetched while the current node is solved.
 template <class T, class TB, bool ST, bool BATCH>
 __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const T *pst, emg::TilePair P,
-                                                                  int colours)
+                                                                  int colours, int nsteps)
 {
     // grid.z = (tiles of colour P.tc[0], then of P.tc[1]) [x right-hand sides if BATCH: a
     // separate instantiation, the single-source kernel keeps its register count]
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
     // two workgroups per CU (launch bounds: <= 256 registers, 2 x 79 KB of LDS): while one
     // waits for the inputs of its next node, the other one computes
 #pragma unroll 1
-    for (int cc = 0; cc < 4; ++cc) {
+    for (int cc = 0; cc < nsteps; ++cc) {     // node colours, two bits each (4, or 7-8 for two fused sweeps)
         emg::PointIn<T> in;
         int ix, iy, iz;
         const bool ok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, (colours >> (2 * cc)) & 3, t, ix, iy, iz);
@@ -919,21 +921,31 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 attr_set = true;
             }
-            const int colours = emg::sweep_colours_packed(iback);
-            for (int p = 0; p < 4; ++p) {          // two complementary tile colours per launch
+            // A sweep ends with the pair of tile colours the next sweep (opposite direction) starts
+            // with, and nothing else runs in between: those tiles do the node colours of BOTH sweeps
+            // on one LDS copy -- one load / store of the tile instead of two (1/8 of the traffic of
+            // two sweeps) -- minus the node colour that would merely be repeated (skip_repeat).
+            const bool fuse_next = g_tile_fuse && it + 1 < nu;
+            for (int p = (g_tile_fuse && it > 0) ? 1 : 0; p < 4; ++p) {   // two complementary tile colours per launch
                 const emg::TilePair P = emg::tile_pair<TB>(nx, ny, nz, iback, p);
                 const int gz = P.gz[0] + P.gz[1];
                 if (gz <= 0) continue;
+                int colours = emg::sweep_colours_packed(iback), nsteps = 4;
+                if (p == 3 && fuse_next) {
+                    const int next = emg::sweep_colours_packed(1 - iback);
+                    if (g_skip_repeat) { colours |= (next >> 2) << 8; nsteps = 7; }
+                    else { colours |= next << 8; nsteps = 8; }
+                }
                 const dim3 gb(P.gx[0] > P.gx[1] ? P.gx[0] : P.gx[1], P.gy[0] > P.gy[1] ? P.gy[0] : P.gy[1], gz * L.batch);
                 const dim3 tb(TB::THREADS);
                 if (pst && L.batch > 1)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, true>), gb, tb, smem, st, L, pst, P, colours);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, true>), gb, tb, smem, st, L, pst, P, colours, nsteps);
                 else if (pst)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, false>), gb, tb, smem, st, L, pst, P, colours);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, false>), gb, tb, smem, st, L, pst, P, colours, nsteps);
                 else if (L.batch > 1)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, true>), gb, tb, smem, st, L, pst, P, colours);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, true>), gb, tb, smem, st, L, pst, P, colours, nsteps);
                 else
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, false>), gb, tb, smem, st, L, pst, P, colours);
+                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, false>), gb, tb, smem, st, L, pst, P, colours, nsteps);
             }
             continue;
         }
@@ -1129,6 +1141,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "line_fuse")) { g_line_fuse = value; return 0; }
     if (!std::strcmp(name, "line_fuse_max")) { g_line_fuse_max = value; return 0; }
     if (!std::strcmp(name, "skip_repeat")) { g_skip_repeat = value; return 0; }
+    if (!std::strcmp(name, "tile_fuse")) { g_tile_fuse = value; return 0; }
     if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
     if (!std::strcmp(name, "line_lpw")) {
         if (value != 0 && value != 4 && value != 8 && value != 16) return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8 or 16");
@@ -1145,6 +1158,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "line_fuse")) return g_line_fuse;
     if (name && !std::strcmp(name, "line_fuse_max")) return g_line_fuse_max;
     if (name && !std::strcmp(name, "skip_repeat")) return g_skip_repeat;
+    if (name && !std::strcmp(name, "tile_fuse")) return g_tile_fuse;
     if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
     if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
     return -1;

@@ -91,7 +91,9 @@ int emg3d_device_count(void);
  * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines (default:
  * no limit -- the fused launch is the faster one at every size measured). "skip_repeat": 1
  * (default) does not launch the colour pass that repeats the last colour class of the previous
- * sweep of the same call (it reproduces the same values bit by bit); 0 launches every pass. */
+ * sweep of the same call (it reproduces the same values bit by bit); 0 launches every pass.
+ * "tile_fuse": 1 (default) lets the tiles of the tiled point smoother where two consecutive
+ * sweeps meet run both sweeps on one LDS copy (same operations, one load / store less). */
 int emg3d_set_option(const char *name, int value);
 int emg3d_get_option(const char *name);
 

@@ -1020,3 +1020,42 @@ def test_repeated_colour_pass_is_redundant(dtype):
                 assert np.array_equal(out[0], out[1]), (name, nu)
     finally:
         lib.emg3d_set_option(b'skip_repeat', 1)
+
+
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_tiled_point_smoother_fused_sweeps(dtype):
+    """Tiled point smoother: the tiles where two consecutive sweeps meet run both sweeps on one LDS
+    copy (option tile_fuse), minus the repeated node colour (skip_repeat): identical bits with
+    every combination of the two options, nu = 1..4, on a grid with partial tiles."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(3)
+    shape = (40, 11, 15)
+    h = [widths(s - 4, 2, 30. + 7 * d, 1.2) for d, s in enumerate(shape)]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sval = 2j * np.pi * 0.7 if dtype is complex else -2.1
+    vol = (h[0][:, None, None] * h[1][None, :, None] * h[2][None, None, :])
+    eta = [np.asfortranarray(-sval * 1.25663706127e-06 * vol * 10 ** rng.uniform(-1, 1, shape)).astype(dtype)
+           for _ in range(3)]
+    zeta = np.asfortranarray(vol)
+    ne = grid.n_edges
+    e0 = rng.standard_normal(ne) + (1j * rng.standard_normal(ne) if dtype is complex else 0)
+    s0 = rng.standard_normal(ne) + (1j * rng.standard_normal(ne) if dtype is complex else 0)
+    old = lib.emg3d_get_option(b'point_tile_min')
+    try:
+        lib.emg3d_set_option(b'point_tile_min', 1)
+        for nu in (1, 2, 3, 4):
+            out = []
+            for fuse, skip in ((1, 1), (1, 0), (0, 1), (0, 0)):
+                lib.emg3d_set_option(b'tile_fuse', fuse)
+                lib.emg3d_set_option(b'skip_repeat', skip)
+                e = mg_ref.Field(grid, e0.astype(dtype).copy())
+                sf = mg_ref.Field(grid, s0.astype(dtype).copy())
+                core.gauss_seidel(e.fx, e.fy, e.fz, sf.fx, sf.fy, sf.fz, eta[0], eta[1], eta[2], zeta,
+                                  h[0], h[1], h[2], nu)
+                out.append(e.field.copy())
+            for o in out[1:]:
+                assert np.array_equal(out[0], o), nu
+    finally:
+        lib.emg3d_set_option(b'point_tile_min', old)
+        lib.emg3d_set_option(b'tile_fuse', 1)
+        lib.emg3d_set_option(b'skip_repeat', 1)
