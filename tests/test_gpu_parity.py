@@ -1059,3 +1059,142 @@ def test_tiled_point_smoother_fused_sweeps(dtype):
         lib.emg3d_set_option(b'point_tile_min', old)
         lib.emg3d_set_option(b'tile_fuse', 1)
         lib.emg3d_set_option(b'skip_repeat', 1)
+
+
+# ------------------------------------------------------------------------------------------
+# Full-size per-sweep parity: the kernel instantiations bench.py times -- default options, so
+# the partial-LDS (VMODE 2) and global-scratch (VMODE 0) record modes of k_line_colour and the
+# un-forced tiled point path with fused sweeps are the ones executing -- against the oracle in
+# the same ordering (order 1: four colours; order 2: tile-blocked point order).
+# ------------------------------------------------------------------------------------------
+def _host_fields(lv, grid, seed):
+    s = _rand_field(lv, grid, seed, pec=False).cpu().numpy()
+    e0 = _rand_field(lv, grid, seed + 1, pec=True).cpu().numpy()
+    return s, e0
+
+
+def _oracle_sweeps(fn, vm, grid, s, e0, nu, tiled):
+    og = mg_ref.Grid(grid.h, grid.origin)
+    S, A = mg_ref.Field(og, s), mg_ref.Field(og, e0.copy())
+    order = 2 if (fn == 'gauss_seidel' and tiled) else 1
+    getattr(ocore, fn)(A.fx, A.fy, A.fz, S.fx, S.fy, S.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta,
+                       *grid.h, nu, order=order)
+    return A.field
+
+
+def _level_with_host_model(shape, case, seed, stretch=1.03):
+    """_rand_level, keeping the host arrays of the model for the oracle."""
+    rng = np.random.default_rng(seed)
+    h = [widths(n // 2, n // 4, 25., stretch) if n % 4 == 0 else
+         25. * stretch ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = emg3d.TensorMesh(h, (0, 0, 0))
+    assert grid.shape_cells == shape
+    vol = grid.cell_volumes.reshape(shape, order='F')
+    smu0 = 2j * np.pi * 1.0 * 1.25663706127e-06
+
+    class VM:
+        pass
+    vm = VM()
+    vm.grid, vm.case = grid, case
+    sig = 10 ** rng.uniform(-1.5, 0.5, shape)
+    vm.eta_x = np.asfortranarray(-smu0 * vol * sig)
+    vm.eta_y = np.asfortranarray(vm.eta_x / 1.5) if case == 'triaxial' else vm.eta_x
+    vm.eta_z = np.asfortranarray(vm.eta_x / 2.5) if case in ('VTI', 'triaxial') else vm.eta_x
+    vm.zeta = np.asfortranarray(vol)
+    return DeviceLevel.from_host(vm, torch.device('cuda')), grid, vm
+
+
+@pytest.mark.parametrize('shape,case', [((128, 128, 128), 'VTI'), ((256, 256, 256), 'triaxial')])
+def test_full_size_per_sweep_parity_vs_oracle(shape, case):
+    """BASELINE.json configs 2 / 3 sizes, every smoother, nu = 2 (backward + forward sweep, the
+    repeated colour pass skipped, the tiled point smoother with its fused sweeps), default
+    library options: per-call values against the oracle in the same ordering, 2e-12 rel-L2."""
+    lv, grid, vm = _level_with_host_model(shape, case, 7)
+    s, e0 = _host_fields(lv, grid, 11)
+    lv.s.copy_(torch.from_numpy(s))
+    nodes = (shape[0] - 1) * (shape[1] - 1) * (shape[2] - 1)
+    tiled = nodes >= _lib.lib().emg3d_get_option(b'point_tile_min') > 0
+    assert tiled                                    # both sizes run the tiled point path
+    for lr, fn in enumerate(SMOOTHERS):
+        lv.e.copy_(torch.from_numpy(e0))
+        lv.smooth(lr, 2)
+        got = lv.e.cpu().numpy()
+        want = _oracle_sweeps(fn, vm, grid, s, e0, 2, tiled)
+        assert relerr(got, want) < 2e-12, (shape, fn)
+        lv._factors.pop(lr, None)                   # free the 5 GB of line factors per direction
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('shape,lr', [
+    ((128, 96, 96), 1), ((96, 128, 96), 2), ((96, 96, 130), 3),        # 16 lines / workgroup, partial-LDS records
+    ((256, 96, 96), 1), ((96, 258, 96), 2), ((96, 96, 256), 3),        # records in the global scratch
+    ((130, 6, 10), 1), ((6, 256, 10), 2), ((10, 6, 129), 3),           # long lines, few of them (4 lines / workgroup)
+])
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_long_line_record_modes_vs_oracle(shape, lr, dtype):
+    """Line directions of 128 / 130 / 256 / 258 blocks: every record mode (VMODE 1 / 2 / 0) and
+    lines-per-workgroup choice of the fused line kernel at the line lengths of the 128^3 and
+    256^3 levels, at a size the oracle sweeps in a second; nu = 3, per call, 2e-12."""
+    rng = np.random.default_rng(sum(shape) + lr)
+    h = [rng.uniform(5., 15., n) * 1.02 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, 0.7 if dtype is complex else -0.7, *sig)
+    s, e0 = mg_ref.Field(grid, dtype=dtype), mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    fn = SMOOTHERS[lr]
+    a, b = e0.copy(), e0.copy()
+    args = (s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
+    getattr(ocore, fn)(a.fx, a.fy, a.fz, *args, order=1)
+    getattr(core, fn)(b.fx, b.fy, b.fz, *args)
+    assert relerr(b.field, a.field) < 2e-12, (shape, fn)
+
+
+def test_marine128_one_cycle_vs_oracle_same_order():
+    """BASELINE.json config 2 itself (bench.py workload 'marine128'): ONE F-cycle with
+    semicoarsening and line relaxation on the GPU against the oracle's multigrid driver run in the
+    same smoother ordering -- every level, transfer and smoother call of the cycle the bench
+    times; fields after the cycle agree to 1e-10 and the residual norms to 1e-9."""
+    from bench import workload
+    wl = workload('marine128')
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-30, maxit=1, return_info=True, **wl['opts'])
+    assert info['it_mg'] == 1
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in wl['res'].items()}
+    vm = mg_ref.volume_model(ogrid, wl['frequency'], cond['property_x'], None, cond['property_z'])
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-30, maxit=1, order=1, **wl['opts'])
+    assert io['it_mg'] == 1
+    assert relerr(e.field, eo.field) < 1e-10
+    assert info['abs_error'] == pytest.approx(io['abs_error'], rel=1e-9)
+    assert info['smoother_cell_sweeps'] == io['smooth_work']
+
+
+@pytest.mark.parametrize('name', ['salt96', 'triaxial64'])
+def test_bench_workloads_converged_vs_oracle(name):
+    """Reduced copies of BASELINE.json configs 5 (salt-like, isotropic, F-cycle + sc + lr) and 3
+    (tri-axial blocky model, W-cycle + sc + lr), exactly as bench.py builds them: converged GPU
+    field vs the oracle in the reference's lexicographic order, both at tol 1e-10 -> 1e-8."""
+    from bench import workload
+    wl = workload(name)
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **wl['opts'])
+    assert info['exit'] == 0, info['exit_message']
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in wl['res'].items()}
+    vm = mg_ref.volume_model(ogrid, wl['frequency'], cond['property_x'], cond.get('property_y'),
+                             cond.get('property_z'))
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **wl['opts'])
+    assert io['exit'] == 0
+    assert relerr(e.field, eo.field) < 1e-8
+    assert abs(info['it_mg'] - io['it_mg']) <= 4
