@@ -96,7 +96,7 @@ class Workspace:
 class DeviceLevel:
     """One grid level resident in HBM."""
 
-    def __init__(self, grid, case, eta_x, eta_y, eta_z, zeta, dtype, work, device, batch=1):
+    def __init__(self, grid, case, eta_x, eta_y, eta_z, zeta, dtype, work, device, batch=1, flags=None):
         self.grid = grid
         self.batch = int(batch)     # right-hand sides that share this level's model and factors
         self.case = case
@@ -126,6 +126,14 @@ class DeviceLevel:
             _ptr(eta_x), _ptr(eta_y), _ptr(eta_z), _ptr(zeta),
             _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]), self.batch, 0, n)
         self._cref = ctypes.byref(self._c)
+        if flags is None:
+            # the finest level asks once (sums of purely imaginary eta stay purely imaginary:
+            # coarse levels inherit the answer)
+            res = ctypes.c_int(0)
+            _lib.check(_lib.lib().emg3d_dev_eta_is_imaginary(self._cref, ctypes.byref(res), _stream()),
+                       'emg3d_dev_eta_is_imaginary')
+            flags = _lib.LEVEL_ETA_IMAG if res.value else 0
+        self.flags = self._c.flags = int(flags)
         work.need_ws(_lib.lib().emg3d_residual_ws_len(nx, ny, nz) * self.batch)
         if self.batch > 1 and work.sumsq.numel() < self.batch:
             work.sumsq = torch.zeros(self.batch, dtype=torch.float64, device=device)
@@ -196,16 +204,19 @@ class DeviceLevel:
         return self._factors[lr]
 
     def point_factors(self):
-        """Eta edge sums of the point smoother (emg3d_dev_point_setup), built on first use."""
-        if 0 not in self._factors:
-            lib = _lib.lib()
-            nx, ny, nz = self.grid.shape_cells
-            fac = torch.empty(lib.emg3d_point_fac_bytes(nx, ny, nz, self.is_complex),
-                              dtype=torch.uint8, device=self.device)
+        """Eta edge sums of the point smoother (emg3d_dev_point_setup), built on first use. Their
+        layout follows the sweep schedule of the level (option point_tile_min): kept per value of
+        that option."""
+        lib = _lib.lib()
+        key = ('point', lib.emg3d_get_option(b'point_tile_min'))
+        if key not in self._factors:
+            for k in [k for k in self._factors if isinstance(k, tuple) and k[0] == 'point']:
+                del self._factors[k]
+            fac = torch.empty(lib.emg3d_point_fac_bytes_lv(self._cref), dtype=torch.uint8, device=self.device)
             _lib.check(lib.emg3d_dev_point_setup(self._cref, _ptr(fac), _stream()),
                        'emg3d_dev_point_setup')
-            self._factors[0] = (fac, None)
-        return self._factors[0][0]
+            self._factors[key] = (fac, None)
+        return self._factors[key][0]
 
     def smooth(self, lr, nu):
         """nu sweeps of smoother lr (0 point, 1/2/3 x/y/z line) on (e, s)."""
@@ -248,7 +259,7 @@ class DeviceLevel:
         c = _lib.Level(nx, ny, nz, self.is_complex, *self.parts(x), *self.parts(self._zero),
                        _ptr(self.eta_x), _ptr(self.eta_y), _ptr(self.eta_z), _ptr(self.zeta),
                        _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]),
-                       self.batch, 0, self.grid.n_edges)
+                       self.batch, self.flags, self.grid.n_edges)
         _lib.check(lib.emg3d_dev_residual(ctypes.byref(c), *self.parts(out), None, 0, None,
                                           _stream()), 'emg3d_dev_residual')
         out.neg_()
@@ -287,7 +298,7 @@ class DeviceLevel:
                   if self.case in ('VTI', 'triaxial') else ceta_x)
         czeta = restrict_param(self.zeta, 0, torch.float64)
         clevel = DeviceLevel(cgrid, self.case, ceta_x, ceta_y, ceta_z, czeta, self.dtype,
-                             self.work, self.device, self.batch)
+                             self.work, self.device, self.batch, self.flags)
 
         # restriction weights (only for coarsened directions; others are never read) and
         # prolongation tables: all 1-D arrays of the link go up in ONE float64 and ONE int32

@@ -46,7 +46,7 @@ class Level(ctypes.Structure):
                 ('sx', _vp), ('sy', _vp), ('sz', _vp),
                 ('eta_x', _vp), ('eta_y', _vp), ('eta_z', _vp),
                 ('zeta', _vp), ('ihx', _vp), ('ihy', _vp), ('ihz', _vp),
-                ('batch', ctypes.c_int32), ('reserved', ctypes.c_int32), ('batch_stride', ctypes.c_int64)]
+                ('batch', ctypes.c_int32), ('flags', ctypes.c_int32), ('batch_stride', ctypes.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/emg3d_amd.h
@@ -66,6 +66,8 @@ SIGNATURES = {
     'emg3d_line_lfac_bytes': (_sz, [_ci] * 4),
     'emg3d_dev_line_setup': (_ci, [ctypes.POINTER(Level), _ci, _vp, _vp, _vp]),
     'emg3d_point_fac_bytes': (_sz, [_ci] * 4),
+    'emg3d_point_fac_bytes_lv': (_sz, [ctypes.POINTER(Level)]),
+    'emg3d_dev_eta_is_imaginary': (_ci, [ctypes.POINTER(Level), ctypes.POINTER(_ci), _vp]),
     'emg3d_dev_point_setup': (_ci, [ctypes.POINTER(Level), _vp, _vp]),
     'emg3d_dev_gauss_seidel': (_ci, [ctypes.POINTER(Level), _ci, _ci, _vp, _vp, _vp, _sz, _vp]),
     'emg3d_residual_ws_len': (_sz, [_ci] * 3),
@@ -82,6 +84,8 @@ SIGNATURES = {
     'emg3d_dev_linear_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _vp, _ci, _vp, _vp]),
     'emg3d_dev_volume_average': (_ci, [_vp] + [_ci] * 3 + [_vp] * 10 + [_ci] * 3 + [_vp, _vp]),
 }
+
+LEVEL_ETA_IMAG = 1      # emg3d_level.flags (include/emg3d_amd.h)
 
 _lib = None
 

@@ -55,6 +55,15 @@ EMG_HD double recip(double a) { return 1.0 / a; }
 EMG_HD double abs2(cplx a) { return a.re * a.re + a.im * a.im; }
 EMG_HD double abs2(double a) { return a * a; }
 
+EMG_HD double imag_of(cplx a) { return a.im; }
+EMG_HD double imag_of(double a) { return a; }
+EMG_HD double real_of(cplx a) { return a.re; }
+EMG_HD double real_of(double) { return 0.0; }      // a real field has no separate "real part of eta"
+// value whose stored half is v: a purely imaginary complex number, or the real number itself
+template <class T> EMG_HD T from_stored(double v);
+template <> EMG_HD double from_stored<double>(double v) { return v; }
+template <> EMG_HD cplx from_stored<cplx>(double v) { return cplx(0.0, v); }
+
 template <class T> EMG_HD T zero();
 template <> EMG_HD double zero<double>() { return 0.0; }
 template <> EMG_HD cplx zero<cplx>() { return cplx(0.0, 0.0); }

@@ -49,6 +49,7 @@ template <class T> emg::Level<T> to_level(const emg3d_level *lv)
     L.ihx = lv->ihx; L.ihy = lv->ihy; L.ihz = lv->ihz;
     L.batch = lv->batch > 1 ? lv->batch : 1;
     L.bstride = lv->batch > 1 ? (size_t)lv->batch_stride : 0;
+    L.flags = lv->flags;
     return L;
 }
 
@@ -83,6 +84,37 @@ int g_line_lds = 1;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
 
+// eta edge sums of the tiled point smoother: 8-byte storage (launch.h: tile_pst_*) for real
+// fields and for complex fields whose eta are purely imaginary (emg3d_level::flags)
+template <class T> bool pst_stored_half(int flags);
+template <> bool pst_stored_half<double>(int) { return true; }
+template <> bool pst_stored_half<cplx>(int flags) { return (flags & emg::LEVEL_ETA_IMAG) != 0; }
+
+// Opt a kernel in to more than 64 KB of dynamic LDS. The attribute belongs to the (kernel,
+// device) pair: remembered per device ordinal, so a process that drives several GPUs sets it on
+// each of them.
+hipError_t allow_lds(const void *kernel, size_t bytes)
+{
+    constexpr int MAXDEV = 64, MAXK = 64;
+    static const void *seen[MAXDEV][MAXK];
+    static size_t seen_bytes[MAXDEV][MAXK];
+    static int nseen[MAXDEV];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < MAXDEV) {
+        for (int i = 0; i < nseen[dev]; ++i)
+            if (seen[dev][i] == kernel && seen_bytes[dev][i] >= bytes) return hipSuccess;
+    }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < MAXDEV && nseen[dev] < MAXK) {
+        seen[dev][nseen[dev]] = kernel;
+        seen_bytes[dev][nseen[dev]] = bytes;
+        ++nseen[dev];
+    }
+    return e;
+}
+
 // ----------------------------------------------------------------------------- kernels --
 
 // Point smoother, one colour. colour = ((ix+iz)&1) | (((iy+iz)&1)<<1).
@@ -113,8 +145,10 @@ __device__ __forceinline__ void lds_barrier()
 // Point smoother, tiled schedule (launch.h): one workgroup = one tile of one tile colour;
 // the tile's edges live in LDS while the four node colours run on it. The model/source
 // inputs of the next colour's node are fetched while the current node is solved.
-template <class T, class TB, bool ST, bool BATCH>
-__global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const T *pst, emg::TilePair P,
+// ST: where the eta edge sums come from: 0 formed on the fly from eta; 2 tile-major buffer of
+// k_point_setup_tile, full values; 3 the same, stored halves (8 bytes: launch.h tile_pst_*).
+template <class T, class TB, int ST, bool BATCH>
+__global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const void *pst, emg::TilePair P,
                                                                   int colours, int nsteps)
 {
     // grid.z = (tiles of colour P.tc[0], then of P.tc[1]) [x right-hand sides if BATCH: a
@@ -133,9 +167,9 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
     extern __shared__ double2 tile_smem[];
     T *lds = reinterpret_cast<T *>(tile_smem);
     using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
-    const int x0 = 1 + ((tc & 1) + 2 * blockIdx.x) * TB::BX;
-    const int y0 = 1 + (((tc >> 1) & 1) + 2 * blockIdx.y) * TB::BY;
-    const int z0 = 1 + (((tc >> 2) & 1) + 2 * bz) * TB::BZ;
+    const int tx = (tc & 1) + 2 * blockIdx.x, ty = ((tc >> 1) & 1) + 2 * blockIdx.y, tz = ((tc >> 2) & 1) + 2 * bz;
+    const int x0 = 1 + tx * TB::BX, y0 = 1 + ty * TB::BY, z0 = 1 + tz * TB::BZ;
+    const int ntx = (L.nx - 1 + TB::BX - 1) / TB::BX, nty = (L.ny - 1 + TB::BY - 1) / TB::BY;
     const int t = threadIdx.x;
     emg::tile_load<T, TB>(L, lds, x0, y0, z0, t);
     lds_barrier();
@@ -145,13 +179,32 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
     for (int cc = 0; cc < nsteps; ++cc) {     // node colours, two bits each (4, or 7-8 for two fused sweeps)
         emg::PointIn<T> in;
         int ix, iy, iz;
-        const bool ok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, (colours >> (2 * cc)) & 3, t, ix, iy, iz);
+        const int colour = (colours >> (2 * cc)) & 3;
+        const bool ok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, colour, t, ix, iy, iz);
         const E ed(lds, x0, y0, z0);
-        emg::point_load<T, ST>(L, pst, emg::ZetaTile<E>{ed}, ix, iy, iz, in);
+        emg::point_load_zeta<T>(emg::ZetaTile<E>{ed}, ix, iy, iz, in);
+        emg::point_load_source<T>(L, ix, iy, iz, in);
+        if (ST == 0) emg::point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
+        else emg::tile_pst_load<T, TB, ST == 3>(pst, ntx, nty, tx, ty, tz, colour, t, in);
         if (ok) emg::point_update<T, E>(L, in, ed, ix, iy, iz);
         lds_barrier();
     }
     emg::tile_store<T, TB>(L, lds, x0, y0, z0, t);
+}
+
+// eta edge sums in tile-major order (launch.h: tile_pst_setup), one workgroup per tile
+template <class T, class TB, bool IMAG>
+__global__ __launch_bounds__(TB::THREADS) void k_point_setup_tile(emg::Level<T> L, void *pst)
+{
+    emg::tile_pst_setup<T, TB, IMAG>(L, pst, gridDim.x, gridDim.y, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
+}
+
+// does any of n complex values have a non-zero real part? (sets *flag)
+__global__ __launch_bounds__(256) void k_any_real_part(const cplx *a, size_t n, int *flag)
+{
+    bool any = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) any |= a[i].re != 0.0;
+    if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(flag, 1);
 }
 
 // Line smoothers (stencil.h: line_setup / line_rhs / line_forward / line_backward /
@@ -843,18 +896,10 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         };
         const size_t smem1 = ((size_t)lpw * lc.n0p * 5 + emg::LINE_DUMMY) * sizeof(T);
         const size_t smem2 = ((size_t)lpw * lc.n0p * 4 + emg::LINE_DUMMY) * sizeof(T);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu);
-            attr = true;
-        }
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, false>), lds_cu);
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false>), lds_cu);
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true>), lds_cu);
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true>), lds_cu);
 #define LC_LAUNCH(VM, SMEM)                                                                                              \
     do {                                                                                                                 \
         if (L.batch > 1)                                                                                                 \
@@ -901,7 +946,10 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             return fail(EMG3D_ERR_SCRATCH, "gauss_seidel: scratch buffer too small");
     }
     const bool tiled = emg::point_tiled(nx, ny, nz, g_point_tile_min);
-    const T *pst = lr == 0 ? (const T *)fac : nullptr;   // optional eta edge sums (emg3d_dev_point_setup)
+    // optional eta edge sums (emg3d_dev_point_setup): edge-shaped for the plain kernel, tile-major
+    // for the tiled one
+    const T *pst = (lr == 0 && !tiled) ? (const T *)fac : nullptr;
+    const hipStream_t st_ = st;
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;   // first sweep backward (reference emg3d/core.py:301,311)
@@ -909,25 +957,23 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             using TB = emg::PointTile;
             using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
             const size_t smem = E::LDS_BYTES;
-            static bool attr_set = false;
-            if (!attr_set) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, true, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, false, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, true, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gs_point_tile<T, TB, false, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr_set = true;
-            }
+            // eta sums: tile-major buffer (stored halves when the level's eta are purely imaginary
+            // or the field is real), or formed on the fly when fac == NULL
+            const int st = !fac ? 0 : (pst_stored_half<T>(L.flags) ? 3 : 2);
+            const void *kfn[2][3] = {
+                {(const void *)&k_gs_point_tile<T, TB, 0, false>, (const void *)&k_gs_point_tile<T, TB, 2, false>,
+                 (const void *)&k_gs_point_tile<T, TB, 3, false>},
+                {(const void *)&k_gs_point_tile<T, TB, 0, true>, (const void *)&k_gs_point_tile<T, TB, 2, true>,
+                 (const void *)&k_gs_point_tile<T, TB, 3, true>}};
+            const void *kern = kfn[L.batch > 1 ? 1 : 0][st == 0 ? 0 : st - 1];
+            HIP_TRY(allow_lds(kern, smem));
             // A sweep ends with the pair of tile colours the next sweep (opposite direction) starts
             // with, and nothing else runs in between: those tiles do the node colours of BOTH sweeps
             // on one LDS copy -- one load / store of the tile instead of two (1/8 of the traffic of
             // two sweeps) -- minus the node colour that would merely be repeated (skip_repeat).
             const bool fuse_next = g_tile_fuse && it + 1 < nu;
             for (int p = (g_tile_fuse && it > 0) ? 1 : 0; p < 4; ++p) {   // two complementary tile colours per launch
-                const emg::TilePair P = emg::tile_pair<TB>(nx, ny, nz, iback, p);
+                emg::TilePair P = emg::tile_pair<TB>(nx, ny, nz, iback, p);
                 const int gz = P.gz[0] + P.gz[1];
                 if (gz <= 0) continue;
                 int colours = emg::sweep_colours_packed(iback), nsteps = 4;
@@ -938,14 +984,9 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
                 }
                 const dim3 gb(P.gx[0] > P.gx[1] ? P.gx[0] : P.gx[1], P.gy[0] > P.gy[1] ? P.gy[0] : P.gy[1], gz * L.batch);
                 const dim3 tb(TB::THREADS);
-                if (pst && L.batch > 1)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, true>), gb, tb, smem, st, L, pst, P, colours, nsteps);
-                else if (pst)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, true, false>), gb, tb, smem, st, L, pst, P, colours, nsteps);
-                else if (L.batch > 1)
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, true>), gb, tb, smem, st, L, pst, P, colours, nsteps);
-                else
-                    hipLaunchKernelGGL((k_gs_point_tile<T, TB, false, false>), gb, tb, smem, st, L, pst, P, colours, nsteps);
+                const void *pstv = fac;
+                void *args[] = {(void *)&L, (void *)&pstv, (void *)&P, (void *)&colours, (void *)&nsteps};
+                HIP_TRY(hipLaunchKernel(kern, gb, tb, args, smem, st_));
             }
             continue;
         }
@@ -1196,21 +1237,74 @@ int emg3d_dev_line_setup(const emg3d_level *lv, int lr, void *fac, double *lfac,
                           : launch_line_setup<double>(lv, lr, fac, lfac, (hipStream_t)stream);
 }
 
-size_t emg3d_point_fac_bytes(int nx, int ny, int nz, int is_complex)
+static size_t point_fac_bytes(int nx, int ny, int nz, int is_complex, int flags)
 {
+    using TB = emg::PointTile;
+    if (emg::point_tiled(nx, ny, nz, g_point_tile_min)) {
+        const bool half = is_complex ? pst_stored_half<cplx>(flags) : true;
+        return emg::tile_pst_elems(nx, ny, nz, TB::BX, TB::BY, TB::BZ) * (half ? 8 : 16);
+    }
     const Sizes S(nx, ny, nz, is_complex);
     return (S.nex + S.ney + S.nez) * S.esz;
+}
+size_t emg3d_point_fac_bytes(int nx, int ny, int nz, int is_complex)
+{
+    return point_fac_bytes(nx, ny, nz, is_complex, 0);      // flags = 0: the larger layout
+}
+size_t emg3d_point_fac_bytes_lv(const emg3d_level *lv)
+{
+    return lv ? point_fac_bytes(lv->nx, lv->ny, lv->nz, lv->is_complex, lv->flags) : 0;
 }
 
 int emg3d_dev_point_setup(const emg3d_level *lv, void *fac, void *stream)
 {
     if (!lv || !fac) return fail(EMG3D_ERR_BADARG, "point_setup: bad argument");
     const hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(fac, 0, emg3d_point_fac_bytes(lv->nx, lv->ny, lv->nz, lv->is_complex), st));
+    if (emg::point_tiled(lv->nx, lv->ny, lv->nz, g_point_tile_min)) {
+        using TB = emg::PointTile;
+        const emg::TileCount n = emg::tile_count<TB>(lv->nx, lv->ny, lv->nz);
+        const dim3 g(n.x, n.y, n.z), b(TB::THREADS);
+        if (!lv->is_complex)
+            hipLaunchKernelGGL((k_point_setup_tile<double, TB, true>), g, b, 0, st, to_level<double>(lv), fac);
+        else if (pst_stored_half<cplx>(lv->flags))
+            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, true>), g, b, 0, st, to_level<cplx>(lv), fac);
+        else
+            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, false>), g, b, 0, st, to_level<cplx>(lv), fac);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    HIP_TRY(hipMemsetAsync(fac, 0, emg3d_point_fac_bytes_lv(lv), st));
     const dim3 g = d3(emg::cell_grid(lv->nx + 1, lv->ny + 1, lv->nz + 1)), b = d3(emg::cell_block());
     if (lv->is_complex) hipLaunchKernelGGL(k_point_setup<cplx>, g, b, 0, st, to_level<cplx>(lv), (cplx *)fac);
     else hipLaunchKernelGGL(k_point_setup<double>, g, b, 0, st, to_level<double>(lv), (double *)fac);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int emg3d_dev_eta_is_imaginary(const emg3d_level *lv, int *result, void *stream)
+{
+    if (!lv || !result) return fail(EMG3D_ERR_BADARG, "eta_is_imaginary: bad argument");
+    *result = 0;
+    if (!lv->is_complex) return 0;
+    const hipStream_t st = (hipStream_t)stream;
+    int *dflag = nullptr;
+    HIP_TRY(hipMalloc((void **)&dflag, sizeof(int)));
+    hipError_t e = hipMemsetAsync(dflag, 0, sizeof(int), st);
+    const size_t n = (size_t)lv->nx * lv->ny * lv->nz;
+    const void *done[3] = {nullptr, nullptr, nullptr};
+    const void *eta[3] = {lv->eta_x, lv->eta_y, lv->eta_z};
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+        if (eta[i] == done[0] || eta[i] == done[1]) continue;       // aliased arrays once
+        done[i] = eta[i];
+        hipLaunchKernelGGL(k_any_real_part, dim3(1024), dim3(256), 0, st, (const cplx *)eta[i], n, dflag);
+        e = hipGetLastError();
+    }
+    int h = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, dflag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dflag);
+    if (e != hipSuccess) return hipfail(e, "eta_is_imaginary");
+    *result = h == 0;
     return 0;
 }
 
@@ -1354,9 +1448,6 @@ int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx
     const size_t sb = emg3d_gs_scratch_bytes(lr, nx, ny, nz, is_complex);
     HIP_TRY(scr.alloc(sb));
     DevBuf dfac, dlfac;
-    HIP_TRY(dfac.alloc(lr ? emg3d_line_fac_bytes(lr, nx, ny, nz, is_complex)
-                          : emg3d_point_fac_bytes(nx, ny, nz, is_complex)));
-    HIP_TRY(dlfac.alloc(emg3d_line_lfac_bytes(lr, nx, ny, nz)));
     emg3d_level lv = {};
     lv.nx = nx; lv.ny = ny; lv.nz = nz; lv.is_complex = is_complex;
     lv.ex = dex.d; lv.ey = dey.d; lv.ez = dez.d;
@@ -1365,6 +1456,14 @@ int emg3d_core_gauss_seidel(int lr, void *ex, void *ey, void *ez, const void *sx
     lv.zeta = (const double *)dz.d;
     lv.ihx = (const double *)dhx.d; lv.ihy = (const double *)dhy.d; lv.ihz = (const double *)dhz.d;
     int rc = 0;
+    if (lr == 0) {
+        int imag = 0;
+        rc = emg3d_dev_eta_is_imaginary(&lv, &imag, nullptr);
+        if (rc) return rc;
+        lv.flags = imag ? EMG3D_LEVEL_ETA_IMAG : 0;
+    }
+    HIP_TRY(dfac.alloc(lr ? emg3d_line_fac_bytes(lr, nx, ny, nz, is_complex) : emg3d_point_fac_bytes_lv(&lv)));
+    HIP_TRY(dlfac.alloc(emg3d_line_lfac_bytes(lr, nx, ny, nz)));
     if (lr != 0) rc = emg3d_dev_line_setup(&lv, lr, dfac.d, (double *)dlfac.d, nullptr);
     else rc = emg3d_dev_point_setup(&lv, dfac.d, nullptr);
     if (rc) return rc;

@@ -238,6 +238,59 @@ EMG_HD void tile_colour(const Level<T> &L, const T *pst, T *lds, int x0, int y0,
     else point_load<T, false>(L, pst, zt, ix, iy, iz, in);
     point_update<T, E>(L, in, ed, ix, iy, iz);
 }
+// ---- eta edge sums in TILE-MAJOR order (tiled point smoother).
+// Stored in the edge-shaped arrays of point_setup_cell, the six sums of a node are strided
+// gathers: the nodes of one colour class sit two apart in x, so every colour step of a tile
+// uses half of each cache line it touches, and the four steps of a tile re-fetch the same
+// lines (the tiles in flight on an XCD exceed its L2). Here the sums are stored per (tile,
+// node colour, entry r = 0..5, thread t): a wave reads 64 consecutive values per entry, every
+// byte of the buffer is read exactly once per sweep. Each edge sum exists twice (once for
+// either end node) -- 96 B per node instead of 48 -- unless the level's eta are purely
+// imaginary (LEVEL_ETA_IMAG; real fields: always): then only that half is stored, 48 B per node.
+template <class TB> EMG_HD size_t tile_pst_index(int ntx, int nty, int tx, int ty, int tz, int colour, int r, int t)
+{
+    const size_t tile = (size_t)tx + (size_t)ntx * ((size_t)ty + (size_t)nty * tz);
+    return ((tile * 4 + colour) * 6 + r) * TB::THREADS + t;
+}
+inline size_t tile_pst_elems(int nx, int ny, int nz, int bx, int by, int bz)
+{
+    return (size_t)cdiv(nx - 1, bx) * cdiv(ny - 1, by) * cdiv(nz - 1, bz) * 6 * (size_t)(bx * by * bz);
+}
+// setup: thread t of the workgroup of tile (tx,ty,tz) writes the sums of its four nodes
+template <class T, class TB, bool IMAG>
+EMG_HD void tile_pst_setup(const Level<T> &L, void *pst, int ntx, int nty, int tx, int ty, int tz, int t)
+{
+    const int x0 = 1 + tx * TB::BX, y0 = 1 + ty * TB::BY, z0 = 1 + tz * TB::BZ;
+    for (int c = 0; c < 4; ++c) {
+        int ix, iy, iz;
+        const bool ok = tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, c, t, ix, iy, iz);
+        PointIn<T> in;
+        point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
+        for (int r = 0; r < 6; ++r) {
+            const size_t o = tile_pst_index<TB>(ntx, nty, tx, ty, tz, c, r, t);
+            const T v = ok ? in.st[r] : zero<T>();
+            if (IMAG) reinterpret_cast<double *>(pst)[o] = imag_of(v);
+            else reinterpret_cast<T *>(pst)[o] = v;
+        }
+    }
+}
+// smoother: the six sums of thread t's node of colour class `colour` in tile (tx,ty,tz)
+template <class T, class TB, bool IMAG>
+EMG_HD void tile_pst_load(const void *pst, int ntx, int nty, int tx, int ty, int tz, int colour, int t, PointIn<T> &in)
+{
+    const size_t o = tile_pst_index<TB>(ntx, nty, tx, ty, tz, colour, 0, t);
+#if !defined(__HIPCC__)
+    for (int r = 0; r < 6; ++r)
+#else
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#endif
+    {
+        if (IMAG) in.st[r] = from_stored<T>(reinterpret_cast<const double *>(pst)[o + (size_t)r * TB::THREADS]);
+        else in.st[r] = reinterpret_cast<const T *>(pst)[o + (size_t)r * TB::THREADS];
+    }
+}
+
 // Phase 3: write the edges attached to the tile's nodes back (the halo is read-only).
 template <class T, class TB>
 EMG_HD void tile_store(const Level<T> &L, const T *lds, int x0, int y0, int z0, int t)

@@ -33,7 +33,11 @@ template <class T> struct Level {
     // latency-bound whatever they carry, cost the same for `batch` sources as for one.
     int batch = 1;
     size_t bstride = 0;
+    int flags = 0;                     // emg3d_level::flags (LEVEL_ETA_IMAG)
 };
+// all eta values have a real part of exactly zero (diffusive approximation at a real
+// frequency: eta = -i omega mu0 sigma V): the eta edge sums are then stored as 8-byte doubles
+constexpr int LEVEL_ETA_IMAG = 1;
 template <class T> EMG_HD Level<T> source_level(Level<T> L, int b)
 {
     size_t o = (size_t)b * L.bstride;
@@ -341,17 +345,25 @@ template <class T, class Z> EMG_HD void point_load_zeta(const Z &zeta, int ix, i
     in.z[4] = zeta(ixm, iym, iz);  in.z[5] = zeta(ix, iym, iz);
     in.z[6] = zeta(ixm, iy, iz);   in.z[7] = zeta(ix, iy, iz);
 }
-// source and eta sums of the node's six edges (everything of PointIn that is not zeta)
-template <class T, bool ST>
-EMG_HD void point_load_model(const Level<T> &L, const T *pst, int ix, int iy, int iz, PointIn<T> &in)
+// source at the node's six edges
+template <class T> EMG_HD void point_load_source(const Level<T> &L, int ix, int iy, int iz, PointIn<T> &in)
 {
     const Axes<T, 0> A(L);
     const int ixm = ix - 1, iym = iy - 1, izm = iz - 1;
-    const int e0 = A.iex(ixm, iy, iz), e1 = A.iex(ix, iy, iz), e2 = A.iey(ix, iym, iz), e3 = A.iey(ix, iy, iz);
-    const int e4 = A.iez(ix, iy, izm), e5 = A.iez(ix, iy, iz);
-    in.s[0] = L.sx[e0]; in.s[1] = L.sx[e1]; in.s[2] = L.sy[e2]; in.s[3] = L.sy[e3];
-    in.s[4] = L.sz[e4]; in.s[5] = L.sz[e5];
+    in.s[0] = L.sx[A.iex(ixm, iy, iz)]; in.s[1] = L.sx[A.iex(ix, iy, iz)];
+    in.s[2] = L.sy[A.iey(ix, iym, iz)]; in.s[3] = L.sy[A.iey(ix, iy, iz)];
+    in.s[4] = L.sz[A.iez(ix, iy, izm)]; in.s[5] = L.sz[A.iez(ix, iy, iz)];
+}
+// eta sums of the node's six edges: from the edge-shaped arrays of point_setup_cell (ST), or
+// formed on the fly from eta (core.py:377-390) -- same order of additions, identical bits
+template <class T, bool ST>
+EMG_HD void point_load_eta(const Level<T> &L, const T *pst, int ix, int iy, int iz, PointIn<T> &in)
+{
+    const Axes<T, 0> A(L);
+    const int ixm = ix - 1, iym = iy - 1, izm = iz - 1;
     if (ST) {
+        const int e0 = A.iex(ixm, iy, iz), e1 = A.iex(ix, iy, iz), e2 = A.iey(ix, iym, iz), e3 = A.iey(ix, iy, iz);
+        const int e4 = A.iez(ix, iy, izm), e5 = A.iez(ix, iy, iz);
         const T *sty = pst + (size_t)L.nx * (L.ny + 1) * (L.nz + 1);
         const T *stz = sty + (size_t)(L.nx + 1) * L.ny * (L.nz + 1);
         in.st[0] = pst[e0]; in.st[1] = pst[e1]; in.st[2] = sty[e2]; in.st[3] = sty[e3];
@@ -372,6 +384,12 @@ EMG_HD void point_load_model(const Level<T> &L, const T *pst, int ix, int iy, in
                    ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ixm, iym, iz);
 #undef ETv
     }
+}
+template <class T, bool ST>
+EMG_HD void point_load_model(const Level<T> &L, const T *pst, int ix, int iy, int iz, PointIn<T> &in)
+{
+    point_load_source<T>(L, ix, iy, iz, in);
+    point_load_eta<T, ST>(L, pst, ix, iy, iz, in);
 }
 template <class T, bool ST, class Z>
 EMG_HD void point_load(const Level<T> &L, const T *pst, const Z &zeta, int ix, int iy, int iz, PointIn<T> &in)

@@ -73,9 +73,16 @@ typedef struct emg3d_level {
      * the same launches. Source b's buffers [ex|ey|ez] and [sx|sy|sz] start b * batch_stride
      * ELEMENTS behind source 0's (the pointers above). 0 or 1: a single source. */
     int32_t batch;
-    int32_t reserved;
+    int32_t flags;             /* EMG3D_LEVEL_* bits, 0 if unknown */
     int64_t batch_stride;
 } emg3d_level;
+
+/* emg3d_level::flags. ETA_IMAG: every eta value has a real part of exactly zero -- the
+ * diffusive approximation at a real frequency, eta = -i omega mu0 sigma V (emg3d/models.py:
+ * 677-678, epsilon_r is None). The tiled point smoother then keeps its eta edge sums as 8-byte
+ * values (half the bytes, identical results). Never required; a caller that does not know
+ * leaves it 0 or asks emg3d_dev_eta_is_imaginary. */
+#define EMG3D_LEVEL_ETA_IMAG 1
 
 int emg3d_version(void);
 const char *emg3d_last_error(void);
@@ -149,8 +156,17 @@ int emg3d_dev_line_setup(const emg3d_level *lv, int lr, void *fac, double *lfac,
  * shaped like ex|ey|ez) depend on the model only; computed once per level they replace 24
  * scattered eta loads per node by 6. Optional: emg3d_dev_gauss_seidel(lr = 0) forms the sums
  * on the fly when fac == NULL; both give identical bits. */
-size_t emg3d_point_fac_bytes(int nx, int ny, int nz, int is_complex);
+size_t emg3d_point_fac_bytes(int nx, int ny, int nz, int is_complex);   /* upper bound (flags = 0) */
+size_t emg3d_point_fac_bytes_lv(const emg3d_level *lv);                  /* exact, honours lv->flags */
 int emg3d_dev_point_setup(const emg3d_level *lv, void *fac, void *stream);
+/* On levels that use the tiled schedule (option "point_tile_min", which must not change between
+ * setup and use) the sums are laid out tile by tile, node colour by node colour, so that every
+ * colour step of a workgroup reads them as one dense stream and every byte once per sweep; each
+ * edge sum then exists twice (once per end node): 96 B per node, or 48 B with
+ * EMG3D_LEVEL_ETA_IMAG / real fields. Elsewhere: arrays shaped like ex|ey|ez.
+ *
+ * *result = 1 if all real parts of lv's eta arrays are exactly zero (synchronises `stream`). */
+int emg3d_dev_eta_is_imaginary(const emg3d_level *lv, int *result, void *stream);
 
 /* nu sweeps of the smoother lr (0 point, 1/2/3 line along x/y/z) on level lv.
  * fac/lfac: from emg3d_dev_line_setup for the same level and lr; for lr = 0 fac is the

@@ -8,6 +8,7 @@
 // package never loads it, and nothing here is reachable from emg3d_amd/.
 #include <cstddef>
 #include <cstdint>
+#include <type_traits>
 #include <vector>
 
 #include "../../emg3d_amd/csrc/launch.h"
@@ -30,29 +31,49 @@ int g_point_tile_min = 1 << 20;
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
 // kernels.hip (k_gs_point_tile), each workgroup's phases separated like its barriers
-template <class T> void gs_point_tiled(const emg::Level<T> &L, const T *pst, int iback)
+// pmode: 0 eta sums formed on the fly, 2 tile-major buffer with full values, 3 with stored halves
+template <class T> void gs_point_tiled(const emg::Level<T> &L, const void *pst, int pmode, int iback)
 {
     using TB = emg::PointTile;
     using E = emg::EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
     std::vector<T> lds(E::LDS_BYTES / sizeof(T) + 1);
     const int colours = emg::sweep_colours_packed(iback);
+    const emg::TileCount n = emg::tile_count<TB>(L.nx, L.ny, L.nz);
     for (int t8 = 0; t8 < 8; ++t8) {
         const int tc = emg::tile_colour_at(iback, t8);
         const emg::Dim3 g = emg::tile_grid<TB>(L.nx, L.ny, L.nz, tc);
         for (int bz = 0; bz < g.z; ++bz)
             for (int by = 0; by < g.y; ++by)
                 for (int bx = 0; bx < g.x; ++bx) {
-                    const int x0 = 1 + ((tc & 1) + 2 * bx) * TB::BX;
-                    const int y0 = 1 + (((tc >> 1) & 1) + 2 * by) * TB::BY;
-                    const int z0 = 1 + (((tc >> 2) & 1) + 2 * bz) * TB::BZ;
+                    const int tx = (tc & 1) + 2 * bx, ty = ((tc >> 1) & 1) + 2 * by, tz = ((tc >> 2) & 1) + 2 * bz;
+                    const int x0 = 1 + tx * TB::BX, y0 = 1 + ty * TB::BY, z0 = 1 + tz * TB::BZ;
                     for (auto &v : lds) v = T(1e300);   // LDS is not initialised on the GPU either
                     for (int t = 0; t < TB::THREADS; ++t) emg::tile_load<T, TB>(L, lds.data(), x0, y0, z0, t);
                     for (int cc = 0; cc < 4; ++cc)
-                        for (int t = 0; t < TB::THREADS; ++t)
-                            emg::tile_colour<T, TB>(L, pst, lds.data(), x0, y0, z0, (colours >> (2 * cc)) & 3, t);
+                        for (int t = 0; t < TB::THREADS; ++t) {     // the body of k_gs_point_tile's colour loop
+                            const int colour = (colours >> (2 * cc)) & 3;
+                            int ix, iy, iz;
+                            const bool ok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, colour, t, ix, iy, iz);
+                            const E ed(lds.data(), x0, y0, z0);
+                            emg::PointIn<T> in;
+                            emg::point_load_zeta<T>(emg::ZetaTile<E>{ed}, ix, iy, iz, in);
+                            emg::point_load_source<T>(L, ix, iy, iz, in);
+                            if (pmode == 0) emg::point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
+                            else if (pmode == 3) emg::tile_pst_load<T, TB, true>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
+                            else emg::tile_pst_load<T, TB, false>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
+                            if (ok) emg::point_update<T, E>(L, in, ed, ix, iy, iz);
+                        }
                     for (int t = 0; t < TB::THREADS; ++t) emg::tile_store<T, TB>(L, lds.data(), x0, y0, z0, t);
                 }
     }
+}
+template <class T> bool eta_purely_imaginary(const emg::Level<T> &L)
+{
+    const size_t n = (size_t)L.nx * L.ny * L.nz;
+    for (size_t i = 0; i < n; ++i)
+        if (emg::real_of(L.eta_x[i]) != 0.0 || emg::real_of(L.eta_y[i]) != 0.0 || emg::real_of(L.eta_z[i]) != 0.0)
+            return false;
+    return true;
 }
 
 template <class T> emg::Level<T> to_level(const LevelArgs *lv)
@@ -131,11 +152,30 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
         });
         pst = pstv.data();
     }
+    // tiled schedule: the tile-major buffer of k_point_setup_tile, with stored halves when the
+    // model allows it (nu = 1, 5, ...), with full values (nu = 3, 7, ...), or no buffer (even nu)
+    const bool tiled = lr == 0 && emg::point_tiled(nx, ny, nz, g_point_tile_min);
+    std::vector<double> tpst;
+    int pmode = 0;
+    if (tiled && (nu & 1)) {
+        using TB = emg::PointTile;
+        const bool half = std::is_same<T, double>::value || ((nu & 3) == 1 && eta_purely_imaginary<T>(L));
+        pmode = half ? 3 : 2;
+        const emg::TileCount n = emg::tile_count<TB>(nx, ny, nz);
+        tpst.assign(emg::tile_pst_elems(nx, ny, nz, TB::BX, TB::BY, TB::BZ) * (half ? 1 : 2), 0.0);
+        for (int tz = 0; tz < n.z; ++tz)
+            for (int ty = 0; ty < n.y; ++ty)
+                for (int tx = 0; tx < n.x; ++tx)
+                    for (int t = 0; t < TB::THREADS; ++t) {
+                        if (half) emg::tile_pst_setup<T, TB, true>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
+                        else emg::tile_pst_setup<T, TB, false>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
+                    }
+    }
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;
-        if (lr == 0 && emg::point_tiled(nx, ny, nz, g_point_tile_min)) {
-            gs_point_tiled<T>(L, pst, iback);
+        if (tiled) {
+            gs_point_tiled<T>(L, tpst.data(), pmode, iback);
             continue;
         }
         if (lr == 0) {

@@ -1134,7 +1134,7 @@ def test_full_size_per_sweep_parity_vs_oracle(shape, case):
 def test_long_line_record_modes_vs_oracle(shape, lr, dtype):
     """Line directions of 128 / 130 / 256 / 258 blocks: every record mode (VMODE 1 / 2 / 0) and
     lines-per-workgroup choice of the fused line kernel at the line lengths of the 128^3 and
-    256^3 levels, at a size the oracle sweeps in a second; nu = 3, per call, 2e-12."""
+    256^3 levels, at a size the oracle sweeps in a second; nu = 3, per call, 1e-11."""
     rng = np.random.default_rng(sum(shape) + lr)
     h = [rng.uniform(5., 15., n) * 1.02 ** np.abs(np.arange(n) - n // 2) for n in shape]
     grid = mg_ref.Grid(h, (0., 0., 0.))
@@ -1153,7 +1153,9 @@ def test_long_line_record_modes_vs_oracle(shape, lr, dtype):
     args = (s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
     getattr(ocore, fn)(a.fx, a.fy, a.fz, *args, order=1)
     getattr(core, fn)(b.fx, b.fy, b.fz, *args)
-    assert relerr(b.field, a.field) < 2e-12, (shape, fn)
+    # three sweeps of exact solves of lines of up to 258 blocks, eliminated from both ends
+    # here and from one end in the oracle: round-off of the two orders, not of the sweep order
+    assert relerr(b.field, a.field) < 1e-11, (shape, fn)
 
 
 def test_marine128_one_cycle_vs_oracle_same_order():

@@ -204,7 +204,7 @@ def test_point_tiled_schedule_matches_oracle_tile_order(shape, dtype):
         f[...] = 0
     emu.lib().emu_set_point_tile_min(1)
     try:
-        for nu in (1, 2):
+        for nu in (1, 2, 3):
             a, b = e0.copy(), e0.copy()
             ocore.gauss_seidel(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
                                vm.zeta, *grid.h, nu, order=2)

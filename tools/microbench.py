@@ -21,7 +21,7 @@ import emg3d_amd as emg3d                       # noqa: E402
 from bench import widths, BYTES_PER_CELL_SWEEP  # noqa: E402
 
 
-def make_level(n, case, stretch=1.03, shape=None):
+def make_level(n, case, stretch=1.03, shape=None, eta_real=False):
     shape = shape or (n, n, n)
     rng = np.random.default_rng(1)
     h = [widths(m // 2, m // 4, 25., stretch) for m in shape]
@@ -35,6 +35,8 @@ def make_level(n, case, stretch=1.03, shape=None):
     vm.grid, vm.case = grid, case
     sig = 10 ** rng.uniform(-1.5, 0.5, shape)
     vm.eta_x = np.asfortranarray(-smu0 * vol * sig)
+    if eta_real:            # as with epsilon_r given: eta gets a real part (16-byte eta sums)
+        vm.eta_x = np.asfortranarray(vm.eta_x + 1e-3 * np.abs(vm.eta_x.imag))
     vm.eta_y = np.asfortranarray(vm.eta_x / 1.5) if case == 'triaxial' else vm.eta_x
     vm.eta_z = np.asfortranarray(vm.eta_x / 2.5) if case in ('VTI', 'triaxial') else vm.eta_x
     vm.zeta = np.asfortranarray(vol)
@@ -75,6 +77,7 @@ def main():
     ap.add_argument('--slabs', default='0,2,4,8,16,32')
     ap.add_argument('--nu', type=int, default=2)
     ap.add_argument('--shape', default='', help='nx,ny,nz instead of n^3')
+    ap.add_argument('--eta-real', action='store_true', help='eta with a real part (as with epsilon_r)')
     ap.add_argument('--opt', action='append', default=[], help='library option name=value (repeatable)')
     args = ap.parse_args()
     lib = _lib.lib()
@@ -82,7 +85,7 @@ def main():
         k, v = o.split('=')
         assert lib.emg3d_set_option(k.encode(), int(v)) == 0, o
     shape = tuple(int(x) for x in args.shape.split(',')) if args.shape else None
-    lv, grid = make_level(args.n, args.case, shape=shape)
+    lv, grid = make_level(args.n, args.case, shape=shape, eta_real=args.eta_real)
     nc = grid.n_cells
     print(f"# {shape or args.n} {args.case}, nu={args.nu}")
     if args.what in ('point', 'all'):
