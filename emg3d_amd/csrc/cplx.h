@@ -52,6 +52,26 @@ EMG_HD cplx recip(cplx a)
 }
 EMG_HD double recip(double a) { return 1.0 / a; }
 
+// Reciprocal for the pivots of the point smoother's 6 x 6 systems: hardware estimate
+// (v_rcp_f64) + two Newton steps, 5 instructions and within an ulp or two of 1/a, instead of
+// the ~12-instruction correctly rounded IEEE division sequence -- six pivots per node.
+EMG_HD double recip_fast(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    return r;
+#else
+    return 1.0 / a;
+#endif
+}
+EMG_HD cplx recip_fast(cplx a)
+{
+    const double d = recip_fast(a.re * a.re + a.im * a.im);
+    return cplx(a.re * d, -a.im * d);
+}
+
 EMG_HD double abs2(cplx a) { return a.re * a.re + a.im * a.im; }
 EMG_HD double abs2(double a) { return a * a; }
 

@@ -81,6 +81,8 @@ int g_skip_repeat = 1;
 // tiled point smoother: the tiles where two consecutive sweeps meet run both on one LDS copy
 int g_tile_fuse = 1;
 int g_line_lds = 1;
+// tiled point smoother: software prefetch of the next colour step's inputs (0 none, 1 source, 2 source + eta sums)
+int g_point_prefetch = 0;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
 
@@ -147,7 +149,10 @@ __device__ __forceinline__ void lds_barrier()
 // inputs of the next colour's node are fetched while the current node is solved.
 // ST: where the eta edge sums come from: 0 formed on the fly from eta; 2 tile-major buffer of
 // k_point_setup_tile, full values; 3 the same, stored halves (8 bytes: launch.h tile_pst_*).
-template <class T, class TB, int ST, bool BATCH>
+// PF: software prefetch -- the global inputs (source; PF = 2: eta sums too) of the NEXT colour
+// step are requested before the current node is solved, so their latency overlaps the ~600
+// fp64 instructions of the 6x6 solve inside the wave, not only across waves.
+template <class T, class TB, int ST, bool BATCH, int PF>
 __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const void *pst, emg::TilePair P,
                                                                   int colours, int nsteps)
 {
@@ -171,23 +176,46 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
     const int x0 = 1 + tx * TB::BX, y0 = 1 + ty * TB::BY, z0 = 1 + tz * TB::BZ;
     const int ntx = (L.nx - 1 + TB::BX - 1) / TB::BX, nty = (L.ny - 1 + TB::BY - 1) / TB::BY;
     const int t = threadIdx.x;
+    const E ed(lds, x0, y0, z0);
+    auto node = [&](int cc, int &ix, int &iy, int &iz, int &colour) {
+        colour = (colours >> (2 * cc)) & 3;
+        return emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, colour, t, ix, iy, iz);
+    };
+    auto load_eta = [&](int ix, int iy, int iz, int colour, emg::PointIn<T> &in) {
+        if (ST == 0) emg::point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
+        else emg::tile_pst_load<T, TB, ST == 3>(pst, ntx, nty, tx, ty, tz, colour, t, in);
+    };
+    emg::PointIn<T> in;
+    int ix, iy, iz, colour;
+    bool ok = node(0, ix, iy, iz, colour);
+    if (PF >= 1) emg::point_load_source<T>(L, ix, iy, iz, in);      // issued ahead of the tile copy
+    if (PF >= 2) load_eta(ix, iy, iz, colour, in);
     emg::tile_load<T, TB>(L, lds, x0, y0, z0, t);
     lds_barrier();
     // two workgroups per CU (launch bounds: <= 256 registers, 2 x 79 KB of LDS): while one
     // waits for the inputs of its next node, the other one computes
 #pragma unroll 1
     for (int cc = 0; cc < nsteps; ++cc) {     // node colours, two bits each (4, or 7-8 for two fused sweeps)
-        emg::PointIn<T> in;
-        int ix, iy, iz;
-        const int colour = (colours >> (2 * cc)) & 3;
-        const bool ok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, colour, t, ix, iy, iz);
-        const E ed(lds, x0, y0, z0);
+        if (PF < 1) emg::point_load_source<T>(L, ix, iy, iz, in);
+        if (PF < 2) load_eta(ix, iy, iz, colour, in);
         emg::point_load_zeta<T>(emg::ZetaTile<E>{ed}, ix, iy, iz, in);
-        emg::point_load_source<T>(L, ix, iy, iz, in);
-        if (ST == 0) emg::point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
-        else emg::tile_pst_load<T, TB, ST == 3>(pst, ntx, nty, tx, ty, tz, colour, t, in);
+        // the next step's node and its global inputs (the last step asks for its own again)
+        emg::PointIn<T> nxt;
+        int jx, jy, jz, ncol;
+        const bool nok = node(min(cc + 1, nsteps - 1), jx, jy, jz, ncol);
+        if (PF >= 1) emg::point_load_source<T>(L, jx, jy, jz, nxt);
+        if (PF >= 2) load_eta(jx, jy, jz, ncol, nxt);
         if (ok) emg::point_update<T, E>(L, in, ed, ix, iy, iz);
         lds_barrier();
+        if (PF >= 1) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) in.s[r] = nxt.s[r];
+        }
+        if (PF >= 2) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) in.st[r] = nxt.st[r];
+        }
+        ix = jx; iy = jy; iz = jz; colour = ncol; ok = nok;
     }
     emg::tile_store<T, TB>(L, lds, x0, y0, z0, t);
 }
@@ -960,12 +988,15 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             // eta sums: tile-major buffer (stored halves when the level's eta are purely imaginary
             // or the field is real), or formed on the fly when fac == NULL
             const int st = !fac ? 0 : (pst_stored_half<T>(L.flags) ? 3 : 2);
-            const void *kfn[2][3] = {
-                {(const void *)&k_gs_point_tile<T, TB, 0, false>, (const void *)&k_gs_point_tile<T, TB, 2, false>,
-                 (const void *)&k_gs_point_tile<T, TB, 3, false>},
-                {(const void *)&k_gs_point_tile<T, TB, 0, true>, (const void *)&k_gs_point_tile<T, TB, 2, true>,
-                 (const void *)&k_gs_point_tile<T, TB, 3, true>}};
-            const void *kern = kfn[L.batch > 1 ? 1 : 0][st == 0 ? 0 : st - 1];
+            int pf = (g_point_prefetch >= 0 && g_point_prefetch <= 2) ? g_point_prefetch : 0;
+            if (st == 0 && pf > 1) pf = 1;      // 24 eta loads per node in flight twice do not fit the registers
+#define PT_ROW(B, PF_)                                                                                         \
+    {(const void *)&k_gs_point_tile<T, TB, 0, B, PF_>, (const void *)&k_gs_point_tile<T, TB, 2, B, PF_>,          \
+     (const void *)&k_gs_point_tile<T, TB, 3, B, PF_>}
+            const void *kfn[2][3][3] = {{PT_ROW(false, 0), PT_ROW(false, 1), PT_ROW(false, 2)},
+                                        {PT_ROW(true, 0), PT_ROW(true, 1), PT_ROW(true, 2)}};
+#undef PT_ROW
+            const void *kern = kfn[L.batch > 1 ? 1 : 0][pf][st == 0 ? 0 : st - 1];
             HIP_TRY(allow_lds(kern, smem));
             // A sweep ends with the pair of tile colours the next sweep (opposite direction) starts
             // with, and nothing else runs in between: those tiles do the node colours of BOTH sweeps
@@ -1184,6 +1215,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "skip_repeat")) { g_skip_repeat = value; return 0; }
     if (!std::strcmp(name, "tile_fuse")) { g_tile_fuse = value; return 0; }
     if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
+    if (!std::strcmp(name, "point_prefetch")) { g_point_prefetch = value; return 0; }
     if (!std::strcmp(name, "line_lpw")) {
         if (value != 0 && value != 4 && value != 8 && value != 16) return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8 or 16");
         g_line_lpw = value;
@@ -1201,6 +1233,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "skip_repeat")) return g_skip_repeat;
     if (name && !std::strcmp(name, "tile_fuse")) return g_tile_fuse;
     if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
+    if (name && !std::strcmp(name, "point_prefetch")) return g_point_prefetch;
     if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
     return -1;
 }

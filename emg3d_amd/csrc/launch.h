@@ -146,7 +146,7 @@ inline int sweep_colours_packed(int iback)
 // slots past the end of a box go to the spare LDS slot), so that a thread has its ~20
 // 16-byte loads in flight together. Box element e of each array is LDS element e.
 template <class T, class TB>
-EMG_HD void tile_load(const Level<T> &L, T *lds, int x0, int y0, int z0, int t)
+EMG_HD void tile_load_generic(const Level<T> &L, T *lds, int x0, int y0, int z0, int t)
 {
     using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
     const EdgesGlobal<T> g(L);
@@ -293,7 +293,7 @@ EMG_HD void tile_pst_load(const void *pst, int ntx, int nty, int tx, int ty, int
 
 // Phase 3: write the edges attached to the tile's nodes back (the halo is read-only).
 template <class T, class TB>
-EMG_HD void tile_store(const Level<T> &L, const T *lds, int x0, int y0, int z0, int t)
+EMG_HD void tile_store_generic(const Level<T> &L, const T *lds, int x0, int y0, int z0, int t)
 {
     using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
     const E ed(const_cast<T *>(lds), x0, y0, z0);
@@ -324,6 +324,164 @@ EMG_HD void tile_store(const Level<T> &L, const T *lds, int x0, int y0, int z0, 
         const int i = x0 + li, j = y0 + r % TB::BY, k = z0 - 1 + r / TB::BY;
         if (e < MZ && i <= x1 && j <= y1 && k <= z1) g.z(i, j, k) = ed.z(i, j, k);
     }
+}
+
+
+// ---- row-wise tile copies (tiles 32 nodes wide: THREADS = 32 * G).
+// The generic copies above decode a flat element number into (i, j, k) with divisions by the
+// box extents -- ~30 integer instructions per element, 1000 per thread and tile, a sixth of
+// the kernel's instruction issue. Here the 32 lanes of group g = t / 32 walk row j = g of every
+// plane of a box: the row index is the group, the plane index the loop counter, LDS offsets are
+// compile-time constants, the global address advances by the plane stride. The one or two
+// columns beyond the 32nd are copied by flat element number (2-3 elements per thread).
+template <class TB> struct TileRows {
+    static constexpr int G = TB::THREADS / 32;
+    static constexpr bool ok = TB::BX == 32 && TB::BY == 4 && TB::BZ == 6;      // (the load fence lists this tile's values)
+};
+// One box of RL x NJ x NK elements (x fastest) whose element (i,j,k) is the global element
+// (ox+i) + sj*(oy+j) + sk*(oz+k), valid while ox+i < lim_i, oy+j < lim_j, oz+k < lim_k. Element
+// numbers are 32-bit (the launcher checks that a component has fewer than 2^31 entries).
+// A thread owns NK "row" elements -- column t & 31 of row t >> 5 in every plane -- and PER
+// "extra" elements of the columns beyond the 32nd, taken by flat number.
+// (Free functions on plain arrays: with the walk wrapped in a struct, or with
+// __builtin_amdgcn_sched_barrier anywhere near, the compiler keeps the value arrays in scratch
+// memory.)
+struct BoxGeo { int ox, oy, oz, sj, sk, lim_i, lim_j, lim_k; };
+template <int RL, int NJ, int NK, class TB> struct BoxDims {
+    static constexpr int XC = RL > 32 ? RL - 32 : 1;
+    static constexpr int NX = (RL - 32) * NJ * NK, PER = (NX + TB::THREADS - 1) / TB::THREADS;
+    static constexpr int PERA = PER > 0 ? PER : 1;         // array extent (no zero-length arrays)
+};
+#if defined(__HIPCC__)
+#define EMG_UNROLL _Pragma("unroll")
+#else
+#define EMG_UNROLL
+#endif
+template <int RL, int NJ, int NK, class TB, class V>
+EMG_HD void box_load(const V *g, int t, const BoxGeo q, V (&rows)[NK], V (&extra)[BoxDims<RL, NJ, NK, TB>::PERA])
+{
+    using D = BoxDims<RL, NJ, NK, TB>;
+    const int li = t & 31, rg = t >> 5;
+    const bool rowok = rg < NJ && q.ox + li < q.lim_i && q.oy + rg < q.lim_j;
+    const int e0 = (q.ox + li) + q.sj * (q.oy + rg) + q.sk * q.oz;
+    EMG_UNROLL
+    for (int lk = 0; lk < NK; ++lk) {
+        const bool ok = rowok && q.oz + lk < q.lim_k;
+        rows[lk] = g[ok ? e0 + q.sk * lk : 0];             // elements that do not exist read element 0
+    }
+    EMG_UNROLL
+    for (int it = 0; it < D::PER; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int c = e % D::XC, r = e / D::XC, j = r % NJ, k = r / NJ, i = 32 + c;
+        const bool ok = e < D::NX && q.ox + i < q.lim_i && q.oy + j < q.lim_j && q.oz + k < q.lim_k;
+        extra[it] = g[ok ? (q.ox + i) + q.sj * (q.oy + j) + q.sk * (q.oz + k) : 0];
+    }
+}
+// into the LDS box (same extents); `spare` absorbs what a thread does not have
+template <int RL, int NJ, int NK, class TB, class V>
+EMG_HD void box_put(V *box, int spare, int t, const V (&rows)[NK], const V (&extra)[BoxDims<RL, NJ, NK, TB>::PERA])
+{
+    using D = BoxDims<RL, NJ, NK, TB>;
+    const int li = t & 31, rg = t >> 5;
+    EMG_UNROLL
+    for (int lk = 0; lk < NK; ++lk) box[rg < NJ ? li + RL * (rg + NJ * lk) : spare] = rows[lk];
+    EMG_UNROLL
+    for (int it = 0; it < D::PER; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int c = e % D::XC, r = e / D::XC, j = r % NJ, k = r / NJ, i = 32 + c;
+        box[e < D::NX ? i + RL * (j + NJ * k) : spare] = extra[it];
+    }
+}
+// from an LDS box of row length LI with LJ rows per plane, in which this box sits at offset
+// (DI, DJ, DK), to global memory
+template <int RL, int NJ, int NK, class TB, int LI, int LJ, int DI, int DJ, int DK, class V>
+EMG_HD void box_store(V *g, const V *box, int t, const BoxGeo q)
+{
+    using D = BoxDims<RL, NJ, NK, TB>;
+    const int li = t & 31, rg = t >> 5;
+    const bool rowok = rg < NJ && q.ox + li < q.lim_i && q.oy + rg < q.lim_j;
+    const int e0 = (q.ox + li) + q.sj * (q.oy + rg) + q.sk * q.oz;
+    EMG_UNROLL
+    for (int lk = 0; lk < NK; ++lk)
+        if (rowok && q.oz + lk < q.lim_k) g[e0 + q.sk * lk] = box[(li + DI) + LI * ((rg + DJ) + LJ * (lk + DK))];
+    EMG_UNROLL
+    for (int it = 0; it < D::PER; ++it) {
+        const int e = t + it * TB::THREADS;
+        const int c = e % D::XC, r = e / D::XC, j = r % NJ, k = r / NJ, i = 32 + c;
+        if (e < D::NX && q.ox + i < q.lim_i && q.oy + j < q.lim_j && q.oz + k < q.lim_k)
+            g[(q.ox + i) + q.sj * (q.oy + j) + q.sk * (q.oz + k)] = box[(i + DI) + LI * ((j + DJ) + LJ * (k + DK))];
+    }
+}
+
+template <class T> EMG_HD double first_word(const T &v);
+template <> EMG_HD double first_word<double>(const double &v) { return v; }
+template <> EMG_HD double first_word<cplx>(const cplx &v) { return v.re; }
+
+template <class T, class TB>
+EMG_HD void tile_load_rows(const Level<T> &L, T *lds, int x0, int y0, int z0, int t)
+{
+    using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+    constexpr int BX = TB::BX, BY = TB::BY, BZ = TB::BZ;
+    static_assert(BZ == 6 && BoxDims<BX + 2, BY + 2, BZ + 1, TB>::PER == 1 && BoxDims<BX + 2, BY + 1, BZ + 2, TB>::PER == 1,
+                  "the load fence below lists the values of a 32 x 4 x 6 tile");
+    const int ox = x0 - 1, oy = y0 - 1, oz = z0 - 1;
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    T rx[BZ + 2], qx[BoxDims<BX + 1, BY + 2, BZ + 2, TB>::PERA];
+    T ry[BZ + 2], qy[BoxDims<BX + 2, BY + 1, BZ + 2, TB>::PERA];
+    T rz[BZ + 1], qz[BoxDims<BX + 2, BY + 2, BZ + 1, TB>::PERA];
+    double rc[BZ + 1], qc[BoxDims<BX + 1, BY + 1, BZ + 1, TB>::PERA];
+    box_load<BX + 1, BY + 2, BZ + 2, TB>(L.ex, t, BoxGeo{ox, oy, oz, nx, nx * (ny + 1), nx, ny + 1, nz + 1}, rx, qx);
+    box_load<BX + 2, BY + 1, BZ + 2, TB>(L.ey, t, BoxGeo{ox, oy, oz, nx + 1, (nx + 1) * ny, nx + 1, ny, nz + 1}, ry, qy);
+    box_load<BX + 2, BY + 2, BZ + 1, TB>(L.ez, t, BoxGeo{ox, oy, oz, nx + 1, (nx + 1) * (ny + 1), nx + 1, ny + 1, nz}, rz, qz);
+    box_load<BX + 1, BY + 1, BZ + 1, TB>(L.zeta, t, BoxGeo{ox, oy, oz, nx, nx * ny, nx, ny, nz}, rc, qc);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Load fence: every load is issued before the first LDS store. Left alone, the instruction
+    // scheduler sinks the loads of a box below the stores of the previous one (fewer live
+    // registers) and the copy becomes a chain of four memory latencies instead of one. The empty
+    // asm statements consume one word of every loaded value and produce `dep` (always 0), which
+    // the LDS addresses depend on: the loads cannot sink below them, the stores cannot rise above.
+#define FW(x) "v"(first_word<T>(x))
+    int dep = 0;
+    asm volatile("" : "+v"(dep) : FW(rx[0]), FW(rx[1]), FW(rx[2]), FW(rx[3]), FW(rx[4]), FW(rx[5]), FW(rx[6]), FW(rx[7]), FW(qx[0]),
+                 FW(ry[0]), FW(ry[1]), FW(ry[2]), FW(ry[3]), FW(ry[4]), FW(ry[5]), FW(ry[6]), FW(ry[7]), FW(qy[0]));
+    asm volatile("" : "+v"(dep) : FW(rz[0]), FW(rz[1]), FW(rz[2]), FW(rz[3]), FW(rz[4]), FW(rz[5]), FW(rz[6]), FW(qz[0]),
+                 "v"(rc[0]), "v"(rc[1]), "v"(rc[2]), "v"(rc[3]), "v"(rc[4]), "v"(rc[5]), "v"(rc[6]), "v"(qc[0]));
+#undef FW
+    lds += dep;
+#endif
+    box_put<BX + 1, BY + 2, BZ + 2, TB>(lds, E::ELEMS, t, rx, qx);
+    box_put<BX + 2, BY + 1, BZ + 2, TB>(lds + E::NXE, E::ELEMS - E::NXE, t, ry, qy);
+    box_put<BX + 2, BY + 2, BZ + 1, TB>(lds + E::NXE + E::NYE, E::ELEMS - E::NXE - E::NYE, t, rz, qz);
+    box_put<BX + 1, BY + 1, BZ + 1, TB>(reinterpret_cast<double *>(lds + E::LDS_ELEMS), E::NZC, t, rc, qc);
+}
+// the edges attached to the tile's nodes (three boxes inside the LDS boxes) go back
+template <class T, class TB>
+EMG_HD void tile_store_rows(const Level<T> &L, const T *lds, int x0, int y0, int z0, int t)
+{
+    using E = EdgesTile<T, TB::BX, TB::BY, TB::BZ>;
+    constexpr int BX = TB::BX, BY = TB::BY, BZ = TB::BZ;
+    const int nx = L.nx, ny = L.ny;
+    // one past the last node of the tile: an edge is written if its (i,j,k) lies below these
+    const int xe = (x0 + BX < L.nx ? x0 + BX : L.nx), ye = (y0 + BY < L.ny ? y0 + BY : L.ny);
+    const int ze = (z0 + BZ < L.nz ? z0 + BZ : L.nz);
+    // ex: i = x0-1 .. x0+BX-1, j = y0 .., k = z0 ..: LDS box position (i, j+1, k+1)
+    box_store<BX + 1, BY, BZ, TB, BX + 1, BY + 2, 0, 1, 1>(L.ex, lds, t, BoxGeo{x0 - 1, y0, z0, nx, nx * (ny + 1), xe, ye, ze});
+    // ey: i = x0 .., j = y0-1 .. y0+BY-1, k = z0 ..: LDS box position (i+1, j, k+1)
+    box_store<BX, BY + 1, BZ, TB, BX + 2, BY + 1, 1, 0, 1>(L.ey, lds + E::NXE, t,
+                                                           BoxGeo{x0, y0 - 1, z0, nx + 1, (nx + 1) * ny, xe, ye, ze});
+    // ez: i = x0 .., j = y0 .., k = z0-1 .. z0+BZ-1: LDS box position (i+1, j+1, k)
+    box_store<BX, BY, BZ + 1, TB, BX + 2, BY + 2, 1, 1, 0>(L.ez, lds + E::NXE + E::NYE, t,
+                                                           BoxGeo{x0, y0, z0 - 1, nx + 1, (nx + 1) * (ny + 1), xe, ye, ze});
+}
+template <class T, class TB> EMG_HD void tile_load(const Level<T> &L, T *lds, int x0, int y0, int z0, int t)
+{
+    if constexpr (TileRows<TB>::ok) tile_load_rows<T, TB>(L, lds, x0, y0, z0, t);
+    else tile_load_generic<T, TB>(L, lds, x0, y0, z0, t);
+}
+template <class T, class TB> EMG_HD void tile_store(const Level<T> &L, const T *lds, int x0, int y0, int z0, int t)
+{
+    if constexpr (TileRows<TB>::ok) tile_store_rows<T, TB>(L, lds, x0, y0, z0, t);
+    else tile_store_generic<T, TB>(L, lds, x0, y0, z0, t);
 }
 
 // ---- line smoothers: (p,q) = transverse PHYSICAL node indices in memory order (p faster):

@@ -253,7 +253,7 @@ template <class T> EMG_HD void solve6(const T (&dg)[6], const double (&od)[6][6]
 #pragma unroll
         for (int k = 0; k < i; ++k)
             if (pt_nz(i, k)) d = nmad(u[k], Lm[i][k], d);
-        dinv[i] = recip(d);
+        dinv[i] = recip_fast(d);
     }
     // forward substitution, diagonal scaling, backward substitution (core.py:1597-1616)
 #pragma unroll
