@@ -108,7 +108,9 @@ template <class TB> inline Dim3 tile_grid(int nx, int ny, int nz, int tc)
 // the rule that selects the tiled schedule (and with it the sweep order) for a level
 inline bool point_tiled(int nx, int ny, int nz, int tile_min)
 {
-    return tile_min > 0 && (long long)(nx - 1) * (ny - 1) * (nz - 1) >= tile_min;
+    // (the row-wise tile copies number the elements of a field component with 32 bits)
+    return tile_min > 0 && (long long)(nx - 1) * (ny - 1) * (nz - 1) >= tile_min &&
+           (long long)(nx + 1) * (ny + 1) * (nz + 1) < (1LL << 31);
 }
 // Tile colours in visiting order: 0,7,1,6,2,5,3,4 (backward: reversed). Consecutive pairs are
 // complementary colours (c, 7-c): their tiles differ in the parity of ALL three tile indices,

@@ -310,16 +310,16 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                 except BaseException as exc:      # surfaced after the join
                     errors.append(exc)
                     return
-        from emg3d_amd import solver as _solver
+        from emg3d_amd import _cycle
         threads = [threading.Thread(target=worker) for _ in range(min(per_gpu, len(mine)))]
-        _solver._CONCURRENT += 1          # no stream capture while several threads solve
+        _cycle.CONCURRENT += 1            # no stream capture while several threads solve
         try:
             for t in threads:
                 t.start()
             for t in threads:
                 t.join()
         finally:
-            _solver._CONCURRENT -= 1
+            _cycle.CONCURRENT -= 1
         if errors:
             raise errors[0]
     small = {k: {kk: vv for kk, vv in v[1].items() if kk not in ('log',)} for k, v in out.items()}

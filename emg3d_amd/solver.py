@@ -14,18 +14,19 @@ Differences from the reference that are intended:
   value is used (level 0, or ``verb > 4``);
 * coarse grids / models / weights are built once per (level, sc_dir) and reused.
 """
-import itertools
-import os
-import time
-from dataclasses import dataclass
-from datetime import datetime, timedelta
-from typing import Union
-
 import numpy as np
 import torch
 
-from emg3d_amd import _lib, fields, models
+from emg3d_amd import _cycle, _lib, fields, models
+from emg3d_amd._cycle import ConvergenceError as _ConvergenceError
+from emg3d_amd._cycle import current_lr_dir as _current_lr_dir
+from emg3d_amd._cycle import current_sc_dir as _current_sc_dir
+from emg3d_amd._cycle import one_liner as _print_one_liner
+from emg3d_amd._cycle import record_cycle as _print_cycle_info
+from emg3d_amd._cycle import smooth_level as _smooth
+from emg3d_amd._cycle import terminate as _terminate
 from emg3d_amd._device import DeviceLevel
+from emg3d_amd._params import MGParameters, Timer      # noqa: F401  (Timer: reference name utils.Timer)
 
 __all__ = ['solve', 'solve_batch', 'solve_source', 'multigrid', 'krylov', 'smoothing', 'restriction',
            'prolongation', 'residual', 'MGParameters', 'RegularGridProlongator']
@@ -35,30 +36,13 @@ def __dir__():
     return __all__
 
 
-class Timer:
-    """Wall-clock timer with the reference's attributes (emg3d/utils.py:169-197)."""
-
-    def __init__(self):
-        self._t0 = time.perf_counter()
-
-    @property
-    def t0(self):
-        return self._t0
-
-    @property
-    def now(self):
-        return datetime.now().strftime("%H:%M:%S")
-
-    @property
-    def elapsed(self):
-        return time.perf_counter() - self._t0
-
-    @property
-    def runtime(self):
-        return str(timedelta(seconds=np.round(self.elapsed)))
-
-
 # ------------------------------------------------------------------------------ solve ---
+# keywords of `solve` that are not solver settings: name -> default
+_SOLVE_EXTRAS = {'always_return': False, 'plain': False, 'efield': None, 'hierarchy': None,
+                 '_download': True,           # False: the result stays in hierarchy.top.e only
+                 '_sparse_source': False}     # the source goes up as its few non-zeros
+
+
 def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=True, verb=0,
           **kwargs):
     """Solver for three-dimensional electromagnetic diffusion on one MI355X.
@@ -79,137 +63,125 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
 
     Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``).
     """
-    always_return = kwargs.pop('always_return', False)
-    if kwargs.pop('plain', False):
-        sslsolver = False if sslsolver is True else sslsolver
-        semicoarsening = False if semicoarsening is True else semicoarsening
-        linerelaxation = False if linerelaxation is True else linerelaxation
-    efield = kwargs.pop('efield', None)
-    hierarchy = kwargs.pop('hierarchy', None)
-    download = bool(kwargs.pop('_download', True))     # False: the result stays in hierarchy.top.e only
-    sparse_source = bool(kwargs.pop('_sparse_source', False)) and getattr(sfield, '_sparse', None) is not None
-
-    var = MGParameters(sslsolver=sslsolver, semicoarsening=semicoarsening,
-                       linerelaxation=linerelaxation, shape_cells=model.shape, verb=verb,
-                       **kwargs)
-
+    extra = {name: kwargs.pop(name, default) for name, default in _SOLVE_EXTRAS.items()}
+    if extra['plain']:       # plain multigrid: whatever was left at its default is switched off
+        sslsolver, semicoarsening, linerelaxation = (
+            False if flag is True else flag for flag in (sslsolver, semicoarsening, linerelaxation))
+    var = MGParameters(verb, sslsolver, semicoarsening, linerelaxation, model.shape, **kwargs)
     var.cprint(f"\n:: emg3d START :: {var.time.now} :: emg3d_amd (MI355X)\n", 2)
     var.cprint(var, 2)
-
-    var.sparse_source = sparse_source
-    var.download = download
-    var.l2_refe = _host_norm(sfield._sparse[1] if sparse_source else sfield.field)
-    var.error_at_cycle[0] = var.l2_refe
 
     if sfield.frequency is None:
         raise ValueError(
             "Source field is missing frequency information; Create "
             "it with `emg3d.fields.get_source_field`, or initiate it "
             "with `emg3d.fields.Field`, providing frequency information.")
+    var.sparse_source = bool(extra['_sparse_source']) and getattr(sfield, '_sparse', None) is not None
+    var.download = bool(extra['_download'])
+    var.l2_refe = _host_norm(sfield._sparse[1] if var.sparse_source else sfield.field)
+    var.error_at_cycle[0] = var.l2_refe
 
     vmodel = models.VolumeModel(model, sfield)
-    info = ""
+    efield, note = _start_field(model, vmodel, sfield, extra['efield'], extra['always_return'], var)
+    if var.l2_refe < 100 * np.finfo(float).tiny:         # zero source: zero field
+        var.l2_refe = np.nan
+        note = _nothing_to_do(var, "   > RETURN ZERO E-FIELD (provided sfield is zero)\n")
+        efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
 
+    _log_table_head(var)
+    if extra['hierarchy'] is not None:
+        extra['hierarchy'].check(vmodel)
+    if var.sslsolver:
+        krylov(vmodel, sfield, efield, var, hierarchy=extra['hierarchy'])
+    elif var.cycle:
+        multigrid(vmodel, sfield, efield, var, hierarchy=extra['hierarchy'])
+    _log_summary(var, note)
+
+    out = []
+    if var.do_return:
+        out.append(efield)
+    if var.return_info:
+        out.append(_info_dict(var))
+    return out[0] if len(out) == 1 else (tuple(out) if out else None)
+
+
+def _nothing_to_do(var, note):
+    var.sslsolver = var.cycle = None
+    var.exit_message = "CONVERGED"
+    return note
+
+
+def _start_field(model, vmodel, sfield, efield, always_return, var):
+    """The field the iteration starts from (emg3d/solver.py:325-370): a new zero field, returned
+    at the end; or the caller's, updated in place after its PEC faces were zeroed -- and left
+    alone if it already satisfies the tolerance. Returns (efield, note for the log)."""
     if efield is None:
         efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
         efield._is_zero = True
         var.do_return = True
+        return efield, ""
+    if sfield.field.dtype != efield.field.dtype:
+        raise ValueError(
+            "Source field and electric field must have the same "
+            "dtype; complex (f-domain) or real (s-domain). Provided:"
+            f"sfield: {sfield.field.dtype}; efield: {efield.field.dtype}.")
+    if efield.frequency is None:
+        efield._frequency = sfield._frequency
+    # tangential components on the six boundary faces (PEC)
+    for comp, tangential_to in ((efield.fx, (1, 2)), (efield.fy, (0, 2)), (efield.fz, (0, 1))):
+        for axis in tangential_to:
+            face = [slice(None)] * 3
+            face[axis] = [0, -1]
+            comp[tuple(face)] = 0.
+    var.do_return = always_return
+    var.l2 = residual(vmodel, sfield, efield, True)
+    if var.l2 < var.tol * var.l2_refe:
+        return efield, _nothing_to_do(var, "   > NOTHING DONE (provided efield already good enough)\n")
+    return efield, ""
+
+
+def _log_table_head(var):
+    head = f"   [hh:mm:ss]  {'rel. error':<22}"
+    if var.sslsolver:
+        head += f"{'solver':<20}" + (f"{'MG':<11} l s" if var.cycle else "")
+    elif var.cycle:
+        head += f"{'[abs. error, last/prev]':>29}   l s"
     else:
-        if sfield.field.dtype != efield.field.dtype:
-            raise ValueError(
-                "Source field and electric field must have the same "
-                "dtype; complex (f-domain) or real (s-domain). Provided:"
-                f"sfield: {sfield.field.dtype}; efield: {efield.field.dtype}.")
-        if efield.frequency is None:
-            efield._frequency = sfield._frequency
+        return
+    var.cprint(head + "\n", 3)
 
-        # PEC boundary on the provided field (emg3d/solver.py:349-355)
-        efield.fx[:, 0, :] = efield.fx[:, -1, :] = 0.
-        efield.fx[:, :, 0] = efield.fx[:, :, -1] = 0.
-        efield.fy[0, :, :] = efield.fy[-1, :, :] = 0.
-        efield.fy[:, :, 0] = efield.fy[:, :, -1] = 0.
-        efield.fz[0, :, :] = efield.fz[-1, :, :] = 0.
-        efield.fz[:, 0, :] = efield.fz[:, -1, :] = 0.
-        var.do_return = always_return
 
-        var.l2 = residual(vmodel, sfield, efield, True)
-        if var.l2 < var.tol * var.l2_refe:
-            var.sslsolver = None
-            var.cycle = None
-            var.exit_message = "CONVERGED"
-            info = "   > NOTHING DONE (provided efield already good enough)\n"
-
-    if var.l2_refe < 100 * np.finfo(float).tiny:
-        var.l2_refe = np.nan
-        var.sslsolver = None
-        var.cycle = None
-        var.exit_message = "CONVERGED"
-        info = "   > RETURN ZERO E-FIELD (provided sfield is zero)\n"
-        efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
-
-    header = f"   [hh:mm:ss]  {'rel. error':<22}"
-    if var.sslsolver:
-        header += f"{'solver':<20}"
-        if var.cycle:
-            header += f"{'MG':<11} l s"
-        var.cprint(header + "\n", 3)
-    elif var.cycle:
-        var.cprint(header + f"{'[abs. error, last/prev]':>29}   l s\n", 3)
-
-    if hierarchy is not None:
-        hierarchy.check(vmodel)
-    if var.sslsolver:
-        krylov(vmodel, sfield, efield, var, hierarchy=hierarchy)
-    elif var.cycle:
-        multigrid(vmodel, sfield, efield, var, hierarchy=hierarchy)
-
-    exit_status = int(var.exit_message != 'CONVERGED')
-
-    if var.verb in [1, 2]:
+def _log_summary(var, note):
+    failed = var.exit_message != 'CONVERGED'
+    if var.verb in (1, 2):
         _print_one_liner(var, var.l2, True)
     elif var.verb > 2:
         if var.sslsolver:
-            info = f"   > Solver steps     : {var.ssl_it}\n"
+            note = f"   > Solver steps     : {var.ssl_it}\n"
             if var.cycle:
-                info += f"   > MG prec. steps   : {var.it}\n"
+                note += f"   > MG prec. steps   : {var.it}\n"
         elif var.cycle:
-            info = f"   > MG cycles        : {var.it}\n"
-        info += f"   > Final rel. error : {var.l2/var.l2_refe:.3e}\n\n"
-        info += f":: emg3d END   :: {var.time.now} :: "
-        info += f"runtime = {var.time.runtime}\n"
-        var.cprint(info, 2)
-    elif var.verb == 0 and exit_status == 1:
+            note = f"   > MG cycles        : {var.it}\n"
+        note += (f"   > Final rel. error : {var.l2/var.l2_refe:.3e}\n\n"
+                 f":: emg3d END   :: {var.time.now} :: runtime = {var.time.runtime}\n")
+        var.cprint(note, 2)
+    elif var.verb == 0 and failed:
         var.cprint(f"* WARNING :: {var.exit_message}", -1)
 
-    if var.return_info:
-        info_dict = _info_dict(var)
 
-    if var.do_return and var.return_info:
-        return efield, info_dict
-    elif var.do_return:
-        return efield
-    elif var.return_info:
-        return info_dict
+# keys of the info dict of `solve` (emg3d/solver.py:416-432) -> where the value comes from
+_INFO = (('exit', lambda v: int(v.exit_message != 'CONVERGED')), ('exit_message', lambda v: v.exit_message),
+         ('abs_error', lambda v: v.l2), ('rel_error', lambda v: v.l2 / v.l2_refe),
+         ('ref_error', lambda v: v.l2_refe), ('tol', lambda v: v.tol), ('it_mg', lambda v: v.it),
+         ('it_ssl', lambda v: v.ssl_it), ('time', lambda v: v.runtime_at_cycle[-1]),
+         ('runtime_at_cycle', lambda v: v.runtime_at_cycle), ('error_at_cycle', lambda v: v.error_at_cycle),
+         ('log', lambda v: v.log_message),
+         # addition of this package (not in the reference):
+         ('smoother_cell_sweeps', lambda v: v.smoother_cell_sweeps))
 
 
 def _info_dict(var):
-    """The info dict of ``solve`` (emg3d/solver.py:416-432)."""
-    return {
-        'exit': int(var.exit_message != 'CONVERGED'),
-        'exit_message': var.exit_message,
-        'abs_error': var.l2,
-        'rel_error': var.l2 / var.l2_refe,
-        'ref_error': var.l2_refe,
-        'tol': var.tol,
-        'it_mg': var.it,
-        'it_ssl': var.ssl_it,
-        'time': var.runtime_at_cycle[-1],
-        'runtime_at_cycle': var.runtime_at_cycle,
-        'error_at_cycle': var.error_at_cycle,
-        'log': var.log_message,
-        # additions of this package (not in the reference):
-        'smoother_cell_sweeps': var.smoother_cell_sweeps,
-    }
+    return {key: get(var) for key, get in _INFO}
 
 
 def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0, **kwargs):
@@ -339,10 +311,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
         sc_dir = _current_sc_dir(svar.sc_dir, lv.grid)
         lv.residual(store=True, norm=False)
         clv = lv.restrict_to(sc_dir)
-        if svar.verb < 5 and _USE_GRAPHS and _CONCURRENT == 0:
-            _coarse_correction_graphed(clv, svar, cycmax)
-        else:
-            _multigrid(clv, svar, 1, cycmax)
+        _cycle.coarse_correction(clv, svar, cycmax)       # eager, or the captured graph of this variant
         lv.prolong_from(sc_dir)
         if svar.nu_post > 0:
             _smooth(lv, svar.nu_post, svar.lr_dir, svar)
@@ -585,147 +554,20 @@ def multigrid(model, sfield, efield, var, **kwargs):
             hier.download(efield)
 
 
-def _smooth(lv, nu, lr_dir, var):
-    """solver.smoothing on a device level (emg3d/solver.py:788-846)."""
-    c = _current_lr_dir(lr_dir, lv.grid)
-    if c == 0:
-        lv.smooth(0, nu)
-    if c in (1, 5, 6, 7):
-        lv.smooth(1, nu)
-    if c in (2, 4, 6, 7):
-        lv.smooth(2, nu)
-    if c in (3, 4, 5, 7):
-        lv.smooth(3, nu)
-    ndir = {0: 1, 1: 1, 2: 1, 3: 1, 4: 2, 5: 2, 6: 2, 7: 3}[int(c)]
-    var.smoother_cell_sweeps += nu * ndir * lv.n_cells
-
-
-# The coarse-grid correction (everything below level 0) consists of hundreds of short,
-# launch-bound kernels whose sequence depends only on (sc_dir, lr_dir): it is captured once
-# per variant into a HIP graph and replayed (MI355X_MICROARCH.md: a dependent kernel
-# boundary costs ~1.5 us inside a graph against ~5-10 us of host time per eager launch).
-_USE_GRAPHS = os.environ.get('EMG3D_AMD_GRAPHS', '1') != '0'
-_GRAPH_AFTER = int(os.environ.get('EMG3D_AMD_GRAPH_AFTER', '2'))   # eager occurrences before capture
-# > 0 while several host threads solve on one GPU (parallel.compute(per_gpu > 1)): stream
-# capture is then off -- a synchronous copy in one thread is illegal while another captures
-_CONCURRENT = 0
-
-
-def _coarse_correction_graphed(clv, var, new_cycmax):
-    """_multigrid(clv, var, 1, new_cycmax) through a HIP graph, captured at its third
-    occurrence: the first, eager one builds all levels, factors and scratch it touches;
-    capturing costs about as much host time as an eager pass and pays off only for variants
-    that keep recurring (long solves, multigrid as a Krylov preconditioner, small grids whose
-    kernels are shorter than a host launch) -- a typical 6-cycle solve with three variants
-    never captures."""
-    cache = clv.__dict__.setdefault('_graphs', {})
-    key = (int(var.sc_dir), int(var.lr_dir), new_cycmax, var.cycle, var.nu_pre, var.nu_post,
-           var.nu_coarse, tuple(int(c) for c in var.clevel))
-    entry = cache.get(key)
-    if entry is None:                       # first time: eager, remember the work it does
-        w0 = var.smoother_cell_sweeps
-        _multigrid(clv, var, 1, new_cycmax)
-        cache[key] = {'work': var.smoother_cell_sweeps - w0, 'graph': None, 'seen': 1}
-        return
-    if entry['graph'] is None and entry['seen'] < _GRAPH_AFTER:
-        entry['seen'] += 1
-        _multigrid(clv, var, 1, new_cycmax)
-        return
-    if entry['graph'] is None:
-        w0 = var.smoother_cell_sweeps
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # thread_local: other host threads may be launching their own solves (parallel.compute
-        # with per_gpu > 1) while this one captures
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
-            _multigrid(clv, var, 1, new_cycmax)
-        var.smoother_cell_sweeps = w0       # capturing does not execute
-        entry['graph'] = g
-    entry['graph'].replay()
-    var.smoother_cell_sweeps += entry['work']
+_GRAPH_AFTER = _cycle.GRAPH_AFTER          # (read by bench.py / tools)
 
 
 def _multigrid(lv, var, level, new_cycmax):
-    """Recursive cycle on device levels; mirrors emg3d/solver.py:512-649."""
-    it = 0
-    if level == var.clevel[var.sc_dir]:
-        cycmax = 1
-    elif new_cycmax == 0 or var.cycle != 'F':
-        cycmax = var.cycmax
-    else:
-        cycmax = new_cycmax
-    cyc = 0
-
-    need_norm = level == 0 or var.verb > 4
-    l2_last = lv.residual(store=False, norm=True) if need_norm else 0.0
-    l2_stag = np.ones(var.maxcycle) * l2_last
-
-    if var.first_cycle and var.verb > 3:
-        var.level_all.append(level)
-
+    """Cycles on device levels: level 0 = the whole solve loop (``_cycle.run_cycles``), level >= 1
+    = one coarse-grid correction with the given visit budget (``_cycle.coarse_correction``)."""
     if level == 0:
-        var.cprint("     it cycmax               error", 4)
-        var.cprint("      level [  dimension  ]            info\n", 4)
-        if var.verb > 4:
-            _print_gs_info(var, it, level, cycmax, lv.grid, l2_last, "initial error")
+        _cycle.run_cycles(lv, var)
+    else:
+        _cycle.coarse_correction(lv, var, new_cycmax, first_level=level, graphed=False)
 
-    if level == 0 and var.nu_init > 0:
-        _smooth(lv, var.nu_init, var.lr_dir, var)
-        if var.verb > 4:
-            _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
-                           "initial smoothing")
 
-    while level == 0 or (level > 0 and it < cycmax):
-        l2_prev = l2_last
-        l2_stag[(it - 1) % var.maxcycle] = l2_last
-
-        if level == var.clevel[var.sc_dir]:            # (A) coarsest grid
-            _smooth(lv, var.nu_coarse, var.lr_dir, var)
-            if var.verb > 4:
-                _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
-                               "coarsest level")
-        else:                                          # (B) not yet coarsest
-            if var.nu_pre > 0:
-                _smooth(lv, var.nu_pre, var.lr_dir, var)
-                if var.verb > 4:
-                    _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
-                                   "pre-smoothing")
-            sc_dir = _current_sc_dir(var.sc_dir, lv.grid)
-            lv.residual(store=True, norm=False)
-            clv = lv.restrict_to(sc_dir)
-            if level == 0 and var.verb < 5 and _USE_GRAPHS and _CONCURRENT == 0:
-                _coarse_correction_graphed(clv, var, cycmax - cyc)
-            else:
-                _multigrid(clv, var, level + 1, cycmax - cyc)
-            lv.prolong_from(sc_dir)
-            if var.first_cycle and var.verb > 3:
-                var.level_all.append(level)
-            if var.nu_post > 0:
-                _smooth(lv, var.nu_post, var.lr_dir, var)
-                if var.verb > 4:
-                    _print_gs_info(var, it, level, cycmax, lv.grid, lv.residual(False, True),
-                                   "post-smoothing")
-
-        it += 1
-        if level == 0:
-            var.it += 1
-        if level > 0:
-            cyc += 1
-        else:
-            l2_last = lv.residual(store=False, norm=True)
-            _print_cycle_info(var, l2_last, l2_prev)
-            if var.sc_cycle:
-                var.sc_dir = next(var.sc_cycle)
-            if var.lr_cycle:
-                var.lr_dir = next(var.lr_cycle)
-            if getattr(var, 'fixed_cycles', None):     # benchmarking: exactly n cycles
-                if it >= var.fixed_cycles:
-                    break
-                continue
-            if _terminate(var, l2_last, l2_stag[(it - 1) % var.maxcycle], it):
-                break
-
-    var.l2 = l2_last
+def _coarse_correction_graphed(clv, var, new_cycmax):
+    _cycle.coarse_correction(clv, var, new_cycmax)
 
 
 # ----------------------------------------------------------------------------- krylov ---
@@ -987,170 +829,6 @@ def prolongation(efield, cefield, sc_dir):
     efield.field[:] = lv.e.cpu().numpy()
 
 
-# -------------------------------------------------------------------- MGParameters ------
-@dataclass
-class MGParameters:
-    """Multigrid solver settings and state (emg3d/solver.py:1074-1381)."""
-
-    verb: int
-    sslsolver: Union[str, bool]
-    semicoarsening: Union[int, bool]
-    linerelaxation: Union[int, bool]
-    shape_cells: tuple
-
-    cycle: Union[str, None] = 'F'
-    tol: float = 1e-6
-    maxit: int = 50
-    nu_init: int = 0
-    nu_pre: int = 2
-    nu_coarse: int = 1
-    nu_post: int = 2
-    clevel: int = -1
-    return_info: bool = False
-    log: int = 0
-
-    def __post_init__(self):
-        self.level_all = list()
-        self.first_cycle = True
-        self.it = 0
-        self.ssl_it = 0
-        self.l2 = 1.0
-        self.l2_refe = 1.0
-        self._max_level()
-
-        self.exit_message = ''
-        self.log_message = ''
-        self.time = Timer()
-        self.runtime_at_cycle = np.array([0.])
-        self.error_at_cycle = np.array([0.])
-        self.do_return = True
-        self.smoother_cell_sweeps = 0       # sum over smoother calls of nu * n_cells
-
-        self._semicoarsening()
-        self._linerelaxation()
-        self._solver_and_cycle()
-
-    def __repr__(self):
-        nc = self.shape_cells[0] * self.shape_cells[1] * self.shape_cells[2]
-        rc = self._repr_clevel
-        return (
-            f"   MG-cycle       : {self.cycle!r:17}   sslsolver : {self.sslsolver!r}\n"
-            f"   semicoarsening : {self._repr_sc_dir:17}   tol       : {self.tol}\n"
-            f"   linerelaxation : {self._repr_lr_dir:17}   maxit     : {self._repr_maxit}\n"
-            f"   nu_{{i,1,c,2}}   : {self.nu_init}, {self.nu_pre}, {self.nu_coarse}, "
-            f"{self.nu_post}          verb      : {self.verb}\n"
-            f"   Original grid  : {self.shape_cells[0]:3} x {self.shape_cells[1]:3} x "
-            f"{self.shape_cells[2]:3}     => {nc:,} cells\n"
-            f"   Coarsest grid  : {rc['shape_cells'][0]:3} x {rc['shape_cells'][1]:3} x "
-            f"{rc['shape_cells'][2]:3}     => {rc['n_cells']:,} cells\n"
-            f"   Coarsest level : {rc['clevel'][0]:3} ; {rc['clevel'][1]:3} ;"
-            f"{rc['clevel'][2]:4}   {rc['message']}\n")
-
-    def cprint(self, info, verbosity, **kwargs):
-        """Print and/or log ``info`` if ``self.verb > verbosity`` (solver.py:1181-1200)."""
-        if self.verb > verbosity:
-            if self.log != 0:
-                self.log_message += str(info) + '\n'
-            if self.log >= 0:
-                print(info, **kwargs)
-
-    def _max_level(self):
-        """Coarsening depth per semicoarsening direction (solver.py:1202-1270)."""
-        inp_clevel = np.inf if self.clevel < 0 else self.clevel
-        clevel = np.zeros(3, dtype=np.int64)
-        for i in range(3):
-            n = self.shape_cells[i]
-            while n % 2 == 0 and n > 2:
-                clevel[i] += 1
-                n /= 2
-        for i in range(3):
-            if -1 < self.clevel < clevel[i]:
-                clevel[i] = self.clevel
-        self.clevel = np.array([max(clevel), max(clevel[1], clevel[2]),
-                                max(clevel[0], clevel[2]), max(clevel[0], clevel[1])])
-
-        sx, sy, sz = (int(self.shape_cells[i] / 2 ** clevel[i]) for i in range(3))
-        self._repr_clevel = {'n_cells': sx * sy * sz, 'shape_cells': (sx, sy, sz),
-                             'clevel': clevel}
-        max_low = any(cl < inp_clevel and sl > 7 for cl, sl in zip(clevel, (sx, sy, sz)))
-        min_div = any(clevel < min(inp_clevel, 3))
-        self._repr_clevel['message'] = (
-            "  :: Grid not optimal for MG solver ::" if max_low or min_div else "")
-
-        if np.any(np.array(self.shape_cells) < 2):
-            raise ValueError(
-                "Nr. of cells must be at least two in each direction "
-                f"Provided shape: ({self.shape_cells[0]}, {self.shape_cells[1]}, "
-                f"{self.shape_cells[2]}).")
-
-    @staticmethod
-    def _parse_cycle(value, default, nmax, name):
-        """bool/int/multi-digit-int -> (cycle iterator or False, list of directions)."""
-        if value is True:
-            lst = np.array(default)
-            return itertools.cycle(lst), lst
-        if value in np.arange(nmax):
-            return False, np.array([int(value)])
-        lst = np.array([int(x) for x in str(abs(value))])
-        if np.any(lst < 0) or np.any(lst > nmax - 1):
-            if name == 'semicoarsening':
-                raise ValueError(
-                    "`semicoarsening` must be one of {False;True;0;1;2;3}. "
-                    "Or a combination of {0;1;2;3} to cycle, e.g. 1213. "
-                    f"Provided: {value}.")
-            raise ValueError(
-                "`linerelaxation` must be one of "
-                "{False;True;0;1;2;3;4;5;6;7}. Or a combination of "
-                "{1;2;3;4;5;6;7} to cycle, e.g. 1213. "
-                f"Provided: {value}.")
-        return itertools.cycle(lst), lst
-
-    def _semicoarsening(self):
-        """solver.py:1272-1304."""
-        self.sc_cycle, lst = self._parse_cycle(self.semicoarsening, [1, 2, 3], 4,
-                                               'semicoarsening')
-        self.sc_dir = next(self.sc_cycle) if self.sc_cycle else lst[0]
-        self.semicoarsening = self.sc_dir != 0
-        self._repr_sc_dir = f"{self.semicoarsening} {lst}"
-        self.raw_sc_cycle = lst
-
-    def _linerelaxation(self):
-        """solver.py:1306-1339."""
-        self.lr_cycle, lst = self._parse_cycle(self.linerelaxation, [4, 5, 6], 8,
-                                               'linerelaxation')
-        self.lr_dir = next(self.lr_cycle) if self.lr_cycle else lst[0]
-        self.linerelaxation = self.lr_dir != 0
-        self._repr_lr_dir = f"{self.linerelaxation} {lst}"
-        self.raw_lr_cycle = lst
-
-    def _solver_and_cycle(self):
-        """solver.py:1341-1381."""
-        solvers = ['bicgstab', 'cgs', 'gcrotmk']
-        if self.sslsolver is True:
-            self.sslsolver = 'bicgstab'
-        elif self.sslsolver is not False and self.sslsolver not in solvers:
-            raise ValueError(
-                f"`sslsolver` must be True, False, or one of {solvers}. "
-                f"Provided: {self.sslsolver!r}.")
-        if self.cycle not in ['F', 'V', 'W', None]:
-            raise ValueError(
-                "`cycle` must be one of {'F';'V';'W';None}. "
-                f"Provided: {self.cycle}.")
-        self.cycmax = 2 if self.cycle in ['F', 'W'] else 1
-        if not self.sslsolver and not self.cycle:
-            raise ValueError(
-                "At least `cycle` or `sslsolver` is required. Provided"
-                f"input: cycle={self.cycle}; sslsolver={self.sslsolver}.")
-        self.ssl_maxit = 0
-        self._repr_maxit = f"{self.maxit}"
-        self.maxcycle = max(len(self.raw_sc_cycle), len(self.raw_lr_cycle))
-        if self.sslsolver:
-            self.ssl_maxit = self.maxit
-            if self.cycle is not None:
-                self.maxit = self.maxcycle
-                self._repr_maxit += f" ({self.maxit})"
-
-
 class RegularGridProlongator:
     """Bilinear interpolation from a coarse to a fine 2-D tensor grid with precomputed
     weights (emg3d/solver.py:1385-1478). Host utility with the reference's call
@@ -1172,61 +850,6 @@ class RegularGridProlongator:
 
 
 # --------------------------------------------------------------------------- helpers ---
-def _current_sc_dir(sc_dir, grid):
-    """Semicoarsening code for this grid (emg3d/solver.py:1482-1531): a direction is
-    coarsened only if its cell count is even, > 2, and it is not the sc direction."""
-    n = grid.shape_cells
-    keep_x = n[0] % 2 != 0 or n[0] < 3 or sc_dir == 1
-    keep_y = n[1] % 2 != 0 or n[1] < 3 or sc_dir == 2
-    keep_z = n[2] % 2 != 0 or n[2] < 3 or sc_dir == 3
-    return {(False, False, False): 0, (True, False, False): 1, (False, True, False): 2,
-            (False, False, True): 3, (False, True, True): 4, (True, False, True): 5,
-            (True, True, False): 6, (True, True, True): 6}[(keep_x, keep_y, keep_z)]
-
-
-def _current_lr_dir(lr_dir, grid):
-    """Drop line relaxation along directions with only two cells
-    (emg3d/solver.py:1534-1588)."""
-    c = int(lr_dir)
-    n = grid.shape_cells
-    if n[0] == 2:
-        c = {1: 0, 5: 3, 6: 2, 7: 4}.get(c, c)
-    if n[1] == 2:
-        c = {2: 0, 4: 3, 6: 1, 7: 5}.get(c, c)
-    if n[2] == 2:
-        c = {3: 0, 4: 2, 5: 1, 7: 6}.get(c, c)
-    return c
-
-
-def _terminate(var, l2_last, l2_stag, it):
-    """Termination criteria of a multigrid cycle (emg3d/solver.py:1591-1664)."""
-    finished = False
-    sslabort = False
-    if l2_last < var.tol * var.l2_refe:
-        var.exit_message = "CONVERGED"
-        finished = True
-    elif l2_last > 10 * var.l2_refe or not np.isfinite(l2_last):
-        var.exit_message = "DIVERGED"
-        finished = True
-        sslabort = True
-    elif it > 2 and l2_last >= l2_stag:
-        var.exit_message = "STAGNATED"
-        finished = True
-        sslabort = True
-    elif it == var.maxit:
-        if not var.sslsolver:
-            var.exit_message = "MAX. ITERATION REACHED, NOT CONVERGED"
-        finished = True
-
-    if finished:
-        if var.sslsolver and sslabort:
-            raise _ConvergenceError
-        elif not var.sslsolver:
-            add = 50 * " " + "\r" if var.verb == 3 else ("\n" if var.verb < 5 else "")
-            var.cprint(add + "   > " + var.exit_message, 2)
-    return finished
-
-
 def _restrict_model_parameters(param, sc_dir):
     """Sum of the 2/4/8 fine cells (emg3d/solver.py:1667-1718), on the device."""
     from emg3d_amd._device import _ptr, _stream, coarsen_flags
@@ -1260,48 +883,3 @@ def _get_restriction_weights(grid, cgrid, sc_dir):
             z = np.zeros(grid.shape_nodes[d], dtype=np.float64)
             out.append((z, np.ones(grid.shape_nodes[d], dtype=np.float64), z))
     return tuple(out)
-
-
-class _ConvergenceError(Exception):
-    """Raised inside ``_terminate`` to abort a SciPy Krylov solver."""
-
-
-def _print_cycle_info(var, l2_last, l2_prev):
-    """Per-cycle bookkeeping and log line (emg3d/solver.py:1788-1862; the ASCII picture
-    of the first cycle is not reproduced)."""
-    var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
-    var.error_at_cycle = np.r_[var.error_at_cycle, l2_last]
-    if var.verb in [2, 3]:
-        _print_one_liner(var, l2_last)
-    if var.verb < 4:
-        return
-    info = "\n" if var.verb > 4 else ""
-    var.first_cycle = False
-    info += f"   [{var.time.now}]   {l2_last/var.l2_refe:.3e}  "
-    if var.sslsolver:
-        info += f"after {19*' '} {var.it:3} {var.cycle}-cycles "
-    else:
-        info += f"after {var.it:3} {var.cycle}-cycles   "
-        info += f"[{l2_last:.3e}, {l2_last/l2_prev:.3f}]"
-    info += f"   {var.lr_dir} {var.sc_dir}"
-    if var.verb > 4:
-        info += "\n"
-    var.cprint(info, 3)
-
-
-def _print_gs_info(var, it, level, cycmax, grid, norm, add):
-    """Log line after a smoothing step (emg3d/solver.py:1865-1892)."""
-    info = f"     {it:2} {level} {cycmax} [{grid.shape_cells[0]:3}, "
-    info += f"{grid.shape_cells[1]:3}, {grid.shape_cells[2]:3}]: {norm:.3e} "
-    var.cprint(info + add, 4)
-
-
-def _print_one_liner(var, l2_last, last=False):
-    """Continuously updated one-liner (emg3d/solver.py:1895-1919)."""
-    info = f":: emg3d :: {l2_last/var.l2_refe:.1e}; "
-    info += f"{var.ssl_it}({var.it}); " if var.sslsolver else f"{var.it}; "
-    info += f"{var.time.runtime}"
-    if last:
-        var.cprint(info + f"; {var.exit_message}", -100)
-    else:
-        var.cprint(info, -100, end='\r')

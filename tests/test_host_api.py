@@ -210,3 +210,61 @@ def test_get_restriction_weights_shapes():
     assert wx[0].size == cg.shape_nodes[0]
     assert wy[0].size == grid.shape_nodes[1] and np.all(wy[0] == 0) and np.all(wy[1] == 1)
     assert wz[1].size == grid.shape_nodes[2]
+
+
+def test_coarse_schedule_matches_recursive_definition():
+    """The flat visiting order of _cycle.coarse_schedule against the recursive definition of the
+    cycle (emg3d/solver.py:512-649: a level loops cycmax times, hands `cycmax - done` to the next
+    coarser level, the coarsest level is smoothed once) written out here as a plain recursion."""
+    from emg3d_amd._cycle import coarse_schedule, SMOOTH, DOWN, UP
+
+    def recurse(cycle, cycmax_all, depth, level, budget, out):
+        visits = 1 if level == depth else (cycmax_all if budget == 0 or cycle != 'F' else budget)
+        for done in range(visits):
+            if level == depth:
+                out.append((SMOOTH, level, 1, done, visits))
+            else:
+                out.append((SMOOTH, level, 2, done, visits))
+                out.append((DOWN, level))
+                recurse(cycle, cycmax_all, depth, level + 1, visits - done, out)
+                out.append((UP, level))
+                out.append((SMOOTH, level, 3, done, visits))
+
+    for cycle, cycmax in (('V', 1), ('W', 2), ('F', 2)):
+        for depth in (1, 2, 3, 6):
+            for budget in (1, 2):
+                want = []
+                recurse(cycle, cycmax, depth, 1, budget, want)
+                got = [(s[0], s[1]) + ((s[2], s[4], s[5]) if s[0] == SMOOTH else ())
+                       for s in coarse_schedule(cycle, cycmax, depth, 1, budget, 2, 1, 3) if s[0] in (SMOOTH, DOWN, UP)]
+                assert got == want, (cycle, depth, budget)
+    # number of coarsest-level visits: V 1, W 2^(depth-1), F depth (one more per level)
+    count = lambda c, m, d: sum(1 for s in coarse_schedule(c, m, d, 1, m, 2, 1, 2) if s[0] == SMOOTH and s[1] == d)
+    assert [count('V', 1, d) for d in (1, 2, 3, 4)] == [1, 1, 1, 1]
+    assert [count('W', 2, d) for d in (1, 2, 3, 4)] == [1, 2, 4, 8]
+    assert [count('F', 2, d) for d in (1, 2, 3, 4)] == [1, 2, 3, 4]
+
+
+def test_direction_schedule_and_stop_rules():
+    from emg3d_amd._params import _DirectionSchedule, coarsening_depths
+    from emg3d_amd._cycle import stop_reason
+    s = _DirectionSchedule(True, (1, 2, 3), 4, "{}")
+    assert s and len(s) == 3 and s.first() == 1 and [next(s) for _ in range(4)] == [2, 3, 1, 2]
+    s = _DirectionSchedule(2, (1, 2, 3), 4, "{}")
+    assert not s and s.first() == 2 and len(s) == 1
+    s = _DirectionSchedule(1213, (1, 2, 3), 4, "{}")
+    assert s and s.first() == 1 and [next(s) for _ in range(5)] == [2, 1, 3, 1, 2]
+    for bad in (4, 15, 'x'):
+        with pytest.raises(ValueError):
+            _DirectionSchedule(bad, (1, 2, 3), 4, "bad {}")
+    d, c = coarsening_depths((48, 20, 2), -1)
+    assert list(d) == [4, 2, 0] and c == (3, 5, 2)
+    d, c = coarsening_depths((48, 20, 2), 1)
+    assert list(d) == [1, 1, 0] and c == (24, 10, 2)
+
+    class V:
+        tol, l2_refe, maxit = 1e-3, 1.0, 4
+    assert stop_reason(V, 1e-4, 1, 1) == ("CONVERGED", False)
+    assert stop_reason(V, 11.0, 1, 1) == ("DIVERGED", True)
+    assert stop_reason(V, 0.5, 0.4, 3) == ("STAGNATED", True)
+    assert stop_reason(V, 0.5, 0.6, 4)[0].startswith("MAX.") and stop_reason(V, 0.5, 0.6, 3) is None
