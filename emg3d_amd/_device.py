@@ -249,21 +249,35 @@ class DeviceLevel:
             return float(np.sqrt(w.sumsq[0].item()))
         return None
 
+    def _level_on(self, e, s):
+        """The level's C struct with other field / source vectors in place of e / s."""
+        nx, ny, nz = self.grid.shape_cells
+        return _lib.Level(nx, ny, nz, self.is_complex, *self.parts(e), *self.parts(s),
+                          _ptr(self.eta_x), _ptr(self.eta_y), _ptr(self.eta_z), _ptr(self.zeta),
+                          _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]),
+                          self.batch, self.flags, self.grid.n_edges)
+
     def apply_A(self, x, out):
         """out = A x for a vector x laid out like a field (the Krylov operator of
         emg3d/solver.py:686-702: core.amat_x into a zero field, negated)."""
-        lib = _lib.lib()
-        if getattr(self, '_zero', None) is None:
-            self._zero = torch.zeros(self.grid.n_edges * self.batch, dtype=self.dtype, device=self.device)
-        nx, ny, nz = self.grid.shape_cells
-        c = _lib.Level(nx, ny, nz, self.is_complex, *self.parts(x), *self.parts(self._zero),
-                       _ptr(self.eta_x), _ptr(self.eta_y), _ptr(self.eta_z), _ptr(self.zeta),
-                       _ptr(self.ih[0]), _ptr(self.ih[1]), _ptr(self.ih[2]),
-                       self.batch, self.flags, self.grid.n_edges)
-        _lib.check(lib.emg3d_dev_residual(ctypes.byref(c), *self.parts(out), None, 0, None,
-                                          _stream()), 'emg3d_dev_residual')
-        out.neg_()
+        c = self._level_on(x, x)
+        _lib.check(_lib.lib().emg3d_dev_apply_operator(ctypes.byref(c), *self.parts(out), _stream()),
+                   'emg3d_dev_apply_operator')
         return out
+
+    def residual_sumsq(self, x, b):
+        """sum |b - A x|^2 as a device tensor (no synchronisation): the true residual of a Krylov
+        iterate, without copying x / b into the level's own buffers."""
+        c = self._level_on(x, b)
+        w = self.work
+        _lib.check(_lib.lib().emg3d_dev_residual(ctypes.byref(c), None, None, None, _ptr(w.ws), w.ws.numel(),
+                                                 _ptr(w.sumsq), _stream()), 'emg3d_dev_residual')
+        return w.sumsq
+
+    def zero_field(self):
+        """e <- 0 (hipMemsetAsync on the stream)."""
+        _lib.check(_lib.lib().emg3d_dev_zero(_ptr(self.e), self.e.numel() * self.e.element_size(), _stream()),
+                   'emg3d_dev_zero')
 
     def pec_zero(self):
         nx, ny, nz = self.grid.shape_cells
@@ -341,7 +355,7 @@ class DeviceLevel:
         _lib.check(_lib.lib().emg3d_dev_restrict_batch(
             *c.parts(c.s), *self.parts(self.r), *link['wptr'], nx, ny, nz, sc_dir,
             self.is_complex, self.batch, self.grid.n_edges, c.grid.n_edges, _stream()), 'emg3d_dev_restrict')
-        c.e.zero_()
+        c.zero_field()
         return c
 
     def prolong_from(self, sc_dir):

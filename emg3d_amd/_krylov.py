@@ -1,0 +1,204 @@
+"""Device BiCGSTAB and CGS around the multigrid preconditioner.
+
+The reference hands ``scipy.sparse.linalg.bicgstab / cgs / gcrotmk`` a host ``LinearOperator``
+and a host preconditioner (emg3d/solver.py:652-784). Here the vectors never leave HBM: every
+update and inner product is one ``emg3d_dev_krylov_step`` (csrc/krylov.h), the recurrence
+scalars live in a small device table, and the host reads that table only where the algorithm
+branches -- twice per BiCGSTAB iteration, together with the true residual norm the reference's
+callback reports. Iteration, breakdown tests, stopping rule ``|r| <= max(atol, rtol |b|)`` and
+return codes are those of SciPy >= 1.12 (``rtol=tol, atol=1e-30, maxiter=maxit``): 0 converged,
+> 0 iteration limit, -10 / -11 breakdown (rho / omega or rt.v vanish).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from emg3d_amd import _lib
+from emg3d_amd._device import _ptr, _stream
+
+_vp = ctypes.c_void_p
+DIV, MUL, NEG, COPY = 0, 1, 2, 3           # scalar instructions of emg3d_dev_krylov_step
+
+
+class Vectors:
+    """Work vectors of one Krylov solve on the device of ``top`` + the scalar table."""
+
+    NSLOTS = 32
+
+    def __init__(self, top):
+        self.top = top
+        self.n = top.e.numel()
+        self.is_complex = top.is_complex
+        self.table = torch.zeros(2 * self.NSLOTS, dtype=torch.float64, device=top.device)
+        self.ws = torch.empty(_lib.lib().emg3d_krylov_ws_len(), dtype=torch.float64, device=top.device)
+        self._names = {}
+        self._host = torch.empty(2 * self.NSLOTS, dtype=torch.float64).pin_memory()
+
+    def new(self):
+        return torch.empty(self.n, dtype=self.top.dtype, device=self.top.device)
+
+    def slot(self, name):
+        if name not in self._names:
+            self._names[name] = len(self._names)
+            assert len(self._names) <= self.NSLOTS
+        return self._names[name]
+
+    def step(self, y=None, terms=(), dots=(), prog=()):
+        """y = sum coef * x over ``terms`` = [(x, coef)], coef a slot name, a float, or
+        (slot name, float); ``dots`` = [(slot name, a, b)] -> table[slot] = conj(a) . b (with the new
+        y); ``prog`` = [(op, dst, a, b)] with slot names (b may be None)."""
+        nt, nd, npg = len(terms), len(dots), len(prog)
+        xs = (_vp * max(nt, 1))()
+        slots = (ctypes.c_int * max(nt, 1))()
+        scales = (ctypes.c_double * max(nt, 1))()
+        for i, (x, coef) in enumerate(terms):
+            xs[i] = x.data_ptr()
+            if isinstance(coef, tuple):
+                slots[i], scales[i] = self.slot(coef[0]), float(coef[1])
+            elif isinstance(coef, str):
+                slots[i], scales[i] = self.slot(coef), 1.0
+            else:
+                slots[i], scales[i] = -1, float(coef)
+        das, dbs = (_vp * max(nd, 1))(), (_vp * max(nd, 1))()
+        dslots = (ctypes.c_int * max(nd, 1))()
+        for k, (name, a, b) in enumerate(dots):
+            das[k], dbs[k], dslots[k] = a.data_ptr(), b.data_ptr(), self.slot(name)
+        pr = (ctypes.c_int * max(4 * npg, 1))()
+        for i, (op, dst, a, b) in enumerate(prog):
+            pr[4 * i:4 * i + 4] = [op, self.slot(dst), self.slot(a), -1 if b is None else self.slot(b)]
+        _lib.check(_lib.lib().emg3d_dev_krylov_step(
+            self.n, self.is_complex, _ptr(y) if y is not None else None, nt, xs, slots, scales, nd, das, dbs, dslots,
+            npg, pr, _ptr(self.table), _ptr(self.ws), self.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
+
+    def read(self, *names, extra=None):
+        """Table entries (complex, or float for real fields) on the host: ONE synchronising copy,
+        which also brings ``extra`` (a small device tensor, e.g. a residual sum of squares)."""
+        self._host.copy_(self.table, non_blocking=True)
+        ex = extra.to('cpu', non_blocking=True) if extra is not None else None
+        torch.cuda.current_stream().synchronize()
+        h = self._host.numpy()
+        out = []
+        for nm in names:
+            s = self.slot(nm)
+            out.append(complex(h[2 * s], h[2 * s + 1]) if self.is_complex else float(h[2 * s]))
+        return (out, ex.numpy().copy()) if extra is not None else out
+
+    def copy(self, dst, src):
+        _lib.check(_lib.lib().emg3d_dev_copy(_ptr(dst), _ptr(src), src.numel() * src.element_size(), _stream()),
+                   'emg3d_dev_copy')
+
+
+def _preconditioner(top, var, run_cycles, vec):
+    """out <- M vec: multigrid cycles on (source = vec, field = 0); identity without a cycle."""
+    def apply(src, out):
+        if not var.cycle:
+            vec.copy(out, src)
+            return
+        vec.copy(top.s, src)
+        top.zero_field()
+        run_cycles(top, var)            # maxit = one round of the direction schedule (solver.py:1376-1381)
+        vec.copy(out, top.e)
+    return apply
+
+
+def bicgstab(hier, b, x, var, run_cycles, callback):
+    """Preconditioned BiCGSTAB (van der Vorst 1992). ``b``, ``x``: device vectors (x is updated
+    in place). ``callback(l2)`` after every iteration with the true residual norm. Returns the
+    SciPy status code."""
+    top = hier.top
+    V = Vectors(top)
+    psolve = _preconditioner(top, var, run_cycles, V)
+    r, v, t, p, phat, shat, rt = (V.new() for _ in range(7))
+    eps = np.finfo(np.float64).eps
+    rhotol = omegatol = eps ** 2
+
+    top.apply_A(x, r)
+    V.step(r, [(b, 1.0), (r, -1.0)], dots=[('bb', b, b)])
+    V.copy(rt, r)
+    V.step(None, dots=[('rr', r, r), ('rho', rt, r)])
+    bb, rr, rho = V.read('bb', 'rr', 'rho')
+    atol = max(1e-30, var.tol * np.sqrt(abs(bb)))
+    omega = alpha = 1.0
+    for iteration in range(var.ssl_maxit):
+        if np.sqrt(abs(rr)) < atol:
+            return 0
+        if abs(rho) < rhotol:
+            return -10
+        if iteration > 0:
+            if abs(omega) < omegatol:
+                return -11
+            V.step(p, [(r, 1.0), (p, 'beta'), (v, 'nbo')])      # p = r + beta (p - omega v)
+        else:
+            V.copy(p, r)
+        psolve(p, phat)
+        top.apply_A(phat, v)
+        # alpha = rho / (rt . v);  s = r - alpha v  (kept in r)
+        V.step(None, dots=[('rv', rt, v)], prog=[(DIV, 'alpha', 'rho', 'rv'), (NEG, 'nalpha', 'alpha', None)])
+        V.step(r, [(r, 1.0), (v, 'nalpha')], dots=[('ss', r, r)])
+        rv, ss, alpha = V.read('rv', 'ss', 'alpha')
+        if rv == 0:
+            return -11
+        if np.sqrt(abs(ss)) < atol:
+            V.step(x, [(x, 1.0), (phat, 'alpha')])
+            return 0
+        psolve(r, shat)
+        top.apply_A(shat, t)
+        # omega = (t . s) / (t . t);  x += alpha phat + omega shat;  r = s - omega t
+        V.step(None, dots=[('ts', t, r), ('tt', t, t)],
+               prog=[(DIV, 'omega', 'ts', 'tt'), (NEG, 'nomega', 'omega', None)])
+        V.step(x, [(x, 1.0), (phat, 'alpha'), (shat, 'omega')])
+        V.step(r, [(r, 1.0), (t, 'nomega')], dots=[('rr', r, r), ('rho_next', rt, r)],
+               prog=[(DIV, 'q1', 'rho_next', 'rho'), (DIV, 'q2', 'alpha', 'omega'), (MUL, 'beta', 'q1', 'q2'),
+                     (MUL, 'bo', 'beta', 'omega'), (NEG, 'nbo', 'bo', None), (COPY, 'rho', 'rho_next', None)])
+        sumsq = top.residual_sumsq(x, b)                 # the reference's callback: |b - A x|
+        (rr, rho, omega), l2 = V.read('rr', 'rho', 'omega', extra=sumsq)
+        callback(float(np.sqrt(l2[0])))
+    return var.ssl_maxit
+
+
+def cgs(hier, b, x, var, run_cycles, callback):
+    """Preconditioned CGS (Sonneveld 1989), as scipy.sparse.linalg.cgs iterates."""
+    top = hier.top
+    V = Vectors(top)
+    psolve = _preconditioner(top, var, run_cycles, V)
+    r, rt, u, p, q, phat, vhat, uhat, tmp = (V.new() for _ in range(9))
+    eps = np.finfo(np.float64).eps
+    rhotol = eps ** 2
+
+    top.apply_A(x, r)
+    V.step(r, [(b, 1.0), (r, -1.0)], dots=[('bb', b, b)])
+    V.copy(rt, r)
+    V.step(None, dots=[('rr', r, r), ('rho', rt, r)])
+    bb, rr, rho = V.read('bb', 'rr', 'rho')
+    atol = max(1e-30, var.tol * np.sqrt(abs(bb)))
+    if np.sqrt(abs(bb)) == 0:
+        return 0
+    for iteration in range(var.ssl_maxit):
+        if np.sqrt(abs(rr)) < atol:
+            return 0
+        if abs(rho) < rhotol:
+            return -10
+        if iteration > 0:
+            V.step(u, [(r, 1.0), (q, 'beta')])                   # u = r + beta q
+            V.step(p, [(u, 1.0), (q, 'beta'), (p, 'beta2')])     # p = u + beta (q + beta p)
+        else:
+            V.copy(p, r)
+            V.copy(u, r)
+        psolve(p, phat)
+        top.apply_A(phat, vhat)
+        V.step(None, dots=[('rv', rt, vhat)], prog=[(DIV, 'alpha', 'rho', 'rv'), (NEG, 'nalpha', 'alpha', None)])
+        V.step(q, [(u, 1.0), (vhat, 'nalpha')])                  # q = u - alpha vhat
+        V.step(tmp, [(u, 1.0), (q, 1.0)])
+        rv, = V.read('rv')
+        if rv == 0:
+            return -11
+        psolve(tmp, uhat)
+        V.step(x, [(x, 1.0), (uhat, 'alpha')])
+        # SciPy recomputes the residual from x (error build-up of the recurrence r -= alpha A uhat)
+        top.apply_A(x, tmp)
+        V.step(r, [(b, 1.0), (tmp, -1.0)], dots=[('rr', r, r), ('rho_next', rt, r)],
+               prog=[(DIV, 'beta', 'rho_next', 'rho'), (MUL, 'beta2', 'beta', 'beta'), (COPY, 'rho', 'rho_next', None)])
+        rr, rho = V.read('rr', 'rho')
+        callback(float(np.sqrt(abs(rr))))          # = |b - A x|, what the reference's callback evaluates
+    return var.ssl_maxit

@@ -1579,3 +1579,4 @@ int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex)
 }  // extern "C"
 
 #include "receivers.h"
+#include "krylov.h"

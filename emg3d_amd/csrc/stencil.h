@@ -114,6 +114,86 @@ template <class T, int DIR> struct Axes {
     }
 };
 
+// The three values of extended cell (ix,iy,iz), ix < nx etc. (the entries core.amat_x touches):
+//   SRC:  r = s - A e   (solver.residual)            !SRC:  r = -A e   (the Krylov operator)
+template <class T, bool SRC>
+EMG_HD void residual_values(const Level<T> &L, int ix, int iy, int iz, T &ox, T &oy, T &oz)
+{
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    (void)nx; (void)ny; (void)nz;
+    const Axes<T, 0> A(L);
+    const int ixm = ix > 0 ? ix - 1 : 0, iym = iy > 0 ? iy - 1 : 0, izm = iz > 0 ? iz - 1 : 0;
+    const int ixp = ix + 1, iyp = iy + 1, izp = iz + 1;
+    const double hx1 = L.ihx[ix], hx0 = L.ihx[ixm];
+    const double hy1 = L.ihy[iy], hy0 = L.ihy[iym];
+    const double hz1 = L.ihz[iz], hz0 = L.ihz[izm];
+#define EXv(i, j, k) L.ex[A.iex(i, j, k)]
+#define EYv(i, j, k) L.ey[A.iey(i, j, k)]
+#define EZv(i, j, k) L.ez[A.iez(i, j, k)]
+#define ZT(i, j, k) L.zeta[A.icc(i, j, k)]
+    const T ex_c = EXv(ix, iy, iz), ey_c = EYv(ix, iy, iz), ez_c = EZv(ix, iy, iz);
+    // 1. curl on the faces around the three edges (core.py:136-155)
+    T v1pp = (EZv(ix, iyp, iz) - ez_c) * hy1 - (EYv(ix, iy, izp) - ey_c) * hz1;
+    T v1mp = (ez_c - EZv(ix, iym, iz)) * hy0 - (EYv(ix, iym, izp) - EYv(ix, iym, iz)) * hz1;
+    T v1pm = (EZv(ix, iyp, izm) - EZv(ix, iy, izm)) * hy1 - (ey_c - EYv(ix, iy, izm)) * hz0;
+
+    T v2pp = (EXv(ix, iy, izp) - ex_c) * hz1 - (EZv(ixp, iy, iz) - ez_c) * hx1;
+    T v2mp = (EXv(ixm, iy, izp) - EXv(ixm, iy, iz)) * hz1 - (ez_c - EZv(ixm, iy, iz)) * hx0;
+    T v2pm = (ex_c - EXv(ix, iy, izm)) * hz0 - (EZv(ixp, iy, izm) - EZv(ix, iy, izm)) * hx1;
+
+    T v3pp = (EYv(ixp, iy, iz) - ey_c) * hx1 - (EXv(ix, iyp, iz) - ex_c) * hy1;
+    T v3mp = (ey_c - EYv(ixm, iy, iz)) * hx0 - (EXv(ixm, iyp, iz) - EXv(ixm, iy, iz)) * hy1;
+    T v3pm = (EYv(ixp, iym, iz) - EYv(ix, iym, iz)) * hx1 - (ex_c - EXv(ix, iym, iz)) * hy0;
+
+    // 2. face averages of zeta (core.py:160-170)
+    const double z000 = ZT(ixm, iym, izm), z100 = ZT(ix, iym, izm);
+    const double z010 = ZT(ixm, iy, izm), z110 = ZT(ix, iy, izm);
+    const double z001 = ZT(ixm, iym, iz), z101 = ZT(ix, iym, iz);
+    const double z011 = ZT(ixm, iy, iz), z111 = ZT(ix, iy, iz);
+    v1pp *= z011 + z111;
+    v1mp *= z001 + z101;
+    v1pm *= z010 + z110;
+    v2pp *= z101 + z111;
+    v2mp *= z001 + z011;
+    v2pm *= z100 + z110;
+    v3pp *= z110 + z111;
+    v3mp *= z010 + z011;
+    v3pm *= z100 + z101;
+
+    // 3. second curl (core.py:174-176)
+    T rrx = v3pp * hy1 - v3pm * hy0 - v2pp * hz1 + v2pm * hz0;
+    T rry = v1pp * hz1 - v1pm * hz0 - v3pp * hx1 + v3mp * hx0;
+    T rrz = v2pp * hx1 - v2mp * hx0 - v1pp * hy1 + v1mp * hy0;
+
+    // 4. eta edge sums (core.py:181-186)
+#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
+    const T stx = ETv(L.eta_x, ix, iym, izm) + ETv(L.eta_x, ix, iym, iz) +
+                  ETv(L.eta_x, ix, iy, izm) + ETv(L.eta_x, ix, iy, iz);
+    const T sty = ETv(L.eta_y, ixm, iy, izm) + ETv(L.eta_y, ix, iy, izm) +
+                  ETv(L.eta_y, ixm, iy, iz) + ETv(L.eta_y, ix, iy, iz);
+    const T stz = ETv(L.eta_z, ixm, iym, iz) + ETv(L.eta_z, ix, iym, iz) +
+                  ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ix, iy, iz);
+#undef ETv
+    // PEC rows (core.py:193-198)
+    if (iy == 0 || iz == 0) rrx = zero<T>();
+    if (ix == 0 || iz == 0) rry = zero<T>();
+    if (ix == 0 || iy == 0) rrz = zero<T>();
+
+    // 5. r = s - (0.5 rr - 0.25 st e)   (core.py:204-206)
+    const T ax = 0.5 * rrx - 0.25 * (stx * ex_c), ay = 0.5 * rry - 0.25 * (sty * ey_c), az = 0.5 * rrz - 0.25 * (stz * ez_c);
+    if (SRC) {
+        ox = L.sx[A.iex(ix, iy, iz)] - ax;
+        oy = L.sy[A.iey(ix, iy, iz)] - ay;
+        oz = L.sz[A.iez(ix, iy, iz)] - az;
+    } else {
+        ox = -ax; oy = -ay; oz = -az;
+    }
+#undef EXv
+#undef EYv
+#undef EZv
+#undef ZT
+}
+
 // ---------------------------------------------------------------------------------------
 // Residual  r = s - A e  at the three "lower" edges of extended cell (ix,iy,iz),
 // 0 <= ix <= nx etc. Follows core.amat_x (reference emg3d/core.py:57-206) for the cells
@@ -132,77 +212,14 @@ EMG_HD double residual_cell(const Level<T> &L, T *rx, T *ry, T *rz, int ix, int 
     double acc = 0.0;
 
     if (inx && iny && inz) {
-        const int ixm = ix > 0 ? ix - 1 : 0, iym = iy > 0 ? iy - 1 : 0, izm = iz > 0 ? iz - 1 : 0;
-        const int ixp = ix + 1, iyp = iy + 1, izp = iz + 1;
-        const double hx1 = L.ihx[ix], hx0 = L.ihx[ixm];
-        const double hy1 = L.ihy[iy], hy0 = L.ihy[iym];
-        const double hz1 = L.ihz[iz], hz0 = L.ihz[izm];
-#define EXv(i, j, k) L.ex[A.iex(i, j, k)]
-#define EYv(i, j, k) L.ey[A.iey(i, j, k)]
-#define EZv(i, j, k) L.ez[A.iez(i, j, k)]
-#define ZT(i, j, k) L.zeta[A.icc(i, j, k)]
-        const T ex_c = EXv(ix, iy, iz), ey_c = EYv(ix, iy, iz), ez_c = EZv(ix, iy, iz);
-        // 1. curl on the faces around the three edges (core.py:136-155)
-        T v1pp = (EZv(ix, iyp, iz) - ez_c) * hy1 - (EYv(ix, iy, izp) - ey_c) * hz1;
-        T v1mp = (ez_c - EZv(ix, iym, iz)) * hy0 - (EYv(ix, iym, izp) - EYv(ix, iym, iz)) * hz1;
-        T v1pm = (EZv(ix, iyp, izm) - EZv(ix, iy, izm)) * hy1 - (ey_c - EYv(ix, iy, izm)) * hz0;
-
-        T v2pp = (EXv(ix, iy, izp) - ex_c) * hz1 - (EZv(ixp, iy, iz) - ez_c) * hx1;
-        T v2mp = (EXv(ixm, iy, izp) - EXv(ixm, iy, iz)) * hz1 - (ez_c - EZv(ixm, iy, iz)) * hx0;
-        T v2pm = (ex_c - EXv(ix, iy, izm)) * hz0 - (EZv(ixp, iy, izm) - EZv(ix, iy, izm)) * hx1;
-
-        T v3pp = (EYv(ixp, iy, iz) - ey_c) * hx1 - (EXv(ix, iyp, iz) - ex_c) * hy1;
-        T v3mp = (ey_c - EYv(ixm, iy, iz)) * hx0 - (EXv(ixm, iyp, iz) - EXv(ixm, iy, iz)) * hy1;
-        T v3pm = (EYv(ixp, iym, iz) - EYv(ix, iym, iz)) * hx1 - (ex_c - EXv(ix, iym, iz)) * hy0;
-
-        // 2. face averages of zeta (core.py:160-170)
-        const double z000 = ZT(ixm, iym, izm), z100 = ZT(ix, iym, izm);
-        const double z010 = ZT(ixm, iy, izm), z110 = ZT(ix, iy, izm);
-        const double z001 = ZT(ixm, iym, iz), z101 = ZT(ix, iym, iz);
-        const double z011 = ZT(ixm, iy, iz), z111 = ZT(ix, iy, iz);
-        v1pp *= z011 + z111;
-        v1mp *= z001 + z101;
-        v1pm *= z010 + z110;
-        v2pp *= z101 + z111;
-        v2mp *= z001 + z011;
-        v2pm *= z100 + z110;
-        v3pp *= z110 + z111;
-        v3mp *= z010 + z011;
-        v3pm *= z100 + z101;
-
-        // 3. second curl (core.py:174-176)
-        T rrx = v3pp * hy1 - v3pm * hy0 - v2pp * hz1 + v2pm * hz0;
-        T rry = v1pp * hz1 - v1pm * hz0 - v3pp * hx1 + v3mp * hx0;
-        T rrz = v2pp * hx1 - v2mp * hx0 - v1pp * hy1 + v1mp * hy0;
-
-        // 4. eta edge sums (core.py:181-186)
-#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
-        const T stx = ETv(L.eta_x, ix, iym, izm) + ETv(L.eta_x, ix, iym, iz) +
-                      ETv(L.eta_x, ix, iy, izm) + ETv(L.eta_x, ix, iy, iz);
-        const T sty = ETv(L.eta_y, ixm, iy, izm) + ETv(L.eta_y, ix, iy, izm) +
-                      ETv(L.eta_y, ixm, iy, iz) + ETv(L.eta_y, ix, iy, iz);
-        const T stz = ETv(L.eta_z, ixm, iym, iz) + ETv(L.eta_z, ix, iym, iz) +
-                      ETv(L.eta_z, ixm, iy, iz) + ETv(L.eta_z, ix, iy, iz);
-#undef ETv
-        // PEC rows (core.py:193-198)
-        if (iy == 0 || iz == 0) rrx = zero<T>();
-        if (ix == 0 || iz == 0) rry = zero<T>();
-        if (ix == 0 || iy == 0) rrz = zero<T>();
-
-        // 5. r = s - (0.5 rr - 0.25 st e)   (core.py:204-206)
-        const T ox = L.sx[A.iex(ix, iy, iz)] - (0.5 * rrx - 0.25 * (stx * ex_c));
-        const T oy = L.sy[A.iey(ix, iy, iz)] - (0.5 * rry - 0.25 * (sty * ey_c));
-        const T oz = L.sz[A.iez(ix, iy, iz)] - (0.5 * rrz - 0.25 * (stz * ez_c));
+        T ox, oy, oz;
+        residual_values<T, true>(L, ix, iy, iz, ox, oy, oz);
         acc = abs2(ox) + abs2(oy) + abs2(oz);
         if (rx) {
             rx[A.iex(ix, iy, iz)] = ox;
             ry[A.iey(ix, iy, iz)] = oy;
             rz[A.iez(ix, iy, iz)] = oz;
         }
-#undef EXv
-#undef EYv
-#undef EZv
-#undef ZT
     } else {
         // Upper-boundary entries: r = s (untouched by core.amat_x).
         if (inx) {  // ex exists for ix < nx, any iy <= ny, iz <= nz

@@ -151,12 +151,15 @@ def solve(inp):
         # levels, line factorisations and graphs (not in the reference: its workers are
         # separate processes that rebuild everything per pair)
         key = (id(inp['model']), id(grid), complex(sfield.sval))
-        hier = cache.get(key)
-        if hier is None:
+        hit = cache.get(key)
+        # an id can be recycled once its object is gone: the entry keeps the objects and is only
+        # valid for the very same ones
+        if hit is None or hit[1] is not inp['model'] or hit[2] is not grid:
+            cache.pop(key, None)
             while len(cache) >= 2:            # bounded: a hierarchy is ~1.3 kB per cell
                 cache.pop(next(iter(cache)))
-            hier = cache[key] = solver.Hierarchy(models.VolumeModel(model, sfield))
-        opts['hierarchy'] = hier
+            hit = cache[key] = (solver.Hierarchy(models.VolumeModel(model, sfield)), inp['model'], grid)
+        opts['hierarchy'] = hit[0]
     rec = inp.get('receivers')
     if rec is None:
         return solver.solve(model=model, sfield=sfield, efield=inp.get('efield'),

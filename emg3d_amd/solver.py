@@ -206,9 +206,9 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     ``Hierarchy(vmodel, batch=len(sfields))`` of an earlier batch of the same frequency).
     """
     sslsolver = kwargs.pop('sslsolver', False)
-    if kwargs.pop('plain', False):
-        semicoarsening = linerelaxation = False
-        sslsolver = False if sslsolver is True else sslsolver
+    if kwargs.pop('plain', False):       # as in solve(): only what was left at True is switched off
+        sslsolver, semicoarsening, linerelaxation = (
+            False if flag is True else flag for flag in (sslsolver, semicoarsening, linerelaxation))
     for k in ('efield', 'return_info', 'always_return'):
         kwargs.pop(k, None)
     receivers = kwargs.pop('receivers', None)            # one tuple for all, or one per source
@@ -262,7 +262,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         v.error_at_cycle[0] = v.l2_refe
         hier.put_source(sf, top.s[b * n:(b + 1) * n], sparse)
         efields.append(fields.Field(model.grid, dtype=sf.field.dtype, frequency=sf._frequency))
-    top.e.zero_()
+    top.zero_field()
     nonzero = [v.l2_refe >= 100 * np.finfo(float).tiny for v in vars_]
     if var.sslsolver:
         done = _bicgstab_batch(hier, svar, vars_, nonzero)
@@ -273,6 +273,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         zero = v.l2_refe < 100 * np.finfo(float).tiny     # zero source: zero field (solver.py:372-379)
         if zero:
             v.exit_message = "CONVERGED"
+            v.l2, v.l2_refe = 0.0, np.nan            # as solve() reports a zero source
         elif keep_fields and done[b] is not None:
             torch.from_numpy(ef.field).copy_(done[b])
         info = _info_dict(v)
@@ -369,7 +370,7 @@ def _bicgstab_batch(hier, svar, vars_, nonzero):
 
     def psolve(VEC, OUT):
         top.s.copy_(VEC)
-        top.e.zero_()
+        top.zero_field()
         done, bad = _multigrid_batch(top, svar, vars_, live)
         for b in range(nb):
             if live[b]:
@@ -525,7 +526,7 @@ class Hierarchy:
     def upload(self, sfield, efield, sparse=False):
         self.put_source(sfield, self.top.s, sparse)
         if getattr(efield, '_is_zero', False):
-            self.top.e.zero_()           # the start field solve() made itself: nothing to send
+            self.top.zero_field()        # the start field solve() made itself: nothing to send
         else:
             self.top.e.copy_(torch.from_numpy(np.ascontiguousarray(efield.field)), non_blocking=False)
 
@@ -574,148 +575,77 @@ def _coarse_correction_graphed(clv, var, new_cycmax):
 def krylov(model, sfield, efield, var, hierarchy=None):
     """Krylov subspace solver with multigrid preconditioner (emg3d/solver.py:652-784).
 
-    ``bicgstab`` (the default of ``solve``) runs entirely on the device: vectors stay in
-    HBM, the operator is the residual kernel with a zero source, the preconditioner is the
-    multigrid cycle on the same hierarchy, and only scalars (inner products, norms) cross
-    PCIe. ``cgs`` and ``gcrotmk`` use SciPy on the host, as the reference does, with device
-    operator / preconditioner applications (vectors cross PCIe per call).
+    ``bicgstab`` (the default of ``solve``) and ``cgs`` run entirely on the device
+    (emg3d_amd/_krylov.py): vectors stay in HBM, their updates and inner products are the fused
+    kernels of csrc/krylov.h with the recurrence scalars in device memory, the operator is
+    ``emg3d_dev_apply_operator``, the preconditioner the multigrid cycle on the same hierarchy.
+    ``gcrotmk`` uses SciPy on the host, as the reference does, with device operator /
+    preconditioner applications (vectors cross PCIe per call).
     """
+    from emg3d_amd import _krylov
     hier = hierarchy or Hierarchy(model)
-    if var.sslsolver == 'bicgstab':
-        i = _bicgstab_device(hier, sfield, efield, var)
-    else:
-        i = _scipy_krylov(hier, model, sfield, efield, var)
+    device_solver = {'bicgstab': _krylov.bicgstab, 'cgs': _krylov.cgs}.get(var.sslsolver)
+    try:
+        if device_solver is not None:
+            status = _krylov_on_device(device_solver, hier, sfield, efield, var)
+        else:
+            status = _scipy_krylov(hier, model, sfield, efield, var)
+    except _ConvergenceError:            # the preconditioner diverged or stagnated
+        status = -1
+        efield.field[:] = 0
+        hier.top.zero_field()            # responses taken from the device field are those of the zero field too
+        var.exit_message += " (returned field is zero)"
 
-    pre = (50 * " " + "\r" if var.verb == 3 else "\n") + "   > "
-    if i < 0:
-        if var.exit_message == '':
-            var.exit_message = f"Error in {var.sslsolver} ({i})"
-        pre = "\n* ERROR   :: "
-    elif i > 0:
-        var.exit_message = "MAX. ITERATION REACHED, NOT CONVERGED"
+    outcome = {True: "CONVERGED", False: "MAX. ITERATION REACHED, NOT CONVERGED"}
+    if status >= 0:
+        var.exit_message = outcome[status == 0]
+        lead = (50 * " " + "\r" if var.verb == 3 else "\n") + "   > "
     else:
-        var.exit_message = "CONVERGED"
-    var.cprint(pre + var.exit_message, 2)
+        var.exit_message = var.exit_message or f"Error in {var.sslsolver} ({status})"
+        lead = "\n* ERROR   :: "
+    var.cprint(lead + var.exit_message, 2)
 
 
 def _krylov_callback(var, l2):
-    """Bookkeeping after a Krylov iteration (emg3d/solver.py:731-757)."""
+    """After every Krylov iteration: counters, histories, log line (emg3d/solver.py:731-757)."""
     var.ssl_it += 1
-    var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
     var.l2 = l2
-    var.error_at_cycle = np.r_[var.error_at_cycle, var.l2]
-    if var.verb > 3:
-        log = f"   [{var.time.now}]   {var.l2/var.l2_refe:.3e} "
-        log += f" after {var.ssl_it:3} {var.sslsolver}-cycles"
-        if var.ssl_it == 1 and var.it == 0 and var.cycle is not None:
-            log += "\n"
-        var.cprint(log, 3)
-    elif var.verb in [2, 3]:
-        _print_one_liner(var, var.l2)
+    var.runtime_at_cycle = np.append(var.runtime_at_cycle, var.time.elapsed)
+    var.error_at_cycle = np.append(var.error_at_cycle, l2)
+    if var.verb in (2, 3):
+        _print_one_liner(var, l2)
+    elif var.verb > 3:
+        first = var.ssl_it == 1 and var.it == 0 and var.cycle is not None
+        var.cprint(f"   [{var.time.now}]   {l2 / var.l2_refe:.3e}  after {var.ssl_it:3} {var.sslsolver}-cycles"
+                   + ("\n" if first else ""), 3)
 
 
-def _bicgstab_device(hier, sfield, efield, var):
-    """Preconditioned BiCGSTAB (van der Vorst 1992) with the iteration, breakdown checks,
-    stopping rule ``|r| <= max(atol, rtol |b|)`` and return codes of
-    ``scipy.sparse.linalg.bicgstab`` (SciPy >= 1.12, which the reference calls at
-    emg3d/solver.py:763-765 with ``rtol=tol, atol=1e-30, maxiter=maxit``), on device
-    tensors. Returns 0 (converged), >0 (maxiter), <0 (breakdown / aborted)."""
+def _krylov_on_device(method, hier, sfield, efield, var):
+    """Source and start vector to the device, ``method`` (``_krylov.bicgstab`` / ``cgs``), solution
+    back into ``efield`` -- and into ``hier.top.e``, where receivers are read from."""
     top = hier.top
-    dev = hier.device
-    dtype = top.dtype
-    b = torch.empty(top.e.numel(), dtype=top.e.dtype, device=dev)
+    b = torch.empty(top.e.numel(), dtype=top.e.dtype, device=hier.device)
     hier.put_source(sfield, b, getattr(var, 'sparse_source', False))
+    x = torch.empty_like(b)
     if getattr(efield, '_is_zero', False):
-        x = torch.zeros_like(b)
+        _lib.check(_lib.lib().emg3d_dev_zero(x.data_ptr(), x.numel() * x.element_size(),
+                                             torch.cuda.current_stream().cuda_stream), 'emg3d_dev_zero')
     else:
-        x = torch.from_numpy(np.ascontiguousarray(efield.field)).to(dev)
-    new = lambda: torch.empty_like(b)   # noqa: E731
-
-    def norm(t):
-        return float(torch.linalg.vector_norm(t).item())
-
-    def dot(u, w):                      # conj(u) . w, like np.vdot
-        return complex(torch.vdot(u, w).item()) if top.is_complex else float(torch.dot(u, w).item())
-
-    def psolve(vec, out):
-        if not var.cycle:
-            out.copy_(vec)
-            return out
-        top.s.copy_(vec)
-        top.e.zero_()
-        _multigrid(top, var, 0, 0)      # maxit = maxcycle cycles (emg3d/solver.py:1376-1381)
-        out.copy_(top.e)
-        return out
-
-    def true_residual_norm():
-        top.s.copy_(b)
-        top.e.copy_(x)
-        return top.residual(store=False, norm=True)
-
-    atol = max(1e-30, var.tol * norm(b))
-    eps = np.finfo(np.float64).eps
-    rhotol = omegatol = eps ** 2
-    r, v, t, p, phat, shat = new(), new(), new(), new(), new(), new()
-    top.apply_A(x, r)
-    torch.sub(b, r, out=r)              # r = b - A x
-    rtilde = r.clone()
-    rho_prev = omega = alpha = 1.0
-    code = var.ssl_maxit
-    try:
-        for iteration in range(var.ssl_maxit):
-            if norm(r) < atol:
-                code = 0
-                break
-            rho = dot(rtilde, r)
-            if abs(rho) < rhotol:
-                code = -10
-                break
-            if iteration > 0:
-                if abs(omega) < omegatol:
-                    code = -11
-                    break
-                beta = (rho / rho_prev) * (alpha / omega)
-                p.sub_(v, alpha=omega).mul_(beta).add_(r)
-            else:
-                p.copy_(r)
-            psolve(p, phat)
-            top.apply_A(phat, v)
-            rv = dot(rtilde, v)
-            if rv == 0:
-                code = -11
-                break
-            alpha = rho / rv
-            r.sub_(v, alpha=alpha)      # s = r - alpha v (in place)
-            if norm(r) < atol:
-                x.add_(phat, alpha=alpha)
-                code = 0
-                break
-            psolve(r, shat)
-            top.apply_A(shat, t)
-            omega = dot(t, r) / dot(t, t)
-            x.add_(phat, alpha=alpha).add_(shat, alpha=omega)
-            r.sub_(t, alpha=omega)
-            rho_prev = rho
-            _krylov_callback(var, true_residual_norm())
-        efield._is_zero = False
+        x.copy_(torch.from_numpy(np.ascontiguousarray(efield.field)))
+    status = method(hier, b, x, var, _cycle.run_cycles, lambda l2: _krylov_callback(var, l2))
+    efield._is_zero = False
+    top.e.copy_(x)          # the hierarchy's field is the solution (not the last preconditioner output)
+    if getattr(var, 'download', True):
         out = efield.field
-        top.e.copy_(x)          # the hierarchy's field is the solution (not the last preconditioner output)
-        if not getattr(var, 'download', True):
-            pass
-        elif out.flags.c_contiguous and out.flags.writeable:
+        if out.flags.c_contiguous and out.flags.writeable:
             torch.from_numpy(out).copy_(x)
         else:
             out[:] = x.cpu().numpy()
-    except _ConvergenceError:
-        code = -1
-        efield.field[:] = 0
-        var.exit_message += " (returned field is zero)"
-    del dtype
-    return code
+    return status
 
 
 def _scipy_krylov(hier, model, sfield, efield, var):
-    """cgs / gcrotmk through SciPy on the host (emg3d/solver.py:685-768)."""
+    """gcrotmk through SciPy on the host (emg3d/solver.py:685-768)."""
     import scipy.sparse.linalg as ssl
 
     top = hier.top
@@ -743,15 +673,10 @@ def _scipy_krylov(hier, model, sfield, efield, var):
         hier.upload(sfield, fields.Field(grid, np.asarray(x, dtype=dt)))
         _krylov_callback(var, top.residual(store=False, norm=True))
 
-    try:
-        x, i = getattr(ssl, var.sslsolver)(
-            A=A, b=sfield.field, x0=efield.field.copy(), rtol=var.tol, maxiter=var.ssl_maxit,
-            atol=1e-30, M=M, callback=callback)
-        efield.field[:] = x
-    except _ConvergenceError:
-        i = -1
-        efield.field[:] = 0
-        var.exit_message += " (returned field is zero)"
+    x, i = getattr(ssl, var.sslsolver)(
+        A=A, b=sfield.field, x0=efield.field.copy(), rtol=var.tol, maxiter=var.ssl_maxit,
+        atol=1e-30, M=M, callback=callback)
+    efield.field[:] = x
     return i
 
 

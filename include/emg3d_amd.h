@@ -226,6 +226,31 @@ int emg3d_dev_restrict_param(void *out, const void *in, int nx, int ny, int nz, 
 int emg3d_dev_pec_zero(void *ex, void *ey, void *ez, int nx, int ny, int nz, int is_complex,
                        void *stream);
 
+/* ---- around the multigrid cycle: Krylov vector work -------------------
+ * solver.krylov (emg3d/solver.py:652-784) wraps scipy.sparse.linalg.{bicgstab, cgs} around the
+ * multigrid preconditioner; their vector updates and inner products run on the device as
+ * instances of one fused step,
+ *     y = sum_{i < nterms} c_i xs[i]         c_i = table[slots[i]] * scales[i], or scales[i] alone
+ *                                            if slots[i] < 0;  y may be one of the xs; nterms <= 4
+ *     table[dslots[k]] = conj(das[k]) . dbs[k]   for k < ndots <= 3, evaluated with the new y
+ * followed by up to 8 scalar instructions prog[4 i .. 4 i + 3] = (op, dst, a, b) on the table:
+ * op 0 dst = a / b, 1 dst = a * b, 2 dst = -a, 3 dst = a. `table` holds complex scalars as
+ * (re, im) pairs of doubles in device memory (real fields use the real parts), so the scalars
+ * of the recurrences stay on the GPU; the host reads the table when it has to decide
+ * (convergence, breakdown). ws: emg3d_krylov_ws_len() doubles. Vectors have n entries of the
+ * field dtype; the arrays of pointers / integers / scales are HOST arrays. */
+size_t emg3d_krylov_ws_len(void);
+int emg3d_dev_krylov_step(size_t n, int is_complex, void *y, int nterms, const void *const *xs, const int *slots,
+                          const double *scales, int ndots, const void *const *das, const void *const *dbs,
+                          const int *dslots, int nprog, const int *prog, double *table, double *ws, size_t ws_len,
+                          void *stream);
+/* The Krylov operator (emg3d/solver.py:686-702): out = A x with x = lv->ex|ey|ez (lv->s* unused);
+ * entries core.amat_x never touches (upper boundary) are set to zero. */
+int emg3d_dev_apply_operator(const emg3d_level *lv, void *ox, void *oy, void *oz, void *stream);
+/* hipMemsetAsync / device-to-device hipMemcpyAsync on the stream */
+int emg3d_dev_zero(void *p, size_t bytes, void *stream);
+int emg3d_dev_copy(void *dst, const void *src, size_t bytes, void *stream);
+
 /* ---- after a solve: magnetic field and receiver responses ------------
  * fields.get_magnetic_field / _edge_curl_factor (emg3d/fields.py:617-659, 941-1009):
  * m = curl(e) * (zeta / (s mu0)) averaged over the two cells of a face, on the faces

@@ -1200,3 +1200,61 @@ def test_bench_workloads_converged_vs_oracle(name):
     assert io['exit'] == 0
     assert relerr(e.field, eo.field) < 1e-8
     assert abs(info['it_mg'] - io['it_mg']) <= 4
+
+
+@pytest.mark.parametrize('method', ['bicgstab', 'cgs'])
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_device_krylov_matches_scipy_iteration(method, dtype):
+    """The device BiCGSTAB / CGS (csrc/krylov.h: fused updates + inner products, scalars in a device
+    table) against scipy.sparse.linalg's own iteration driven with the same device operator and
+    multigrid preconditioner through host vectors: same status, same number of iterations and
+    multigrid cycles, same true-residual history (1e-6 relative), fields equal to 1e-9."""
+    import scipy.sparse.linalg as ssl
+    from emg3d_amd import models as emodels
+    rng = np.random.default_rng(5)
+    shape = (24, 16, 20)
+    h = [widths(n // 2, n // 4, 20., 1.2) for n in shape]
+    grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
+    rho = 10 ** rng.uniform(-0.5, 1.0, shape)
+    model = emg3d.Model(grid, rho, 1.5 * rho, 2.0 * rho)
+    freq = 1.2 if dtype is complex else -1.2
+    sfield = emg3d.get_source_field(grid, (3., -2., 1., 20., 30.), freq)
+    kw = dict(sslsolver=method, cycle='F', semicoarsening=True, linerelaxation=True, tol=1e-8, maxit=30)
+    e, info = emg3d.solve(model, sfield, return_info=True, **kw)
+    assert info['exit'] == 0, info['exit_message']
+
+    # SciPy's iteration on host vectors, device operator and preconditioner
+    var = solver.MGParameters(verb=0, shape_cells=shape, **kw)
+    var.l2_refe = float(np.linalg.norm(sfield.field))
+    var.error_at_cycle[0] = var.l2_refe
+    vm = emodels.VolumeModel(model, sfield)
+    hier = solver.Hierarchy(vm)
+    top = hier.top
+    dt = sfield.field.dtype
+
+    def up(v):
+        return torch.from_numpy(np.ascontiguousarray(v, dtype=dt)).cuda()
+
+    def amat(v):
+        return top.apply_A(up(v), torch.empty_like(top.e)).cpu().numpy()
+
+    def prec(v):
+        top.s.copy_(up(v))
+        top.e.zero_()
+        solver._multigrid(top, var, 0, 0)
+        return top.e.cpu().numpy()
+    n = sfield.field.size
+    hist = []
+
+    def cb(x):
+        top.s.copy_(up(sfield.field))
+        top.e.copy_(up(x))
+        hist.append(top.residual(store=False, norm=True))
+    x, code = getattr(ssl, method)(ssl.LinearOperator((n, n), matvec=amat, dtype=dt), sfield.field, x0=np.zeros(n, dt),
+                                   rtol=var.tol, atol=1e-30, maxiter=var.ssl_maxit,
+                                   M=ssl.LinearOperator((n, n), matvec=prec, dtype=dt), callback=cb)
+    assert code == 0
+    assert info['it_ssl'] == len(hist)
+    assert info['it_mg'] == var.it
+    assert np.allclose(info['error_at_cycle'][1:], hist, rtol=1e-6)
+    assert relerr(e.field, x) < 1e-9
