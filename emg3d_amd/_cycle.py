@@ -195,6 +195,7 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None):
         # thread_local: other host threads may launch their own solves meanwhile
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             runner.run(steps)
+        entry['work'] = var.smoother_cell_sweeps - before
         var.smoother_cell_sweeps = before           # capturing does not execute
         entry['graph'] = graph
     entry['graph'].replay()

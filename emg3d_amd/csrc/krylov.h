@@ -159,6 +159,12 @@ __global__ __launch_bounds__(256) void k_apply_operator(emg::Level<T> L0, T *ox,
     }
 }
 
+// zero fill as a kernel of this library (a node like any other in a captured graph)
+__global__ __launch_bounds__(256) void k_fill_zero(double *p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,10 +218,16 @@ int emg3d_dev_apply_operator(const emg3d_level *lv, void *ox, void *oy, void *oz
     return 0;
 }
 
-/* plain device memory helpers, so that no library tensor operation touches field-sized data */
+/* plain device memory helpers, so that no tensor-library operation touches field-sized data */
 int emg3d_dev_zero(void *p, size_t bytes, void *stream)
 {
-    if (bytes) HIP_TRY(hipMemsetAsync(p, 0, bytes, (hipStream_t)stream));
+    if (!bytes) return 0;
+    if (bytes % 8 != 0 || ((size_t)p & 7) != 0) return fail(EMG3D_ERR_BADARG, "zero: buffer of doubles expected");
+    const size_t n = bytes / 8;
+    size_t want = (n + 255) / 256;
+    const int grid = (int)(want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(k_fill_zero, dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)p, n);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 int emg3d_dev_copy(void *dst, const void *src, size_t bytes, void *stream)
