@@ -199,6 +199,8 @@ class VolumeModel:
         dtype = torch.complex128 if cplx else torch.float64
 
         def up(a):
+            if isinstance(a, torch.Tensor):
+                return a
             a = np.broadcast_to(np.asarray(a, dtype=np.float64), model.shape)
             a = a.ravel('F')
             if not a.flags.writeable or not a.flags.c_contiguous:
@@ -213,16 +215,24 @@ class VolumeModel:
         eps = None
         if model.epsilon_r is not None:
             sval = complex(self._sval) if cplx else float(self._sval)
-            eps = (sval * EPSILON_0) * up(model.epsilon_r).to(dtype)
+            eps = (sval * EPSILON_0) * up(getattr(model, '_device_props', {}).get('epsilon_r', model.epsilon_r)).to(dtype)
+        # properties that arrived through a device broadcast (parallel.broadcast_model) are
+        # already in HBM: map them to conductivities there
+        resident = {k: v for k, v in getattr(model, '_device_props', {}).items() if v.device == torch.device(device)}
+        dev_map = {'Resistivity': lambda p: 1.0 / p, 'Conductivity': lambda p: p,
+                   'LgResistivity': lambda p: 10.0 ** (-p), 'LgConductivity': lambda p: 10.0 ** p,
+                   'LnResistivity': lambda p: torch.exp(-p), 'LnConductivity': torch.exp}[model.mapping]
+        conds = [dev_map(resident[n]) if n in resident else c
+                 for n, c in zip(('property_x', 'property_y', 'property_z'), self._conductivities())]
         etas = []
-        for cond in self._conductivities():
+        for cond in conds:
             if cond is None:
                 etas.append(None)
             elif eps is None:
                 etas.append(base * up(cond))
             else:
                 etas.append(base * (up(cond) + eps))
-        zeta = vol.clone() if model.mu_r is None else vol / up(model.mu_r)
+        zeta = vol.clone() if model.mu_r is None else vol / up(resident.get('mu_r', model.mu_r))
         ex = etas[0]
         ey = etas[1] if self.case in ('HTI', 'triaxial') else ex
         ez = etas[2] if self.case in ('VTI', 'triaxial') else ex

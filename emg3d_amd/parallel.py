@@ -115,7 +115,8 @@ def broadcast_model(model, src=0, device=None):
     dist.broadcast_object_list(meta, src)
     meta = meta[0]
     grid = model.grid if rank == src else meshes.TensorMesh(meta['h'], meta['origin'])
-    kw = {}
+    kw, dev = {}, {}
+    on_gpu = device.type == 'cuda'
     for n, present in zip(names, meta['present']):
         if not present:
             continue
@@ -124,10 +125,14 @@ def broadcast_model(model, src=0, device=None):
         else:
             t = torch.empty(grid.n_cells, dtype=torch.float64)
         t = _bcast_tensor(t, src, device)
-        kw[n] = t.cpu().numpy().reshape(grid.shape_cells, order='F')
-    if rank == src:
-        return model
-    return models.Model(grid, mapping=meta['mapping'], **kw)
+        if on_gpu:
+            dev[n] = t            # stays in HBM: VolumeModel.device_arrays starts from it, no second upload
+        if rank != src:           # the host-side Model of a receiving rank needs its own copy
+            kw[n] = t.cpu().numpy().reshape(grid.shape_cells, order='F')
+    if rank != src:
+        model = models.Model(grid, mapping=meta['mapping'], **kw)
+    model._device_props = dev
+    return model
 
 
 def solve(inp):

@@ -1199,7 +1199,10 @@ def test_bench_workloads_converged_vs_oracle(name):
     eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **wl['opts'])
     assert io['exit'] == 0
     assert relerr(e.field, eo.field) < 1e-8
-    assert abs(info['it_mg'] - io['it_mg']) <= 4
+    # the four-colour line ordering needs more cycles than the lexicographic one on this kind of
+    # model (triaxial64, W-cycle: 25 against 17 at tol 1e-10; every colour sequence 18-20 against 12
+    # at 1e-8)
+    assert info['it_mg'] <= int(np.ceil(1.6 * io['it_mg']))
 
 
 @pytest.mark.parametrize('method', ['bicgstab', 'cgs'])
@@ -1259,3 +1262,28 @@ def test_device_krylov_matches_scipy_iteration(method, dtype):
     assert info['it_mg'] == var.it
     assert np.allclose(info['error_at_cycle'], var.error_at_cycle, rtol=1e-6)      # multigrid cycles and Krylov steps
     assert relerr(e.field, x) < 1e-9
+
+
+def test_bench_two_ranks_through_its_own_launcher():
+    """`python bench.py --gpus 2` as a driver would call it: bench.py spawns its two ranks itself
+    (torch.distributed.run on 127.0.0.1), the ranks share this box's one GPU and run their
+    collectives over gloo (EMG3D_BENCH_BACKEND) -- rank-dependent source, model broadcast, barrier,
+    MAX / SUM reductions and the rank-0 JSON line of the multi-GPU path."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, EMG3D_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'marine64',
+                        '--steps', '3', '--warmup', '1', '--no-256', '--no-survey', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
+    assert out['config']['workload'] == 'marine64' and out['value'] > 0
+    # two independent sources: twice the cell-sweeps of one rank per step
+    assert out['config']['cell_sweeps_per_step'] > 0
+    assert out['value'] == pytest.approx(2 * out['config']['cell_sweeps_per_step'] * 3 / (out['ms_per_step'] * 3e-3) / 1e6, rel=0.02)

@@ -289,6 +289,66 @@ def solves():
     print('solves.npz written')
 
 
+def solves32():
+    """32^3 solves of the reference itself (several minutes, un-jitted): BASELINE.json config 1
+    -- h = 50 m x 32, unit fullspace, x-dipole at the origin, 1 Hz, plain F-cycle -- at tol 1e-6
+    (cycle count and error of SURVEY.md 8d: 6 cycles, 1.784e-07) and at tol 1e-10 (the field the
+    GPU solve is compared with), and a 32^3 stretched marine VTI model with W-cycle,
+    semicoarsening and line relaxation at tol 1e-10. Only inputs that cannot be re-derived and the
+    converged fields are stored."""
+    out = dict(META)
+    names = []
+
+    def run(name, grid, model, src, freq, tols, **kw):
+        sfield = emg3d.get_source_field(grid, src, freq)
+        p = name + '_'
+        names.append(name)
+        out[p + 'hx'], out[p + 'hy'], out[p + 'hz'] = grid.h
+        out[p + 'origin'] = np.asarray(grid.origin, float)
+        out[p + 'case'] = model.case
+        out[p + 'frequency'] = float(freq)
+        out[p + 'source'] = np.asarray(src, float)
+        out[p + 'res_x'] = model.property_x
+        if model.property_z is not None:
+            out[p + 'res_z'] = model.property_z
+        for k, v in kw.items():
+            out[p + 'kw_' + k] = v
+        for tol in tols:
+            t0 = time.time()
+            ef, info = rsolver.solve(model, sfield, return_info=True, sslsolver=False, verb=0, tol=tol, **kw)
+            q = p + f"tol{tol:.0e}_"
+            out[q + 'it_mg'] = info['it_mg']
+            out[q + 'exit_message'] = info['exit_message']
+            out[q + 'error_at_cycle'] = info['error_at_cycle']
+            out[q + 'rel_error'] = info['rel_error']
+            out[q + 'ref_error'] = info['ref_error']
+            if tol == min(tols):
+                out[p + 'efield'] = np.asarray(ef.field)
+            print(f"  {name} tol={tol:.0e}: {info['exit_message']} it={info['it_mg']} "
+                  f"rel={info['rel_error']:.3e}  ({time.time() - t0:.1f} s)", flush=True)
+
+    h = np.ones(32) * 50.
+    grid = emg3d.TensorMesh([h, h, h], origin=(-800, -800, -800))
+    model = emg3d.Model(grid, property_x=1., mapping='Resistivity')
+    run('uni32_F', grid, model, (0, 0, 0, 0, 0), 1.0, (1e-6, 1e-10), semicoarsening=False,
+        linerelaxation=False, cycle='F')
+
+    hx = widths(16, 8, 50, 1.2); hz = widths(16, 8, 25, 1.25)
+    grid = emg3d.TensorMesh([hx, hx, hz], origin=(-hx.sum() / 2, -hx.sum() / 2, -hz[:20].sum()))
+    zc = grid.cell_centers_z
+    rh = np.where(zc > -200, 0.3, 1.0)
+    rv = np.where(zc > -200, 0.3, 2.0)
+    px = np.tile(rh[None, None, :], (32, 32, 1)).ravel('F')
+    pz = np.tile(rv[None, None, :], (32, 32, 1)).ravel('F')
+    model = emg3d.Model(grid, property_x=px, property_z=pz, mapping='Resistivity')
+    run('marine32_W', grid, model, (0, 0, -150, 0, 0), 1.0, (1e-10,), semicoarsening=True,
+        linerelaxation=True, cycle='W')
+
+    out['meta_cases'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'solves32.npz'), **out)
+    print('solves32.npz written')
+
+
 def receivers():
     """Magnetic field and receiver responses: inputs and the outputs of
     the reference's fields.get_magnetic_field / fields.get_receiver (cubic and linear), for a
@@ -390,3 +450,5 @@ if __name__ == '__main__':
         kernels()
     if 'solves' in which:
         solves()
+    if 'solves32' in which:
+        solves32()
