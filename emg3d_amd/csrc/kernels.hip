@@ -83,6 +83,9 @@ int g_tile_fuse = 1;
 int g_line_lds = 1;
 // tiled point smoother: software prefetch of the next colour step's inputs (0 none, 1 source, 2 source + eta sums)
 int g_point_prefetch = 0;
+// fused line kernel with the records in the global scratch (the largest levels): the instantiation
+// that is held to 256 registers, so that two workgroups share a CU and overlap their phases
+int g_line_occ2 = 0;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
 
@@ -916,21 +919,27 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         if (g_line_lpw > 0) lpw = g_line_lpw;
         else if (cdiv(lc.lines, 4) * L.batch <= 256) lpw = 4;      // all right-hand sides count
         else if (cdiv(lc.lines, 8) * L.batch <= 256) lpw = 8;
-        const unsigned nwg = cdiv(lc.lines, lpw);
-        // records in LDS if they fit (+ the dummy slots) and every workgroup gets a CU
+        // records in LDS if they fit (+ the dummy slots) and every workgroup gets a CU;
+        // line_lds = 2: whenever they fit, with fewer lines per workgroup if the lines are too
+        // long for 16 (experiment)
         const size_t lds_cu = 160 * 1024;
+        auto rec_bytes = [&](int l, int w) { return ((size_t)l * lc.n0p * w + emg::LINE_DUMMY) * sizeof(T); };
+        if (g_line_lds == 2 && g_line_lpw == 0) {
+            while (lpw > 4 && rec_bytes(lpw, 4) > lds_cu) lpw /= 2;
+        }
+        const unsigned nwg = cdiv(lc.lines, lpw);
         auto fits = [&](size_t smem) {
-            return g_line_lds && smem <= lds_cu && (size_t)nwg <= 256 * (lds_cu / smem);
+            return g_line_lds && smem <= lds_cu && (g_line_lds == 2 || (size_t)nwg <= 256 * (lds_cu / smem));
         };
-        const size_t smem1 = ((size_t)lpw * lc.n0p * 5 + emg::LINE_DUMMY) * sizeof(T);
-        const size_t smem2 = ((size_t)lpw * lc.n0p * 4 + emg::LINE_DUMMY) * sizeof(T);
+        const size_t smem1 = rec_bytes(lpw, 5);
+        const size_t smem2 = rec_bytes(lpw, 4);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, false>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true>), lds_cu);
 #define LC_LAUNCH(VM, SMEM)                                                                                              \
     do {                                                                                                                 \
-        if (L.batch > 1)                                                                                                 \
+        if (L.batch > 1 || (g_line_occ2 && VM == 0))                                                                     \
             hipLaunchKernelGGL((k_line_colour<T, DIR, VM, true>), dim3(nwg, L.batch), dim3(LC_THREADS), SMEM, st, L, c,   \
                                lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                     \
         else                                                                                                             \
@@ -1216,6 +1225,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "tile_fuse")) { g_tile_fuse = value; return 0; }
     if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
     if (!std::strcmp(name, "point_prefetch")) { g_point_prefetch = value; return 0; }
+    if (!std::strcmp(name, "line_occ2")) { g_line_occ2 = value; return 0; }
     if (!std::strcmp(name, "line_lpw")) {
         if (value != 0 && value != 4 && value != 8 && value != 16) return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8 or 16");
         g_line_lpw = value;
@@ -1234,6 +1244,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "tile_fuse")) return g_tile_fuse;
     if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
     if (name && !std::strcmp(name, "point_prefetch")) return g_point_prefetch;
+    if (name && !std::strcmp(name, "line_occ2")) return g_line_occ2;
     if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
     return -1;
 }

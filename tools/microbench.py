@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--slabs', default='0,2,4,8,16,32')
     ap.add_argument('--nu', type=int, default=2)
     ap.add_argument('--shape', default='', help='nx,ny,nz instead of n^3')
+    ap.add_argument('--fused-only', action='store_true', help='line smoothers: the default fused launches only')
     ap.add_argument('--eta-real', action='store_true', help='eta with a real part (as with epsilon_r)')
     ap.add_argument('--opt', action='append', default=[], help='library option name=value (repeatable)')
     args = ap.parse_args()
@@ -100,7 +101,7 @@ def main():
         lib.emg3d_set_option(b'point_slab', 0)
         lib.emg3d_set_option(b'point_tile_min', 1 << 20)
     if args.what in ('lines', 'all'):
-        for fuse in (0, 1):
+        for fuse in ((1,) if args.fused_only else (0, 1)):
             lib.emg3d_set_option(b'line_fuse', fuse)
             for lr in (1, 2, 3):
                 med, mn = timeit(lambda: lv.smooth(lr, args.nu), reps=5, warm=1)

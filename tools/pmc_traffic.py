@@ -1,4 +1,4 @@
-"""Turn the two PMC passes of a bench run into profiles/r01_pmc_traffic.json.
+"""Turn the two PMC passes of a bench run into profiles/r02_pmc_traffic.json.
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/f -o run -- python bench.py ...
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/w -o run -- python bench.py ...
@@ -58,7 +58,13 @@ def main():
             {k: p for k, p in parts.items() if 'colour' not in k}
         total = sum(p['read'] + p['write'] for p in use.values())
         res[name] = {'bytes_per_launch': total, 'kernels': use}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r01_pmc_traffic.json')
+    pt = [k for k in fetch if 'k_gs_point_tile' in k]
+    if pt:
+        k = max(pt, key=lambda k: fetch[k][1])
+        res['k_gs_point_tile'] = {'bytes_per_launch': 2 * fetch[k][1] * 1024 + write.get(k, (0, 0, 0))[1] * 1024,
+                                  'kernels': {'k_gs_point_tile': {'read': 2 * fetch[k][1] * 1024, 'write': write.get(k, (0, 0, 0))[1] * 1024,
+                                                                  'grid': fetch[k][0], 'launches': fetch[k][2]}}}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r02_pmc_traffic.json')
     try:
         with open(path) as f:
             allres = json.load(f)
