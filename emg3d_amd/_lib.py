@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIBDIR = os.path.join(_HERE, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'libemg3d_amd.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'emg3d_amd.h')
-SOURCES = [os.path.join(CSRC, f) for f in ('kernels.hip', 'stencil.h', 'launch.h', 'cplx.h', 'receivers.h', 'krylov.h')] + [HEADER]
+SOURCES = [os.path.join(CSRC, f) for f in ('kernels.hip', 'stencil.h', 'launch.h', 'cplx.h', 'receivers.h', 'krylov.h', 'adjoint.h')] + [HEADER]
 
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     'emg3d_dev_apply_operator': (_ci, [ctypes.POINTER(Level), _vp, _vp, _vp, _vp]),
     'emg3d_dev_zero': (_ci, [_vp, _sz, _vp]),
     'emg3d_dev_copy': (_ci, [_vp, _vp, _sz, _vp]),
+    'emg3d_dev_gradient_accumulate': (_ci, [_ci] * 4 + [_vp] * 6 + [ctypes.c_double] * 2 + [_vp] * 5),
     'emg3d_dev_magnetic_field': (_ci, [_ci] * 4 + [_vp] * 7 + [ctypes.c_double] * 2 + [_vp] * 4),
     'emg3d_dev_spline_filter': (_ci, [_vp] + [_ci] * 4 + [_vp]),
     'emg3d_dev_spline_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _ci, _vp, _vp]),

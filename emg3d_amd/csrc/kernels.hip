@@ -1591,3 +1591,4 @@ int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex)
 
 #include "receivers.h"
 #include "krylov.h"
+#include "adjoint.h"

@@ -1,0 +1,162 @@
+"""Data misfit and adjoint-state gradient.
+
+The reference obtains both from ``Simulation`` (emg3d/simulations.py:943-1094 ``gradient``,
+:1097-1190 ``misfit``, :1193-1268 ``_bcompute`` / ``_get_rfield``) whose bookkeeping lives in
+xarray datasets and whose solves run in a process pool. Here the same computation is a plain
+function over (source, frequency) pairs, sharded over the ranks of the process group like the
+forward solves of ``parallel.compute``:
+
+    per pair, on its GPU
+      1. forward solve                      -> efield stays in HBM
+      2. responses at the receivers         (linear interpolation on the device, as the exact
+                                             adjoint requires, simulations.py:975-983)
+      3. residual = synthetic - observed;   misfit += sum w |residual|^2 / 2
+      4. residual source field              = sum over receivers of a point dipole at the receiver
+                                              with strength conj(residual w / (-s mu0))
+      5. back-propagated solve, same hierarchy (levels, line factors, graphs)  -> bfield in HBM
+      6. gradient += cells(real(bfield s mu0 efield))      (emg3d_dev_gradient_accumulate)
+    once
+      7. all-reduce of the cell gradient and of the misfit over the ranks (RCCL)
+      8. anisotropy bookkeeping and the derivative chain of the property mapping (host, one pass)
+
+Limits as in the reference: electric point receivers, no epsilon_r / mu_r; and, here, the
+computational grid must be the model grid (the reference maps back with discretize).
+"""
+import numpy as np
+
+from emg3d_amd import fields, models
+from emg3d_amd.fields import Field
+
+__all__ = ['misfit_and_gradient', 'residual_source_field']
+
+_DCHAIN = {          # d sigma / d property, applied to the gradient w.r.t. conductivity (emg3d/maps.py:120-330)
+    'Conductivity': lambda g, p: g,
+    'Resistivity': lambda g, p: g * -(1.0 / p) ** 2,
+    'LgConductivity': lambda g, p: g * (10.0 ** p) * np.log(10.0),
+    'LgResistivity': lambda g, p: g * -(10.0 ** -p) * np.log(10.0),
+    'LnConductivity': lambda g, p: g * np.exp(p),
+    'LnResistivity': lambda g, p: g * -np.exp(-p),
+}
+
+
+def residual_source_field(grid, frequency, receivers, residual, weight):
+    """Source field of the back-propagation (``Simulation._get_rfield``, simulations.py:1235-1268):
+    every receiver with data acts as a point dipole of strength ``conj(residual weight / (-s mu0))``.
+    ``receivers``: sequence of (x, y, z, azimuth, elevation); ``residual`` / ``weight``: one value per
+    receiver (NaN residual: no data)."""
+    rfield = Field(grid, frequency=frequency)
+    strength = np.conj(np.asarray(residual) * np.asarray(weight) / -rfield.smu0)
+    index, value = [], []
+    for rec, res, st in zip(receivers, np.asarray(residual), strength):
+        if np.isnan(res):
+            continue
+        part = fields.get_source_field(grid, tuple(rec), frequency, strength=st)
+        index.append(part._sparse[0])
+        value.append(part._sparse[1])
+    if index:
+        index, value = np.concatenate(index), np.concatenate(value)
+        np.add.at(rfield._field, index, value)
+        nz = np.unique(index)
+        rfield._sparse = (nz, rfield._field[nz].copy())
+    else:
+        rfield._sparse = (np.zeros(0, dtype=np.int64), np.zeros(0, dtype=rfield._field.dtype))
+    return rfield
+
+
+def _receiver_tuple(receivers):
+    r = np.asarray(receivers, dtype=float)
+    return tuple(r[:, k] for k in range(5))
+
+
+def misfit_and_gradient(model, sources, frequencies, receivers, observed, weights=None, solver_opts=None,
+                        tol_gradient=1e-5, costs=None):
+    """Misfit ``sum w |synthetic - observed|^2 / 2`` and its adjoint-state gradient with respect to
+    the model properties (shape (nx, ny, nz) for isotropic models, (2, ...) HTI / VTI, (3, ...)
+    tri-axial, as ``Simulation.gradient``).
+
+    sources: dict name -> source coordinates; frequencies: dict name -> Hz; receivers: sequence of
+    (x, y, z, azimuth, elevation) electric point receivers; observed / weights: dict
+    (source name, frequency name) -> one value per receiver (NaN: no data; weights default 1).
+    With an initialised process group the pairs are sharded over the ranks and both results are
+    all-reduced: every rank returns the complete misfit and gradient."""
+    import torch
+    from emg3d_amd import _lib, parallel, solver
+    from emg3d_amd._device import _ptr, _stream
+    _lib.require_gpu()
+    for name, prop in (('el. permittivity', model.epsilon_r), ('magn. permeability', model.mu_r)):
+        if prop is not None and not np.allclose(prop, 1.0):
+            raise NotImplementedError(f"Gradient not implemented for {name}.")
+    grid = model.grid
+    opts = dict(solver_opts or {})
+    opts.setdefault('sslsolver', True)
+    rec = _receiver_tuple(receivers)
+    pairs = parallel.srcfreq_pairs(sources, frequencies)
+    rank, world = parallel.rank_and_world()
+    mine = parallel.shard(len(pairs), rank, world, costs)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    nx, ny, nz = grid.shape_cells
+    ncell = grid.n_cells
+    grad = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
+    vol = torch.from_numpy(np.ascontiguousarray(grid.cell_volumes, dtype=np.float64)).to(dev)
+    misfit = 0.0
+    hierarchies = {}
+    info = {}
+    for i in mine:
+        sname, fname = pairs[i]
+        freq = frequencies[fname]
+        sfield = fields.get_source_field(grid, sources[sname], freq)
+        hier = hierarchies.get(complex(sfield.sval))
+        if hier is None:
+            hierarchies.clear()                       # one frequency at a time in HBM
+            hier = hierarchies[complex(sfield.sval)] = solver.Hierarchy(models.VolumeModel(model, sfield))
+        top = hier.top
+        _, finfo = solver.solve(model, sfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
+                                _sparse_source=True, **opts)
+        e_fwd = torch.empty_like(top.e)
+        _lib.check(_lib.lib().emg3d_dev_copy(_ptr(e_fwd), _ptr(top.e), top.e.numel() * top.e.element_size(), _stream()),
+                   'emg3d_dev_copy')
+        meta = Field(grid, frequency=freq)
+        synthetic = fields.get_receiver(meta, rec, 'linear', device_field=e_fwd)
+        obs = np.asarray(observed[(sname, fname)])
+        w = np.ones(obs.shape) if weights is None else np.asarray(weights[(sname, fname)], dtype=float)
+        residual = synthetic - obs
+        have = ~np.isnan(residual)
+        misfit += float(np.sum(w[have] * (residual[have].conj() * residual[have])).real) / 2
+        rfield = residual_source_field(grid, freq, receivers, residual, w)
+        _, binfo = solver.solve(model, rfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
+                                _sparse_source=True, **{**opts, 'tol': tol_gradient})
+        smu0 = complex(sfield.smu0)
+        o1, o2 = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y
+        _lib.check(_lib.lib().emg3d_dev_gradient_accumulate(
+            nx, ny, nz, int(top.is_complex), _ptr(e_fwd), _ptr(e_fwd, o1), _ptr(e_fwd, o2),
+            _ptr(top.e), _ptr(top.e, o1), _ptr(top.e, o2), smu0.real, smu0.imag, _ptr(vol),
+            _ptr(grad), _ptr(grad, ncell), _ptr(grad, 2 * ncell), _stream()), 'emg3d_dev_gradient_accumulate')
+        info[(sname, fname)] = {'forward': finfo, 'backward': binfo, 'synthetic': synthetic}
+    # the one collective of the path: sum over the ranks
+    tm = torch.tensor([misfit], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist = parallel._dist()
+        cdev = dev if dist.get_backend() == 'nccl' else torch.device('cpu')
+        g, m = grad.to(cdev), tm.to(cdev)
+        dist.all_reduce(g)
+        dist.all_reduce(m)
+        grad, tm = g, m
+    misfit = float(tm.cpu()[0])
+    g3 = np.stack([grad[k * ncell:(k + 1) * ncell].cpu().numpy().reshape((nx, ny, nz), order='F') for k in range(3)])
+
+    # anisotropy bookkeeping + derivative chain of the mapping (simulations.py:1070-1090)
+    chain = _DCHAIN[model.mapping]
+    keep = [0]
+    if model.case in ('HTI', 'triaxial'):
+        g3[1] = chain(g3[1], model.property_y)
+        keep.append(1)
+    else:
+        g3[0] += g3[1]
+    if model.case in ('VTI', 'triaxial'):
+        g3[2] = chain(g3[2], model.property_z)
+        keep.append(2)
+    else:
+        g3[0] += g3[2]
+    g3[0] = chain(g3[0], model.property_x)
+    return misfit, np.asfortranarray(g3[keep].squeeze()), info
+

@@ -62,6 +62,14 @@ def finalize():
         dist.destroy_process_group()
 
 
+def rank_and_world():
+    """(rank, world size) of the process group; (0, 1) without one."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def srcfreq_pairs(sources, frequencies):
     """All (source, frequency) keys in the reference's order: product(sources, frequencies)
     (emg3d/simulations.py:1453-1464)."""

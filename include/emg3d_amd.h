@@ -278,6 +278,17 @@ int emg3d_dev_spline_eval(const void *coef, int n0, int n1, int n2, int is_compl
 int emg3d_dev_linear_eval(const void *values, int n0, int n1, int n2, int is_complex,
                           const int32_t *idx, const double *w, int npts, void *out, void *stream);
 
+/* ---- adjoint-state gradient ---------------------------------------------
+ * Simulation.gradient (emg3d/simulations.py:1041-1063) per source-frequency pair:
+ * gfield = real(bfield * s mu0 * efield) on the edges, maps.interp_edges_to_vol_averages
+ * (emg3d/maps.py:667-719) to the cells, added to the gradient -- one kernel over the cells with
+ * the forward field e* and the back-propagated field b* in HBM. volumes (nx,ny,nz), g* (nx,ny,nz)
+ * doubles, accumulated (+=): the three components of the reference's (3, nx, ny, nz) array. */
+int emg3d_dev_gradient_accumulate(int nx, int ny, int nz, int is_complex, const void *ex, const void *ey,
+                                  const void *ez, const void *bx, const void *by, const void *bz,
+                                  double smu0_re, double smu0_im, const double *volumes, double *gx,
+                                  double *gy, double *gz, void *stream);
+
 /* ---- before a solve: model re-gridding -------------------------------
  * maps.interp_volume_average (emg3d/maps.py:555-616) behind Model.interpolate_to_grid
  * (emg3d/models.py:322-366). values (nx,ny,nz) -> out (mx,my,mz), doubles, x fastest. Per axis

@@ -40,3 +40,13 @@ def golden_receivers():
 @pytest.fixture(scope='session')
 def golden_gridding():
     return np.load(os.path.join(GOLDEN, 'gridding.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_solves32():
+    return np.load(os.path.join(GOLDEN, 'solves32.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_gradient():
+    return np.load(os.path.join(GOLDEN, 'gradient.npz'), allow_pickle=False)

@@ -1287,3 +1287,103 @@ def test_bench_two_ranks_through_its_own_launcher():
     # two independent sources: twice the cell-sweeps of one rank per step
     assert out['config']['cell_sweeps_per_step'] > 0
     assert out['value'] == pytest.approx(2 * out['config']['cell_sweeps_per_step'] * 3 / (out['ms_per_step'] * 3e-3) / 1e6, rel=0.02)
+
+
+@pytest.mark.parametrize('name,cycles', [('uni32_F', 10), ('marine32_W', 8)])
+def test_32cubed_solves_vs_the_reference_itself(golden_solves32, name, cycles):
+    """Converged fields of the reference (imported un-jitted in the build container,
+    tools/make_golden.py solves32) at 32^3: BASELINE.json config 1 (plain F-cycle: the point
+    smoother) and a stretched marine VTI model with W-cycle + semicoarsening + line relaxation.
+    GPU at tol 1e-10: rel-L2 <= 1e-8 (the bar of BASELINE.json)."""
+    g = golden_solves32
+    p = name + '_'
+    grid = emg3d.TensorMesh([g[p + 'hx'], g[p + 'hy'], g[p + 'hz']], g[p + 'origin'])
+    kwm = {'property_x': g[p + 'res_x']}
+    if p + 'res_z' in g.files:
+        kwm['property_z'] = g[p + 'res_z']
+    model = emg3d.Model(grid, **kwm)
+    sfield = emg3d.get_source_field(grid, g[p + 'source'], float(g[p + 'frequency']))
+    kw = {k[len(p) + 3:]: g[k].item() for k in g.files if k.startswith(p + 'kw_')}
+    for k in ('semicoarsening', 'linerelaxation'):
+        if isinstance(kw[k], (bool, np.bool_)):
+            kw[k] = bool(kw[k])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **kw)
+    assert info['exit'] == 0, info['exit_message']
+    assert relerr(e.field, g[p + 'efield']) < 1e-8
+    assert int(g[p + 'tol1e-10_it_mg']) == cycles and abs(info['it_mg'] - cycles) <= 3
+    if name == 'uni32_F':          # config 1 as stated: tol 1e-6
+        _, i6 = emg3d.solve(model, sfield, sslsolver=False, tol=1e-6, return_info=True, **kw)
+        assert i6['exit'] == 0 and abs(i6['it_mg'] - 6) <= 1
+
+
+def test_gradient_kernel_and_adjoint_gradient_vs_reference(golden_gradient):
+    """SURVEY.md 8f rank 4. (1) emg3d_dev_gradient_accumulate on the reference's forward and
+    back-propagated fields against maps.interp_edges_to_vol_averages of real(b smu0 e) (1e-14);
+    (2) gradient.misfit_and_gradient -- forward solve, linear responses, residual source,
+    back-propagation, cell reduction, derivative chain -- against the misfit and gradient the
+    reference's functions give for the same data (solves at tol 1e-9: 1e-5)."""
+    from emg3d_amd import gradient
+    from emg3d_amd._device import _ptr
+    g = golden_gradient
+    grid = emg3d.TensorMesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    nx, ny, nz = grid.shape_cells
+    dev = torch.device('cuda')
+    e, b = torch.from_numpy(g['efield']).to(dev), torch.from_numpy(g['bfield']).to(dev)
+    vol = torch.from_numpy(np.ascontiguousarray(grid.cell_volumes)).to(dev)
+    out = torch.zeros(3 * grid.n_cells, dtype=torch.float64, device=dev)
+    smu0 = 2j * np.pi * float(g['frequency']) * float(g['meta_mu_0'])
+    o1, o2, nc = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y, grid.n_cells
+    for _ in range(2):      # accumulates
+        _lib.check(_lib.lib().emg3d_dev_gradient_accumulate(
+            nx, ny, nz, 1, _ptr(e), _ptr(e, o1), _ptr(e, o2), _ptr(b), _ptr(b, o1), _ptr(b, o2), smu0.real, smu0.imag,
+            _ptr(vol), _ptr(out), _ptr(out, nc), _ptr(out, 2 * nc), None), 'emg3d_dev_gradient_accumulate')
+    got = out.cpu().numpy().reshape(3, nz, ny, nx).transpose(0, 3, 2, 1)
+    assert relerr(got, 2 * g['grad_cells_raw']) < 1e-14
+
+    model = emg3d.Model(grid, property_x=g['res_x'], property_z=g['res_z'])
+    key = ('s1', 'f1')
+    misfit, grad, info = gradient.misfit_and_gradient(
+        model, {'s1': tuple(g['source'])}, {'f1': float(g['frequency'])}, g['receivers'], {key: g['observed']},
+        {key: g['weights']}, solver_opts=dict(tol=1e-9), tol_gradient=1e-9)
+    have = ~np.isnan(g['observed'])
+    assert np.allclose(info[key]['synthetic'][have], g['synthetic'][have], rtol=1e-6)
+    assert misfit == pytest.approx(float(g['misfit']), rel=1e-5)
+    assert grad.shape == (2, nx, ny, nz)
+    assert relerr(grad, g['gradient']) < 1e-5
+
+
+def test_adjoint_gradient_vs_finite_differences():
+    """The gradient is the derivative of the misfit: central differences of the misfit with
+    respect to the resistivity of single cells (isotropic model, two sources, one frequency,
+    both solves at tol 1e-10) agree with the adjoint-state gradient to 1 %, as in the
+    reference's own test (tests/test_simulations.py: test_gradient / FD check)."""
+    from emg3d_amd import gradient
+    rng = np.random.default_rng(3)
+    hx = widths(4, 3, 50., 1.3)
+    hz = widths(4, 2, 40., 1.3)
+    grid = emg3d.TensorMesh([hx, hx, hz], (-hx.sum() / 2, -hx.sum() / 2, -hz[:4].sum()))
+    shape = grid.shape_cells
+    rho = 10 ** rng.uniform(-0.2, 0.5, shape)
+    srcs = {'a': (-60., 0., -30., 0., 0.), 'b': (40., 30., -30., 90., 0.)}
+    freqs = {'f': 1.0}
+    recs = np.array([[70., 10., -40., 0., 0.], [-30., -60., -40., 90., 0.], [10., 80., -25., 45., 0.]])
+    true = emg3d.Model(grid, property_x=rho * (1 + 0.3 * rng.standard_normal(shape) * 0.5).clip(0.5, 2.0))
+    opts = dict(tol=1e-10, sslsolver=True)
+    obs = {}
+    for s in srcs:
+        ef = emg3d.solve(true, emg3d.get_source_field(grid, srcs[s], 1.0), **opts)
+        obs[(s, 'f')] = emg3d.fields.get_receiver(ef, tuple(recs[:, k] for k in range(5)), 'linear')
+    wts = {k: 1.0 / (0.05 * np.abs(v)) ** 2 for k, v in obs.items()}
+
+    def phi(r):
+        return gradient.misfit_and_gradient(emg3d.Model(grid, property_x=r), srcs, freqs, recs, obs, wts,
+                                            solver_opts=opts, tol_gradient=1e-10)
+    m0, g0, _ = phi(rho)
+    assert g0.shape == shape and m0 > 0
+    for cell in ((5, 5, 4), (3, 6, 3), (6, 4, 5)):
+        d = 1e-3 * rho[cell]
+        rp, rm = rho.copy(), rho.copy()
+        rp[cell] += d
+        rm[cell] -= d
+        fd = (phi(rp)[0] - phi(rm)[0]) / (2 * d)
+        assert fd == pytest.approx(g0[cell], rel=1e-2), (cell, fd, g0[cell])

@@ -268,3 +268,18 @@ def test_direction_schedule_and_stop_rules():
     assert stop_reason(V, 11.0, 1, 1) == ("DIVERGED", True)
     assert stop_reason(V, 0.5, 0.4, 3) == ("STAGNATED", True)
     assert stop_reason(V, 0.5, 0.6, 4)[0].startswith("MAX.") and stop_reason(V, 0.5, 0.6, 3) is None
+
+
+def test_residual_source_field_vs_reference(golden_gradient):
+    """gradient.residual_source_field (Simulation._get_rfield, emg3d/simulations.py:1235-1268): the
+    residual source the reference's own functions assemble for the fixture's receivers."""
+    from emg3d_amd import gradient
+    g = golden_gradient
+    grid = emg3d.TensorMesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    residual = g['synthetic'] - g['observed']
+    rf = gradient.residual_source_field(grid, float(g['frequency']), g['receivers'], residual, g['weights'])
+    assert relerr(rf.field, g['rfield']) < 1e-12
+    idx, val = rf._sparse
+    dense = np.zeros_like(rf.field)
+    dense[idx] = val
+    assert np.array_equal(dense, rf.field)

@@ -180,6 +180,53 @@ def test_solver_vs_reference_solves(golden_solves, name):
     assert relerr(e.field, g[p + 'efield']) < 1e-11
 
 
+def _case32(g, name):
+    """Model and source of a tests/golden/solves32.npz case, re-derived with this repo's host code
+    (volume model and source field are pinned against the reference in test_host_api.py)."""
+    import emg3d_amd as emg3d
+    p = name + '_'
+    grid = emg3d.TensorMesh([g[p + 'hx'], g[p + 'hy'], g[p + 'hz']], g[p + 'origin'])
+    sf = emg3d.get_source_field(grid, g[p + 'source'], float(g[p + 'frequency']))
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    shape = grid.shape_cells
+    rx = np.asarray(g[p + 'res_x'], dtype=float)
+    cx = 1.0 / (np.full(shape, float(rx)) if rx.ndim == 0 else rx.reshape(shape, order='F'))
+    cz = 1.0 / g[p + 'res_z'].reshape(shape, order='F') if p + 'res_z' in g.files else None
+    vm = mg_ref.volume_model(ogrid, float(g[p + 'frequency']), cx, None, cz)
+    kw = {k[len(p) + 3:]: g[k].item() for k in g.files if k.startswith(p + 'kw_')}
+    for k in ('semicoarsening', 'linerelaxation'):
+        if isinstance(kw[k], (bool, np.bool_)):
+            kw[k] = bool(kw[k])
+    return grid, sf, ogrid, vm, kw
+
+
+def test_config1_32cubed_vs_reference(golden_solves32):
+    """BASELINE.json config 1 (32^3 uniform fullspace, x-dipole, 1 Hz, plain F-cycle) solved by the
+    reference itself: 6 cycles and a relative error of 1.784e-07 at tol 1e-6, the
+    same cycle by cycle for the oracle; the converged field at tol 1e-10 to 1e-10."""
+    g = golden_solves32
+    grid, sf, ogrid, vm, kw = _case32(g, 'uni32_F')
+    assert int(g['uni32_F_tol1e-06_it_mg']) == 6 and abs(float(g['uni32_F_tol1e-06_rel_error']) - 1.784e-07) < 5e-11
+    e, info = mg_ref.solve(vm, mg_ref.Field(ogrid, sf.field.copy()), tol=1e-6, **kw)
+    assert info['it_mg'] == 6 and info['exit_message'] == 'CONVERGED'
+    assert np.allclose(info['error_at_cycle'], g['uni32_F_tol1e-06_error_at_cycle'], rtol=1e-6)
+    assert abs(info['rel_error'] - 1.784e-07) < 5e-11
+    e, info = mg_ref.solve(vm, mg_ref.Field(ogrid, sf.field.copy()), tol=1e-10, **kw)
+    assert info['it_mg'] == int(g['uni32_F_tol1e-10_it_mg']) == 10
+    assert relerr(e.field, g['uni32_F_efield']) < 1e-10
+
+
+def test_marine32_w_cycle_vs_reference(golden_solves32):
+    """32^3 stretched marine VTI model, W-cycle + semicoarsening + line relaxation, reference
+    solve at tol 1e-10 (8 cycles): the oracle reproduces history and field."""
+    g = golden_solves32
+    grid, sf, ogrid, vm, kw = _case32(g, 'marine32_W')
+    e, info = mg_ref.solve(vm, mg_ref.Field(ogrid, sf.field.copy()), tol=1e-10, **kw)
+    assert info['it_mg'] == int(g['marine32_W_tol1e-10_it_mg']) == 8
+    assert np.allclose(info['error_at_cycle'], g['marine32_W_tol1e-10_error_at_cycle'], rtol=1e-6)
+    assert relerr(e.field, g['marine32_W_efield']) < 1e-10
+
+
 def test_solver_vs_reference_regression_file(golden_regression):
     """The reference's own golden file: F/W/V on 8x8x16 (tests/test_solver.py:18-60),
     reg_2 (sc=123, lr=456, :152-199), Laplace (:227-253). The stored file predates

@@ -349,6 +349,62 @@ def solves32():
     print('solves32.npz written')
 
 
+def gradient():
+    """Misfit and adjoint-state gradient of a small problem, computed with the reference's own
+    functions in the order Simulation.gradient / _get_rfield use them (emg3d/simulations.py:
+    1041-1090, 1235-1268; Survey / Simulation themselves need xarray, which is not installed):
+    forward solve, linear receiver responses, residual source, back-propagated solve,
+    real(bfield smu0 efield), maps.interp_edges_to_vol_averages, derivative chain of the
+    resistivity mapping. Also raw input / output vectors of interp_edges_to_vol_averages."""
+    from emg3d import maps as rmaps, fields as rfields
+    rng = np.random.default_rng(21)
+    out = dict(META)
+    hx = widths(6, 3, 40, 1.3); hy = widths(4, 3, 50, 1.25); hz = widths(4, 2, 30, 1.4)
+    grid = emg3d.TensorMesh([hx, hy, hz], origin=(-hx.sum() / 2, -hy.sum() / 2, -hz[:5].sum()))
+    shape = grid.shape_cells
+    rho_h = 10 ** rng.uniform(-0.3, 0.7, shape)
+    rho_v = rho_h * rng.uniform(1.0, 2.5, shape)
+    model = emg3d.Model(grid, property_x=rho_h, property_z=rho_v, mapping='Resistivity')
+    freq, src = 0.8, (-45., 10., -20., 15., 5.)
+    recs = np.array([[60., -20., -35., 0., 0.], [95., 30., -35., 90., 0.], [-110., 40., -50., 30., 10.],
+                     [20., 75., -15., 0., 90.]])
+    rec_t = tuple(recs[:, k] for k in range(5))
+    solver_opts = dict(sslsolver=True, semicoarsening=True, linerelaxation=True, verb=0, tol=1e-9)
+    sfield = emg3d.get_source_field(grid, src, freq)
+    efield = rsolver.solve(model, sfield, **solver_opts)
+    synthetic = rfields.get_receiver(efield, rec_t, method='linear')
+    observed = synthetic * (1 + 0.15 * (rng.standard_normal(4) + 1j * rng.standard_normal(4)))
+    observed[3] = np.nan                                   # a receiver without data
+    weights = 1.0 / (0.05 * np.abs(observed)) ** 2
+    weights[3] = 0.0
+    residual = synthetic - observed
+    have = ~np.isnan(residual)
+    misfit = np.sum(weights[have] * (residual[have].conj() * residual[have])).real / 2
+    rfield = emg3d.Field(grid, frequency=freq)
+    strength = np.conj(residual * weights / -rfield.smu0)
+    for i in range(4):
+        if np.isnan(residual[i]):
+            continue
+        rfield.field += emg3d.get_source_field(grid, tuple(recs[i]), freq, strength=strength[i]).field
+    bfield = rsolver.solve(model, rfield, **{**solver_opts, 'tol': 1e-9})
+    gfield = emg3d.Field(grid, data=np.real(bfield.field * efield.smu0 * efield.field))
+    grad = np.zeros((3, *shape), order='F')
+    vol = grid.cell_volumes.reshape(shape, order='F')
+    rmaps.interp_edges_to_vol_averages(ex=gfield.fx, ey=gfield.fy, ez=gfield.fz, volumes=vol,
+                                       ox=grad[0], oy=grad[1], oz=grad[2])
+    raw = grad.copy()
+    mp = rmaps.MapResistivity()
+    mp.derivative_chain(grad[2], model.property_z)
+    grad[0] += grad[1]
+    mp.derivative_chain(grad[0], model.property_x)
+    out.update(hx=hx, hy=hy, hz=hz, origin=np.asarray(grid.origin, float), res_x=rho_h, res_z=rho_v,
+               frequency=freq, source=np.asarray(src), receivers=recs, observed=observed, weights=weights,
+               synthetic=synthetic, misfit=misfit, gradient=grad[[0, 2]], rfield=rfield.field,
+               efield=efield.field, bfield=bfield.field, grad_cells_raw=raw)
+    np.savez_compressed(os.path.join(OUT, 'gradient.npz'), **out)
+    print(f'gradient.npz written: misfit {misfit:.6e}, |grad| {np.linalg.norm(grad[[0, 2]]):.4e}')
+
+
 def receivers():
     """Magnetic field and receiver responses: inputs and the outputs of
     the reference's fields.get_magnetic_field / fields.get_receiver (cubic and linear), for a
@@ -452,3 +508,5 @@ if __name__ == '__main__':
         solves()
     if 'solves32' in which:
         solves32()
+    if 'gradient' in which:
+        gradient()
