@@ -218,6 +218,56 @@ def _segment_to_edges(grid, p0, p1, out):
             add(ez(ix + 1, iy + 1, iz), piece[2] * rx * ry)
 
 
+def _point_weights(nodes, value):
+    """Lower index, upper index and weight of the upper one for `value` between the ascending
+    `nodes` (emg3d/fields.py:695-713: `point_source` / `get_index_and_strength`)."""
+    i = max(0, int(np.nonzero(value < np.r_[nodes, np.inf])[0][0]) - 1)
+    if i == nodes.size - 1:
+        return i, i, 1.0            # (the reference sets both weights to 1 on the last node)
+    return i, i + 1, (value - nodes[i]) / (nodes[i + 1] - nodes[i])
+
+
+def get_point_source_field(grid, coordinates, frequency, strength=1.0):
+    """Source field of an electric POINT dipole ``(x, y, z, azimuth, elevation)``: the adjoint of
+    the tri-linear interpolation of each field component to that point (the reference's
+    ``_point_vector``, emg3d/fields.py:662-746, used for ``TxElectricPoint`` -- the adjoint source
+    of a point receiver, emg3d/electrodes.py:683). Component c is spread over the eight values of
+    that component around the point, in the coordinates that component lives on (cell centres
+    along its own direction, nodes across)."""
+    c = np.asarray(coordinates, dtype=float)
+    lo = np.array([grid.nodes_x[0], grid.nodes_y[0], grid.nodes_z[0]])
+    hi = np.array([grid.nodes_x[-1], grid.nodes_y[-1], grid.nodes_z[-1]])
+    if np.any(c[:3] < lo) or np.any(c[:3] > hi):
+        raise ValueError(f"Provided source outside grid: {c}.")
+    sfield = Field(grid, frequency=frequency, dtype=None if frequency is not None else np.float64)
+    direction = _rotation(c[3], c[4])
+    nodes = (grid.nodes_x, grid.nodes_y, grid.nodes_z)
+    centres = (grid.cell_centers_x, grid.cell_centers_y, grid.cell_centers_z)
+    scale = strength * (-sfield.smu0 if frequency is not None else 1.0)
+    index, values = [], []
+    offset = 0
+    for comp in range(3):
+        shape = sfield._shapes[comp]
+        axes = [centres[a] if a == comp else nodes[a] for a in range(3)]
+        (i0, i1, rx), (j0, j1, ry), (k0, k1, rz) = (_point_weights(axes[a], c[a]) for a in range(3))
+        wx = ((i0, 1.0 - rx), (i1, rx)) if i0 != i1 else ((i0, 1.0),)
+        wy = ((j0, 1.0 - ry), (j1, ry)) if j0 != j1 else ((j0, 1.0),)
+        wz = ((k0, 1.0 - rz), (k1, rz)) if k0 != k1 else ((k0, 1.0),)
+        for k, wk in wz:
+            for j, wj in wy:
+                for i, wi in wx:
+                    index.append(offset + i + shape[0] * (j + shape[1] * k))
+                    values.append(wi * wj * wk * direction[comp])
+        offset += sfield._sizes[comp]
+    index = np.array(index, dtype=np.int64)
+    values = (np.array(values) * scale).astype(sfield._field.dtype)
+    keep = values != 0
+    index, values = index[keep], values[keep]
+    sfield._field[index] = values
+    sfield._sparse = (index, values)
+    return sfield
+
+
 def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs):
     """Source field ``-s mu_0 J_s`` of an electric dipole or wire.
 

@@ -41,7 +41,8 @@ _DCHAIN = {          # d sigma / d property, applied to the gradient w.r.t. cond
 
 def residual_source_field(grid, frequency, receivers, residual, weight):
     """Source field of the back-propagation (``Simulation._get_rfield``, simulations.py:1235-1268):
-    every receiver with data acts as a point dipole of strength ``conj(residual weight / (-s mu0))``.
+    every receiver with data acts as a point dipole of strength ``conj(residual weight / (-s mu0))``
+    (``TxElectricPoint``: the adjoint of the tri-linear receiver interpolation).
     ``receivers``: sequence of (x, y, z, azimuth, elevation); ``residual`` / ``weight``: one value per
     receiver (NaN residual: no data)."""
     rfield = Field(grid, frequency=frequency)
@@ -50,7 +51,7 @@ def residual_source_field(grid, frequency, receivers, residual, weight):
     for rec, res, st in zip(receivers, np.asarray(residual), strength):
         if np.isnan(res):
             continue
-        part = fields.get_source_field(grid, tuple(rec), frequency, strength=st)
+        part = fields.get_point_source_field(grid, tuple(rec), frequency, strength=st)
         index.append(part._sparse[0])
         value.append(part._sparse[1])
     if index:

