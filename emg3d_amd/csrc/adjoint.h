@@ -87,3 +87,126 @@ int emg3d_dev_gradient_accumulate(int nx, int ny, int nz, int is_complex, const 
 }
 
 }  // extern "C"
+
+// ---- before a solve: the source vector of a dipole or wire on the
+// device. The reference (fields._dipole_vector, emg3d/fields.py:792-938) walks, per straight
+// segment, over the cells of its bounding box and clips the segment against each cell; here one
+// thread walks along its segment from grid plane to grid plane (the crossing parameters of the
+// three axes are three increasing sequences, merged on the fly) and deposits every piece -- its
+// x / y / z extent on the four edges of that direction of the cell holding the piece's midpoint,
+// weighted bilinearly in the two transverse coordinates of the midpoint -- with atomic adds.
+namespace {
+
+__device__ __forceinline__ int src_cell(const double *nodes, int n, double v)
+{   // index of the cell [nodes[i], nodes[i+1]) that holds v, clamped to 0 .. n-1 (n cells)
+    int lo = 0, hi = n + 1;                      // upper_bound over the n + 1 nodes
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (nodes[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    const int i = lo - 1;
+    return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+}
+template <class T> __device__ __forceinline__ void src_add(T *p, double v, cplx scale);
+template <> __device__ __forceinline__ void src_add<cplx>(cplx *p, double v, cplx scale)
+{
+    atomicAdd(&p->re, v * scale.re);
+    atomicAdd(&p->im, v * scale.im);
+}
+template <> __device__ __forceinline__ void src_add<double>(double *p, double v, cplx scale) { atomicAdd(p, v * scale.re); }
+
+template <class T>
+__global__ __launch_bounds__(64) void k_source_segments(int nx, int ny, int nz, const double *nodes_x, const double *nodes_y,
+                                                        const double *nodes_z, const double *hx, const double *hy,
+                                                        const double *hz, const double *points, int nseg, cplx scale,
+                                                        T *sx, T *sy, T *sz)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const double *nodes[3] = {nodes_x, nodes_y, nodes_z};
+    const double *h[3] = {hx, hy, hz};
+    const int n[3] = {nx, ny, nz};
+    double p0[3], d[3];
+    int k[3], kend[3], step[3];
+    for (int a = 0; a < 3; ++a) {
+        p0[a] = points[3 * s + a];
+        d[a] = points[3 * (s + 1) + a] - p0[a];
+        // grid planes crossed strictly inside the segment, in the order of the walk
+        const double lo = d[a] > 0 ? p0[a] : p0[a] + d[a], hi = d[a] > 0 ? p0[a] + d[a] : p0[a];
+        int first = 0, last = n[a];
+        while (first <= n[a] && !(nodes[a][first] > lo)) ++first;       // first node > lo
+        while (last >= 0 && !(nodes[a][last] < hi)) --last;              // last node < hi
+        if (d[a] == 0.0 || first > last) { k[a] = 0; kend[a] = -1; step[a] = 1; }
+        else if (d[a] > 0) { k[a] = first; kend[a] = last; step[a] = 1; }
+        else { k[a] = last; kend[a] = first; step[a] = -1; }
+    }
+    auto remaining = [&](int a) { return kend[a] >= 0 && (step[a] > 0 ? k[a] <= kend[a] : k[a] >= kend[a]); };
+    auto tcross = [&](int a) { return (nodes[a][k[a]] - p0[a]) / d[a]; };
+    double t0 = 0.0;
+    for (;;) {
+        double t1 = 1.0;
+        for (int a = 0; a < 3; ++a)
+            if (remaining(a)) { const double t = tcross(a); if (t < t1) t1 = t; }
+        for (int a = 0; a < 3; ++a)             // crossings that coincide (a corner, an edge) count once
+            while (remaining(a) && tcross(a) <= t1 + 1e-14) k[a] += step[a];
+        if (t1 - t0 > 1e-14) {
+            int c[3];
+            double r[3];
+            for (int a = 0; a < 3; ++a) {
+                const double mid = p0[a] + 0.5 * (t0 + t1) * d[a];
+                c[a] = src_cell(nodes[a], n[a], mid);
+                r[a] = (mid - nodes[a][c[a]]) / h[a][c[a]];
+            }
+            const double w = t1 - t0;
+            const int ix = c[0], iy = c[1], iz = c[2];
+            const double rx = r[0], ry = r[1], rz = r[2];
+            if (d[0] != 0.0) {
+                const double m = w * d[0];
+                src_add<T>(sx + ((size_t)ix + (size_t)nx * (iy + (size_t)(ny + 1) * iz)), m * (1 - ry) * (1 - rz), scale);
+                src_add<T>(sx + ((size_t)ix + (size_t)nx * (iy + 1 + (size_t)(ny + 1) * iz)), m * ry * (1 - rz), scale);
+                src_add<T>(sx + ((size_t)ix + (size_t)nx * (iy + (size_t)(ny + 1) * (iz + 1))), m * (1 - ry) * rz, scale);
+                src_add<T>(sx + ((size_t)ix + (size_t)nx * (iy + 1 + (size_t)(ny + 1) * (iz + 1))), m * ry * rz, scale);
+            }
+            if (d[1] != 0.0) {
+                const double m = w * d[1];
+                src_add<T>(sy + ((size_t)ix + (size_t)(nx + 1) * (iy + (size_t)ny * iz)), m * (1 - rx) * (1 - rz), scale);
+                src_add<T>(sy + ((size_t)ix + 1 + (size_t)(nx + 1) * (iy + (size_t)ny * iz)), m * rx * (1 - rz), scale);
+                src_add<T>(sy + ((size_t)ix + (size_t)(nx + 1) * (iy + (size_t)ny * (iz + 1))), m * (1 - rx) * rz, scale);
+                src_add<T>(sy + ((size_t)ix + 1 + (size_t)(nx + 1) * (iy + (size_t)ny * (iz + 1))), m * rx * rz, scale);
+            }
+            if (d[2] != 0.0) {
+                const double m = w * d[2];
+                src_add<T>(sz + ((size_t)ix + (size_t)(nx + 1) * (iy + (size_t)(ny + 1) * iz)), m * (1 - rx) * (1 - ry), scale);
+                src_add<T>(sz + ((size_t)ix + 1 + (size_t)(nx + 1) * (iy + (size_t)(ny + 1) * iz)), m * rx * (1 - ry), scale);
+                src_add<T>(sz + ((size_t)ix + (size_t)(nx + 1) * (iy + 1 + (size_t)(ny + 1) * iz)), m * (1 - rx) * ry, scale);
+                src_add<T>(sz + ((size_t)ix + 1 + (size_t)(nx + 1) * (iy + 1 + (size_t)(ny + 1) * iz)), m * rx * ry, scale);
+            }
+        }
+        if (t1 >= 1.0) break;
+        t0 = t1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int emg3d_dev_source_field(int nx, int ny, int nz, int is_complex, const double *nodes_x, const double *nodes_y,
+                           const double *nodes_z, const double *hx, const double *hy, const double *hz,
+                           const double *points, int npoints, double scale_re, double scale_im, void *sx, void *sy,
+                           void *sz, void *stream)
+{
+    if (!nodes_x || !points || !sx || !sy || !sz || npoints < 2) return fail(EMG3D_ERR_BADARG, "source_field: bad argument");
+    const int nseg = npoints - 1;
+    const dim3 grid(cdiv(nseg, 64)), block(64);
+    if (is_complex)
+        hipLaunchKernelGGL(k_source_segments<cplx>, grid, block, 0, (hipStream_t)stream, nx, ny, nz, nodes_x, nodes_y, nodes_z,
+                           hx, hy, hz, points, nseg, cplx(scale_re, scale_im), (cplx *)sx, (cplx *)sy, (cplx *)sz);
+    else
+        hipLaunchKernelGGL(k_source_segments<double>, grid, block, 0, (hipStream_t)stream, nx, ny, nz, nodes_x, nodes_y, nodes_z,
+                           hx, hy, hz, points, nseg, cplx(scale_re, 0.0), (double *)sx, (double *)sy, (double *)sz);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

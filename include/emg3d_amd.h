@@ -301,6 +301,15 @@ int emg3d_dev_volume_average(const double *values, int nx, int ny, int nz, const
                              const int32_t *iny, const int32_t *inz, const double *new_vol, int mx,
                              int my, int mz, double *out, void *stream);
 
+/* fields.get_source_field -> _dipole_vector (emg3d/fields.py:386-519, 792-938): the source vector
+ * of a dipole / wire through `npoints` points (device, npoints x 3, metres), times the complex
+ * factor `scale` (strength x (-s mu0)), ADDED to sx|sy|sz with atomic adds -- one thread walks one
+ * straight segment from grid plane to grid plane. nodes_* (n + 1) and h* (n): device doubles. */
+int emg3d_dev_source_field(int nx, int ny, int nz, int is_complex, const double *nodes_x, const double *nodes_y,
+                           const double *nodes_z, const double *hx, const double *hy, const double *hz,
+                           const double *points, int npoints, double scale_re, double scale_im, void *sx,
+                           void *sy, void *sz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
