@@ -317,7 +317,34 @@ def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs
         values = values * -sfield.smu0
     sfield._field[index] = values
     sfield._sparse = (index, values)     # valid only while the field is not modified (parallel.solve)
+    sfield._segments = (pts, complex(strength) if np.iscomplexobj(strength) else float(strength))
     return sfield
+
+
+def source_field_device(grid, points, frequency, strength=1.0, out=None):
+    """The source field of a wire through ``points`` (n x 3, n >= 2; a dipole is its two end
+    points) assembled ON THE DEVICE (``emg3d_dev_source_field``: one thread walks one segment
+    from grid plane to grid plane, csrc/adjoint.h) -- what ``get_source_field`` computes on the
+    host (reference emg3d/fields.py:386-519, 792-938), without a field-sized host array or
+    upload. Returns the device tensor ``[sx | sy | sz]``; ``out``: tensor to fill instead."""
+    torch, _lib, _ptr, _stream, dev = _device_tools()
+    meta = Field(grid, frequency=frequency, dtype=None if frequency is not None else np.float64)
+    dtype = torch.complex128 if np.iscomplexobj(meta.field) else torch.float64
+    if out is None:
+        out = torch.empty(grid.n_edges, dtype=dtype, device=dev)
+    lib = _lib.lib()
+    _lib.check(lib.emg3d_dev_zero(_ptr(out), out.numel() * out.element_size(), _stream()), 'emg3d_dev_zero')
+    pts = np.round(np.asarray(points, dtype=float), 9)
+    geo = np.concatenate([grid.nodes_x, grid.nodes_y, grid.nodes_z, grid.h[0], grid.h[1], grid.h[2], pts.ravel()])
+    g = torch.from_numpy(geo).to(dev)
+    nx, ny, nz = grid.shape_cells
+    o = np.cumsum([0, nx + 1, ny + 1, nz + 1, nx, ny, nz])
+    scale = complex(strength) * (-complex(meta.smu0) if frequency is not None else 1.0)
+    o1, o2 = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y
+    _lib.check(lib.emg3d_dev_source_field(
+        nx, ny, nz, int(dtype == torch.complex128), *[_ptr(g, int(o[k])) for k in range(7)], pts.shape[0],
+        scale.real, scale.imag, _ptr(out), _ptr(out, o1), _ptr(out, o2), _stream()), 'emg3d_dev_source_field')
+    return out
 
 
 # ---------------------------------------------------------------------------------------

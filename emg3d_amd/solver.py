@@ -516,7 +516,12 @@ class Hierarchy:
         ``parallel.solve``, which makes the field itself, asks for it) -- a dipole touches a
         handful of edges, the dense field is 100 MB at 128^3."""
         sp = getattr(sfield, '_sparse', None) if sparse else None
-        if sp is None:
+        seg = getattr(sfield, '_segments', None) if sparse else None
+        if seg is not None and out.device.type == 'cuda':
+            # a dipole / wire made by get_source_field and not modified since: assembled on the
+            # device from its few points (csrc/adjoint.h), nothing field-sized crosses PCIe
+            fields.source_field_device(sfield.grid, seg[0], sfield._frequency, seg[1], out=out)
+        elif sp is None:
             out.copy_(torch.from_numpy(np.ascontiguousarray(sfield.field)), non_blocking=False)
         else:
             out.zero_()

@@ -1394,3 +1394,34 @@ def test_adjoint_gradient_vs_finite_differences():
         fd = (phi(rp)[0] - m0) / d
         nrmsd = 200 * abs(g0[cell] - fd) / (abs(g0[cell]) + abs(fd))
         assert nrmsd < 1.5, (cell, fd, g0[cell])
+
+
+@pytest.mark.parametrize('freq', [1.3, -2.0])
+def test_source_field_on_the_device_vs_host(freq):
+    """the source vector of dipoles, finite dipoles and wires assembled by
+    emg3d_dev_source_field (one thread per segment, walking from grid plane to grid plane) against
+    the host get_source_field, which is pinned to the reference's fields (tests/test_host_api.py):
+    point-like dipoles in all orientations, dipoles that end on nodes / run along grid lines and
+    planes, a closed loop, a long wire through many cells; frequency and Laplace domain."""
+    rng = np.random.default_rng(4)
+    hx, hy, hz = widths(6, 3, 40., 1.3), widths(4, 3, 50., 1.25), widths(4, 2, 30., 1.4)
+    grid = emg3d.TensorMesh([hx, hy, hz], (-hx.sum() / 2, -hy.sum() / 2, -hz[:5].sum()))
+    nx_, ny_, nz_ = grid.nodes_x, grid.nodes_y, grid.nodes_z
+    sources = [(0., 0., -20., 0., 0.), (13., -7., 5., 37., -21.), (-50., 20., -30., 90., 0.), (5., 5., 5., 0., 90.),
+               (-20., 25., -3., -3., 7., 7.),                                     # finite, along x
+               (nx_[3], nx_[7], ny_[2], ny_[2], nz_[4], nz_[4]),                 # on a grid line, node to node
+               (nx_[2], nx_[9], ny_[1], ny_[6], nz_[2], nz_[5]),                 # node to node, diagonal
+               (nx_[4], nx_[4], ny_[2] + 3., ny_[5] - 2., nz_[3], nz_[3]),       # inside a grid plane
+               np.array([[-60., -40., -30.], [55., -35., -20.], [60., 45., 10.], [-50., 50., 0.], [-60., -40., -30.]]),
+               np.cumsum(rng.uniform(-25., 40., (30, 3)), axis=0) * [1, 0.3, 0.1] + [-200., -60., -40.]]
+    for src in sources:
+        for strength in (1.0, 2.5 - 0.5j if freq > 0 else -1.5):
+            host = emg3d.get_source_field(grid, src, freq, strength=strength)
+            dev = emg3d.fields.source_field_device(grid, host._segments[0], freq, strength).cpu().numpy()
+            assert relerr(dev, host.field) < 1e-13, (src, strength)
+    # the path that uses it: parallel.solve's sparse upload goes through the device assembly
+    model = emg3d.Model(grid, property_x=1.5)
+    sf = emg3d.get_source_field(grid, sources[-2], freq)
+    hier = solver.Hierarchy(emg3d.models.VolumeModel(model, sf))
+    hier.put_source(sf, hier.top.s, sparse=True)
+    assert relerr(hier.top.s.cpu().numpy(), sf.field) < 1e-13
