@@ -780,9 +780,13 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
         *V.p4(k, lid) = keep * rhs[4];
     }
     __syncthreads();
-    if (threadIdx.x >= 128) return;      // helper waves of the rhs phase are done
-    const int half = threadIdx.x >> 6;
-    const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
+    // chain waves: waves 0 / 1 walk the top / bottom halves of the workgroup's first 16 lines; with
+    // 32 lines per workgroup waves 2 / 3 do the same for lines 16..31, otherwise they only helped
+    // with the right-hand sides and are done
+    const int wave = threadIdx.x >> 6;
+    if (wave >= 2 && lpw < 32) return;
+    const int half = wave & 1;
+    const int qline = line0 + (wave >> 1) * 16 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
     if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
     else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
@@ -1227,7 +1231,8 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "point_prefetch")) { g_point_prefetch = value; return 0; }
     if (!std::strcmp(name, "line_occ2")) { g_line_occ2 = value; return 0; }
     if (!std::strcmp(name, "line_lpw")) {
-        if (value != 0 && value != 4 && value != 8 && value != 16) return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8 or 16");
+        if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32)
+            return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8, 16 or 32");
         g_line_lpw = value;
         return 0;
     }
