@@ -85,11 +85,12 @@ SIGNATURES = {
     'emg3d_dev_copy': (_ci, [_vp, _vp, _sz, _vp]),
     'emg3d_dev_gradient_accumulate': (_ci, [_ci] * 4 + [_vp] * 6 + [ctypes.c_double] * 2 + [_vp] * 5),
     'emg3d_dev_source_field': (_ci, [_ci] * 4 + [_vp] * 7 + [_ci] + [ctypes.c_double] * 2 + [_vp] * 4),
+    'emg3d_dev_volume_model': (_ci, [_ci] * 4 + [_vp] * 5 + [_ci] + [_vp] * 3 + [ctypes.c_double] * 4 + [_vp] * 5),
     'emg3d_dev_magnetic_field': (_ci, [_ci] * 4 + [_vp] * 7 + [ctypes.c_double] * 2 + [_vp] * 4),
     'emg3d_dev_spline_filter': (_ci, [_vp] + [_ci] * 4 + [_vp]),
     'emg3d_dev_spline_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _ci, _vp, _vp]),
     'emg3d_dev_linear_eval': (_ci, [_vp] + [_ci] * 4 + [_vp, _vp, _ci, _vp, _vp]),
-    'emg3d_dev_volume_average': (_ci, [_vp] + [_ci] * 3 + [_vp] * 10 + [_ci] * 3 + [_vp, _vp]),
+    'emg3d_dev_volume_average': (_ci, [_vp] + [_ci] * 3 + [_vp] * 10 + [_ci] * 3 + [_vp, _ci, _vp]),
 }
 
 LEVEL_ETA_IMAG = 1      # emg3d_level.flags (include/emg3d_amd.h)

@@ -210,3 +210,77 @@ int emg3d_dev_source_field(int nx, int ny, int nz, int is_complex, const double 
 }
 
 }  // extern "C"
+
+// ---- before a solve: the volume-integrated model on the device. models.VolumeModel
+// (emg3d/models.py:654-691): eta = -s mu0 V (sigma [+ s eps0 eps_r]), zeta = V / mu_r with
+// V = hx hy hz, evaluated in the reference's order of operations, from the PROPERTY arrays and the
+// model's mapping (emg3d/maps.py:120-330: conductivity = backward(property)).
+namespace {
+
+__device__ __forceinline__ double vm_conductivity(double p, int mapping)
+{
+    switch (mapping) {
+    case 1: return 1.0 / p;                 // Resistivity
+    case 2: return pow(10.0, p);            // LgConductivity
+    case 3: return pow(10.0, -p);           // LgResistivity
+    case 4: return exp(p);                  // LnConductivity
+    case 5: return exp(-p);                 // LnResistivity
+    default: return p;                      // Conductivity
+    }
+}
+__device__ __forceinline__ cplx vm_eta(cplx nsmu0, double vol, double sigma, bool has_eps, cplx seps)
+{
+    const cplx base = nsmu0 * vol;                               // (-s mu0) * V
+    if (!has_eps) return base * sigma;
+    return base * (cplx(sigma, 0.0) + seps);                     // (-s mu0 V) * (sigma + s eps0 eps_r)
+}
+__device__ __forceinline__ double vm_eta(double nsmu0, double vol, double sigma, bool has_eps, double seps)
+{
+    return has_eps ? (nsmu0 * vol) * (sigma + seps) : (nsmu0 * vol) * sigma;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_volume_model(int nx, int ny, int nz, const double *px, const double *py,
+                                                      const double *pz, const double *eps_r, const double *mu_r,
+                                                      int mapping, const double *hx, const double *hy, const double *hz,
+                                                      T nsmu0, T seps0, T *eta_x, T *eta_y, T *eta_z, double *zeta)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y * blockDim.y + threadIdx.y, iz = blockIdx.z;
+    if (ix >= nx || iy >= ny) return;
+    const size_t c = (size_t)ix + (size_t)nx * (iy + (size_t)ny * iz);
+    const double vol = (hx[ix] * hy[iy]) * hz[iz];
+    const bool has_eps = eps_r != nullptr;
+    const T seps = has_eps ? seps0 * eps_r[c] : emg::zero<T>();
+    eta_x[c] = vm_eta(nsmu0, vol, vm_conductivity(px[c], mapping), has_eps, seps);
+    if (py) eta_y[c] = vm_eta(nsmu0, vol, vm_conductivity(py[c], mapping), has_eps, seps);
+    if (pz) eta_z[c] = vm_eta(nsmu0, vol, vm_conductivity(pz[c], mapping), has_eps, seps);
+    zeta[c] = mu_r ? vol / mu_r[c] : vol;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emg3d_dev_volume_model(int nx, int ny, int nz, int is_complex, const double *property_x, const double *property_y,
+                           const double *property_z, const double *epsilon_r, const double *mu_r, int mapping,
+                           const double *hx, const double *hy, const double *hz, double smu0_re, double smu0_im,
+                           double seps0_re, double seps0_im, void *eta_x, void *eta_y, void *eta_z, double *zeta,
+                           void *stream)
+{
+    if (!property_x || !hx || !hy || !hz || !eta_x || !zeta || (property_y && !eta_y) || (property_z && !eta_z) ||
+        mapping < 0 || mapping > 5)
+        return fail(EMG3D_ERR_BADARG, "volume_model: bad argument");
+    const dim3 block(64, 4, 1), grid(cdiv(nx, 64), cdiv(ny, 4), nz);
+    if (is_complex)
+        hipLaunchKernelGGL(k_volume_model<cplx>, grid, block, 0, (hipStream_t)stream, nx, ny, nz, property_x, property_y,
+                           property_z, epsilon_r, mu_r, mapping, hx, hy, hz, cplx(-smu0_re, -smu0_im),
+                           cplx(seps0_re, seps0_im), (cplx *)eta_x, (cplx *)eta_y, (cplx *)eta_z, zeta);
+    else
+        hipLaunchKernelGGL(k_volume_model<double>, grid, block, 0, (hipStream_t)stream, nx, ny, nz, property_x, property_y,
+                           property_z, epsilon_r, mu_r, mapping, hx, hy, hz, -smu0_re, seps0_re, (double *)eta_x,
+                           (double *)eta_y, (double *)eta_z, zeta);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_volume_average(const double *v, int nx,
                                                         const int32_t *sy, const int32_t *sz, const double *wx,
                                                         const double *wy, const double *wz, const int32_t *inx,
                                                         const int32_t *iny, const int32_t *inz, const double *vol,
-                                                        int mx, int my, int mz, double *out)
+                                                        int mx, int my, int mz, double *out, int logscale)
 {
     const int ox = blockIdx.x * blockDim.x + threadIdx.x;
     const int oy = blockIdx.y * blockDim.y + threadIdx.y;
@@ -182,10 +182,11 @@ __global__ __launch_bounds__(256) void k_volume_average(const double *v, int nx,
         for (int b = sy[oy]; b < sy[oy + 1]; ++b) {
             const double w_zy = wz[a] * wy[b];
             const double *row = v + (size_t)nx * (iny[b] + (size_t)ny * inz[a]);
-            for (int c = sx[ox]; c < sx[ox + 1]; ++c) acc += w_zy * wx[c] * row[inx[c]];
+            // logscale: the average of log10(value), returned as 10 ** average (maps.py:346-358)
+            for (int c = sx[ox]; c < sx[ox + 1]; ++c) acc += w_zy * wx[c] * (logscale ? log10(row[inx[c]]) : row[inx[c]]);
         }
     const size_t o = (size_t)ox + (size_t)mx * (oy + (size_t)my * oz);
-    out[o] = acc / vol[o];
+    out[o] = logscale ? pow(10.0, acc / vol[o]) : acc / vol[o];
 }
 
 }  // namespace
@@ -195,14 +196,14 @@ extern "C" {
 int emg3d_dev_volume_average(const double *values, int nx, int ny, int nz, const int32_t *segx, const int32_t *segy,
                              const int32_t *segz, const double *wx, const double *wy, const double *wz,
                              const int32_t *inx, const int32_t *iny, const int32_t *inz, const double *new_vol,
-                             int mx, int my, int mz, double *out, void *stream)
+                             int mx, int my, int mz, double *out, int log10_scale, void *stream)
 {
     if (!values || !segx || !segy || !segz || !wx || !wy || !wz || !inx || !iny || !inz || !new_vol || !out ||
         nx < 1 || ny < 1 || nz < 1 || mx < 1 || my < 1 || mz < 1)
         return fail(EMG3D_ERR_BADARG, "volume_average: bad argument");
     const dim3 block(64, 4, 1), grid((mx + 63) / 64, (my + 3) / 4, mz);
     hipLaunchKernelGGL(k_volume_average, grid, block, 0, (hipStream_t)stream, values, nx, ny, segx, segy, segz, wx, wy,
-                       wz, inx, iny, inz, new_vol, mx, my, mz, out);
+                       wz, inx, iny, inz, new_vol, mx, my, mz, out, log10_scale);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -26,6 +26,11 @@ _MAPS = {
 }
 
 
+# codes of emg3d_dev_volume_model (include/emg3d_amd.h)
+_MAP_CODES = {'Conductivity': 0, 'Resistivity': 1, 'LgConductivity': 2, 'LgResistivity': 3,
+              'LnConductivity': 4, 'LnResistivity': 5}
+
+
 class Model:
     """Resistivity/conductivity model on a tensor mesh (subset of emg3d.models.Model,
     reference emg3d/models.py:33-620, needed to feed the solver)."""
@@ -135,16 +140,12 @@ class _VolumeAverage:
         from emg3d_amd import _lib
         from emg3d_amd._device import _ptr, _stream
         v = torch.from_numpy(np.ascontiguousarray(values.ravel('F'))).to(self.dev)
-        if log:
-            v = torch.log10(v)
         out = torch.empty(int(np.prod(self.shape_out)), dtype=torch.float64, device=self.dev)
         (sx, wx, ix), (sy, wy, iy), (sz, wz, iz) = self.tabs
         _lib.check(_lib.lib().emg3d_dev_volume_average(
             _ptr(v), *self.shape_in, _ptr(sx), _ptr(sy), _ptr(sz), _ptr(wx), _ptr(wy), _ptr(wz),
-            _ptr(ix), _ptr(iy), _ptr(iz), _ptr(self.vol), *self.shape_out, _ptr(out), _stream()),
+            _ptr(ix), _ptr(iy), _ptr(iz), _ptr(self.vol), *self.shape_out, _ptr(out), int(bool(log)), _stream()),
             'emg3d_dev_volume_average')
-        if log:
-            out = torch.pow(10.0, out)
         return out.cpu().numpy().reshape(self.shape_out, order='F')
 
 
@@ -192,50 +193,46 @@ class VolumeModel:
 
     def device_arrays(self, device):
         """(eta_x, eta_y, eta_z, zeta) as flat F-ordered torch tensors on `device`, with the
-        reference's aliasing (eta_y / eta_z are eta_x's tensor unless the model has them)."""
+        reference's aliasing (eta_y / eta_z are eta_x's tensor unless the model has them), formed
+        by ``emg3d_dev_volume_model`` from the property arrays: those that arrived through a
+        device broadcast (``parallel.broadcast_model``) are already in HBM, the others go up as
+        they are (17 MB per array at 128^3)."""
         import torch
+        from emg3d_amd import _lib
+        from emg3d_amd._device import _ptr, _stream
         model = self._model
         cplx = np.iscomplexobj(self._smu0)
         dtype = torch.complex128 if cplx else torch.float64
+        resident = {k: v for k, v in getattr(model, '_device_props', {}).items() if v.device == torch.device(device)}
 
-        def up(a):
-            if isinstance(a, torch.Tensor):
-                return a
-            a = np.broadcast_to(np.asarray(a, dtype=np.float64), model.shape)
-            a = a.ravel('F')
+        def prop(name):
+            if name in resident:
+                return resident[name]
+            a = getattr(model, name)
+            if a is None:
+                return None
+            a = np.broadcast_to(np.asarray(a, dtype=np.float64), model.shape).ravel('F')
             if not a.flags.writeable or not a.flags.c_contiguous:
                 a = np.array(a)                         # torch wants a writable, dense buffer
             return torch.from_numpy(a).to(device)
-        hx, hy, hz = (torch.from_numpy(np.ascontiguousarray(h, dtype=np.float64)).to(device)
-                      for h in self.grid.h)
-        # (hx[:, None] * hy) in numpy's cell_volumes order: x fastest
-        vol = ((hx[None, None, :] * hy[None, :, None]) * hz[:, None, None]).reshape(-1)
-        smu0 = complex(self._smu0) if cplx else float(self._smu0)
-        base = (-smu0) * vol.to(dtype)
-        eps = None
-        if model.epsilon_r is not None:
-            sval = complex(self._sval) if cplx else float(self._sval)
-            eps = (sval * EPSILON_0) * up(getattr(model, '_device_props', {}).get('epsilon_r', model.epsilon_r)).to(dtype)
-        # properties that arrived through a device broadcast (parallel.broadcast_model) are
-        # already in HBM: map them to conductivities there
-        resident = {k: v for k, v in getattr(model, '_device_props', {}).items() if v.device == torch.device(device)}
-        dev_map = {'Resistivity': lambda p: 1.0 / p, 'Conductivity': lambda p: p,
-                   'LgResistivity': lambda p: 10.0 ** (-p), 'LgConductivity': lambda p: 10.0 ** p,
-                   'LnResistivity': lambda p: torch.exp(-p), 'LnConductivity': torch.exp}[model.mapping]
-        conds = [dev_map(resident[n]) if n in resident else c
-                 for n, c in zip(('property_x', 'property_y', 'property_z'), self._conductivities())]
-        etas = []
-        for cond in conds:
-            if cond is None:
-                etas.append(None)
-            elif eps is None:
-                etas.append(base * up(cond))
-            else:
-                etas.append(base * (up(cond) + eps))
-        zeta = vol.clone() if model.mu_r is None else vol / up(resident.get('mu_r', model.mu_r))
-        ex = etas[0]
-        ey = etas[1] if self.case in ('HTI', 'triaxial') else ex
-        ez = etas[2] if self.case in ('VTI', 'triaxial') else ex
+        px, eps, mu = prop('property_x'), prop('epsilon_r'), prop('mu_r')
+        py = prop('property_y') if self.case in ('HTI', 'triaxial') else None
+        pz = prop('property_z') if self.case in ('VTI', 'triaxial') else None
+        h = torch.from_numpy(np.concatenate([np.asarray(w, dtype=np.float64) for w in self.grid.h])).to(device)
+        nx, ny, nz = self.grid.shape_cells
+        n = self.grid.n_cells
+        ex = torch.empty(n, dtype=dtype, device=device)
+        ey = torch.empty(n, dtype=dtype, device=device) if py is not None else ex
+        ez = torch.empty(n, dtype=dtype, device=device) if pz is not None else ex
+        zeta = torch.empty(n, dtype=torch.float64, device=device)
+        smu0 = complex(self._smu0)
+        seps0 = complex(self._sval) * EPSILON_0
+        opt = lambda t: _ptr(t) if t is not None else None                    # noqa: E731
+        _lib.check(_lib.lib().emg3d_dev_volume_model(
+            nx, ny, nz, int(cplx), _ptr(px), opt(py), opt(pz), opt(eps), opt(mu), _MAP_CODES[model.mapping],
+            _ptr(h), _ptr(h, nx), _ptr(h, nx + ny), smu0.real, smu0.imag, seps0.real, seps0.imag,
+            _ptr(ex), opt(ey if py is not None else None), opt(ez if pz is not None else None), _ptr(zeta), _stream()),
+            'emg3d_dev_volume_model')
         return ex, ey, ez, zeta
 
     @property

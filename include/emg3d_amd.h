@@ -294,12 +294,13 @@ int emg3d_dev_gradient_accumulate(int nx, int ny, int nz, int is_complex, const 
  * (emg3d/models.py:322-366). values (nx,ny,nz) -> out (mx,my,mz), doubles, x fastest. Per axis
  * the host supplies maps._volume_average_weights (maps.py:619-664) grouped by output cell:
  * seg* (m+1 offsets), w* (segment lengths), in* (input cell of each segment); new_vol = output
- * cell volumes. Same additions in the same order as the reference: bit-identical. */
+ * cell volumes. Same additions in the same order as the reference: bit-identical. log10_scale = 1:
+ * the values are averaged on a log10 scale (maps.interpolate(log=True), emg3d/maps.py:346-358). */
 int emg3d_dev_volume_average(const double *values, int nx, int ny, int nz, const int32_t *segx,
                              const int32_t *segy, const int32_t *segz, const double *wx,
                              const double *wy, const double *wz, const int32_t *inx,
                              const int32_t *iny, const int32_t *inz, const double *new_vol, int mx,
-                             int my, int mz, double *out, void *stream);
+                             int my, int mz, double *out, int log10_scale, void *stream);
 
 /* fields.get_source_field -> _dipole_vector (emg3d/fields.py:386-519, 792-938): the source vector
  * of a dipole / wire through `npoints` points (device, npoints x 3, metres), times the complex
@@ -309,6 +310,20 @@ int emg3d_dev_source_field(int nx, int ny, int nz, int is_complex, const double 
                            const double *nodes_z, const double *hx, const double *hy, const double *hz,
                            const double *points, int npoints, double scale_re, double scale_im, void *sx,
                            void *sy, void *sz, void *stream);
+
+/* models.VolumeModel (emg3d/models.py:654-691) on the device: eta_{x,y,z} = -s mu0 V (sigma [+ s eps0
+ * eps_r]) and zeta = V / mu_r from the model's PROPERTY arrays (nx,ny,nz doubles; property_y /
+ * property_z / epsilon_r / mu_r may be NULL) and its mapping (0 Conductivity, 1 Resistivity,
+ * 2 LgConductivity, 3 LgResistivity, 4 LnConductivity, 5 LnResistivity; emg3d/maps.py:120-330);
+ * hx/hy/hz: cell widths (device); s mu0 and s eps0 as (re, im) (real fields: re only). eta_y / eta_z
+ * are written only when property_y / property_z are given -- the caller aliases them to eta_x
+ * otherwise, as the reference does (emg3d/models.py:693-712). */
+int emg3d_dev_volume_model(int nx, int ny, int nz, int is_complex, const double *property_x,
+                           const double *property_y, const double *property_z, const double *epsilon_r,
+                           const double *mu_r, int mapping, const double *hx, const double *hy,
+                           const double *hz, double smu0_re, double smu0_im, double seps0_re,
+                           double seps0_im, void *eta_x, void *eta_y, void *eta_z, double *zeta,
+                           void *stream);
 
 #ifdef __cplusplus
 }
