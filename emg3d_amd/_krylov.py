@@ -26,9 +26,9 @@ class Vectors:
 
     NSLOTS = 32
 
-    def __init__(self, top):
+    def __init__(self, top, n=None):
         self.top = top
-        self.n = top.e.numel()
+        self.n = top.e.numel() if n is None else int(n)       # (n: one right-hand side of a batch)
         self.is_complex = top.is_complex
         self.table = torch.zeros(2 * self.NSLOTS, dtype=torch.float64, device=top.device)
         self.ws = torch.empty(_lib.lib().emg3d_krylov_ws_len(), dtype=torch.float64, device=top.device)
@@ -202,3 +202,93 @@ def cgs(hier, b, x, var, run_cycles, callback):
         rr, rho = V.read('rr', 'rho')
         callback(float(np.sqrt(abs(rr))))          # = |b - A x|, what the reference's callback evaluates
     return var.ssl_maxit
+
+
+def bicgstab_batch(hier, var_cycle, vars_, live, precondition, callback):
+    """BiCGSTAB for the ``top.batch`` right-hand sides of a batched hierarchy. Every source runs
+    the iteration of ``bicgstab`` above on its own rows with its own scalar table (its own
+    breakdown tests and stopping rule); what the sources share are the two preconditioner
+    applications (``precondition(SRC, OUT, live)``: multigrid cycles on all right-hand sides at
+    once; it clears ``live[b]`` for sources whose preconditioner failed) and the two operator
+    applications per iteration. ``live``: which sources iterate (updated in place).
+    Returns (X, codes): the solutions stacked like the fields, and the SciPy status per source."""
+    top = hier.top
+    nb, n = top.batch, top.grid.n_edges
+    rows = lambda t, b: t[b * n:(b + 1) * n]           # noqa: E731
+    W = [Vectors(top, n) for _ in range(nb)]
+    full = Vectors(top)
+    B, X = full.new(), full.new()
+    full.copy(B, top.s)
+    _lib.check(_lib.lib().emg3d_dev_zero(_ptr(X), X.numel() * X.element_size(), _stream()), 'emg3d_dev_zero')
+    R, V, T, P, PHAT, SHAT, RT = (full.new() for _ in range(7))
+    eps = np.finfo(np.float64).eps
+    rhotol = omegatol = eps ** 2
+    maxit = var_cycle.ssl_maxit
+    code = [maxit] * nb
+
+    top.apply_A(X, R)
+    atol, rr, rho, omega = [0.0] * nb, [0.0] * nb, [0.0] * nb, [1.0] * nb
+    for b in range(nb):
+        if not live[b]:
+            continue
+        W[b].step(rows(R, b), [(rows(B, b), 1.0), (rows(R, b), -1.0)], dots=[('bb', rows(B, b), rows(B, b))])
+        W[b].copy(rows(RT, b), rows(R, b))
+        W[b].step(None, dots=[('rr', rows(R, b), rows(R, b)), ('rho', rows(RT, b), rows(R, b))])
+    for b in range(nb):
+        if live[b]:
+            bb, rr[b], rho[b] = W[b].read('bb', 'rr', 'rho')
+            atol[b] = max(1e-30, vars_[b].tol * np.sqrt(abs(bb)))
+    for iteration in range(maxit):
+        for b in range(nb):                              # ---- up to the first preconditioner call
+            if not live[b]:
+                continue
+            r, p, v = rows(R, b), rows(P, b), rows(V, b)
+            if np.sqrt(abs(rr[b])) < atol[b]:
+                code[b], live[b] = 0, False
+            elif abs(rho[b]) < rhotol:
+                code[b], live[b] = -10, False
+            elif iteration > 0 and abs(omega[b]) < omegatol:
+                code[b], live[b] = -11, False
+            elif iteration > 0:
+                W[b].step(p, [(r, 1.0), (p, 'beta'), (v, 'nbo')])
+            else:
+                W[b].copy(p, r)
+        if not any(live):
+            break
+        precondition(P, PHAT, live)
+        top.apply_A(PHAT, V)
+        for b in range(nb):                              # ---- between the two calls
+            if live[b]:
+                r, v = rows(R, b), rows(V, b)
+                W[b].step(None, dots=[('rv', rows(RT, b), v)],
+                          prog=[(DIV, 'alpha', 'rho', 'rv'), (NEG, 'nalpha', 'alpha', None)])
+                W[b].step(r, [(r, 1.0), (v, 'nalpha')], dots=[('ss', r, r)])
+        for b in range(nb):
+            if not live[b]:
+                continue
+            rv, ss = W[b].read('rv', 'ss')
+            if rv == 0:
+                code[b], live[b] = -11, False
+            elif np.sqrt(abs(ss)) < atol[b]:
+                W[b].step(rows(X, b), [(rows(X, b), 1.0), (rows(PHAT, b), 'alpha')])
+                code[b], live[b] = 0, False
+        if not any(live):
+            break
+        precondition(R, SHAT, live)
+        top.apply_A(SHAT, T)
+        for b in range(nb):                              # ---- after the second call
+            if live[b]:
+                r, t, x = rows(R, b), rows(T, b), rows(X, b)
+                W[b].step(None, dots=[('ts', t, r), ('tt', t, t)],
+                          prog=[(DIV, 'omega', 'ts', 'tt'), (NEG, 'nomega', 'omega', None)])
+                W[b].step(x, [(x, 1.0), (rows(PHAT, b), 'alpha'), (rows(SHAT, b), 'omega')])
+                W[b].step(r, [(r, 1.0), (t, 'nomega')], dots=[('rr', r, r), ('rho_next', rows(RT, b), r)],
+                          prog=[(DIV, 'q1', 'rho_next', 'rho'), (DIV, 'q2', 'alpha', 'omega'), (MUL, 'beta', 'q1', 'q2'),
+                                (MUL, 'bo', 'beta', 'omega'), (NEG, 'nbo', 'bo', None), (COPY, 'rho', 'rho_next', None)])
+        sumsq = top.residual_sumsq(X, B)                 # all right-hand sides in one launch
+        l2 = np.sqrt(sumsq[:nb].cpu().numpy())
+        for b in range(nb):
+            if live[b]:
+                rr[b], rho[b], omega[b] = W[b].read('rr', 'rho', 'omega')
+                callback(b, float(l2[b]))
+    return X, code

@@ -343,129 +343,45 @@ def _multigrid_batch(lv, svar, vars_, active=None):
 
 
 def _bicgstab_batch(hier, svar, vars_, nonzero):
-    """``_bicgstab_device`` for the right-hand sides of a batch. The vector algebra of every
-    source is the single-source code (same 1-D tensor operations on that source's rows, its own
-    scalars, breakdown checks and stopping rule); what is shared are the two preconditioner
-    applications (multigrid cycles on all sources at once, ``_multigrid_batch``) and the two
-    operator applications per iteration. Identical to separate solves as long as the sources
-    run the same number of cycles inside every preconditioner call (the rule: ``maxit`` cycles;
-    a source may stop earlier on convergence) -- otherwise the sc/lr cycling of the shared
+    """BiCGSTAB with multigrid as preconditioner for the right-hand sides of a batch
+    (``_krylov.bicgstab_batch``: every source iterates with its own scalars; the preconditioner
+    and operator applications are shared launches). Identical to separate solves as long as the
+    sources run the same number of cycles inside every preconditioner call (the rule: ``maxit``
+    cycles; a source may stop earlier on convergence) -- otherwise the sc/lr cycling of the shared
     structure and of a separate solve drift apart, and the fields agree to the tolerance only.
     Returns the solutions (device tensors; None for zero sources / failed solves)."""
+    from emg3d_amd import _krylov
     top = hier.top
     nb, n = top.batch, top.grid.n_edges
-    rows = lambda t, b: t[b * n:(b + 1) * n]           # noqa: E731
-    B = top.s.clone()
-    X = torch.zeros_like(B)
-    R, V, T, P, PHAT, SHAT = (torch.empty_like(B) for _ in range(6))
-
-    def norm(t):
-        return float(torch.linalg.vector_norm(t).item())
-
-    def dot(u, w):
-        return complex(torch.vdot(u, w).item()) if top.is_complex else float(torch.dot(u, w).item())
-
-    live = list(nonzero)                   # still iterating
+    live = list(nonzero)
     failed = [False] * nb
+    mover = _krylov.Vectors(top)
 
-    def psolve(VEC, OUT):
-        top.s.copy_(VEC)
+    def precondition(SRC, OUT, live_now):
+        mover.copy(top.s, SRC)
         top.zero_field()
-        done, bad = _multigrid_batch(top, svar, vars_, live)
+        done, bad = _multigrid_batch(top, svar, vars_, live_now)
         for b in range(nb):
-            if live[b]:
-                rows(OUT, b).copy_(done[b])
+            if live_now[b]:
+                mover.copy(OUT[b * n:(b + 1) * n], done[b])
                 if bad[b]:
                     failed[b] = True
-                    live[b] = False
+                    live_now[b] = False
 
-    def apply_A(XIN, OUT):
-        top.apply_A(XIN, OUT)
-
-    def true_residual_norms():
-        top.s.copy_(B)
-        top.e.copy_(X)
-        return top.residual(store=False, norm=True)
-
-    eps = np.finfo(np.float64).eps
-    rhotol = omegatol = eps ** 2
-    atol = [max(1e-30, v.tol * norm(rows(B, b))) if live[b] else 0.0 for b, v in enumerate(vars_)]
-    apply_A(X, R)
-    torch.sub(B, R, out=R)
-    RT = R.clone()
-    rho_prev = [1.0] * nb
-    omega = [1.0] * nb
-    alpha = [1.0] * nb
-    rho = [1.0] * nb
-    code = [v.ssl_maxit for v in vars_]
-    for iteration in range(svar.ssl_maxit):
-        for b in range(nb):                              # ---- up to the first preconditioner call
-            if not live[b]:
-                continue
-            r, p, v = rows(R, b), rows(P, b), rows(V, b)
-            if norm(r) < atol[b]:
-                code[b], live[b] = 0, False
-                continue
-            rho[b] = dot(rows(RT, b), r)
-            if abs(rho[b]) < rhotol:
-                code[b], live[b] = -10, False
-                continue
-            if iteration > 0:
-                if abs(omega[b]) < omegatol:
-                    code[b], live[b] = -11, False
-                    continue
-                beta = (rho[b] / rho_prev[b]) * (alpha[b] / omega[b])
-                p.sub_(v, alpha=omega[b]).mul_(beta).add_(r)
-            else:
-                p.copy_(r)
-        if not any(live):
-            break
-        psolve(P, PHAT)
-        apply_A(PHAT, V)
-        for b in range(nb):                              # ---- between the two calls
-            if not live[b]:
-                continue
-            r = rows(R, b)
-            rv = dot(rows(RT, b), rows(V, b))
-            if rv == 0:
-                code[b], live[b] = -11, False
-                continue
-            alpha[b] = rho[b] / rv
-            r.sub_(rows(V, b), alpha=alpha[b])
-            if norm(r) < atol[b]:
-                rows(X, b).add_(rows(PHAT, b), alpha=alpha[b])
-                code[b], live[b] = 0, False
-        if not any(live):
-            break
-        psolve(R, SHAT)
-        apply_A(SHAT, T)
-        for b in range(nb):                              # ---- after the second call
-            if not live[b]:
-                continue
-            r, t = rows(R, b), rows(T, b)
-            omega[b] = dot(t, r) / dot(t, t)
-            rows(X, b).add_(rows(PHAT, b), alpha=alpha[b]).add_(rows(SHAT, b), alpha=omega[b])
-            r.sub_(t, alpha=omega[b])
-            rho_prev[b] = rho[b]
-        l2 = true_residual_norms()
-        for b, v in enumerate(vars_):
-            if live[b]:
-                _krylov_callback(v, float(l2[b]))
+    X, code = _krylov.bicgstab_batch(hier, svar, vars_, live, precondition,
+                                     lambda b, l2: _krylov_callback(vars_[b], l2))
     done = [None] * nb
     for b, v in enumerate(vars_):
         if not nonzero[b]:
             continue
-        i = -1 if failed[b] else code[b]
         if failed[b]:
             v.exit_message += " (returned field is zero)"
-        elif i < 0 and v.exit_message == '':
-            v.exit_message = f"Error in {v.sslsolver} ({i})"
-        elif i > 0:
-            v.exit_message = "MAX. ITERATION REACHED, NOT CONVERGED"
-        elif i == 0:
-            v.exit_message = "CONVERGED"
-        if not failed[b]:
-            done[b] = rows(X, b)
+            continue
+        if code[b] < 0:
+            v.exit_message = v.exit_message or f"Error in {v.sslsolver} ({code[b]})"
+        else:
+            v.exit_message = "CONVERGED" if code[b] == 0 else "MAX. ITERATION REACHED, NOT CONVERGED"
+        done[b] = X[b * n:(b + 1) * n]
     return done
 
 
