@@ -3,6 +3,7 @@
     python tools/microbench.py point --n 256 --slabs 0,4,8,16,32
     python tools/microbench.py lines --n 128
     python tools/microbench.py residual --n 256
+    python tools/microbench.py around --n 256      (Krylov steps, operator, gradient gather: SURVEY.md 8f)
 Values: complex standard normal fields (PEC zeroed), model from the config.
 Timing: torch.cuda events on the launch stream, warm-up 2, median of `reps`.
 """
@@ -71,7 +72,7 @@ def report(name, ms, ncells, nsweeps, case):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['point', 'lines', 'residual', 'all'])
+    ap.add_argument('what', choices=['point', 'lines', 'residual', 'around', 'all'])
     ap.add_argument('--n', type=int, default=256)
     ap.add_argument('--case', default='triaxial')
     ap.add_argument('--slabs', default='0,2,4,8,16,32')
@@ -112,6 +113,50 @@ def main():
         report("residual (store)", med, nc, 1, args.case)
         med, mn = timeit(lambda: lv.residual(store=False, norm=True))
         report("residual (norm only, incl. sync)", med, nc, 1, args.case)
+    if args.what in ('around', 'all'):
+        around(lv, grid)
+
+
+def around(lv, grid):
+    """Kernels either side of the cycle: bytes they must move / time."""
+    import ctypes
+    from emg3d_amd import _krylov
+    from emg3d_amd._device import _ptr, _stream
+    lib = _lib.lib()
+    n, nc = grid.n_edges, grid.n_cells
+
+    def line(name, ms, nbytes):
+        print(f"{name:52s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  ({100 * nbytes / ms / 1e6 / 8000:5.1f}% of 8 TB/s)",
+              flush=True)
+
+    V = _krylov.Vectors(lv)
+    a, b, c, d = (V.new() for _ in range(4))
+    for t in (a, b, c, d):
+        t.copy_(lv.e)
+    for nm in ('beta', 'nbo', 'alpha', 'omega'):
+        V.slot(nm)
+    V.table[:8] = 0.5
+    med, _ = timeit(lambda: V.step(a, [(b, 1.0), (a, 'beta'), (c, 'nbo')]))
+    line("krylov step  p = r + beta p - beta omega v", med, 4 * 16 * n)
+    med, _ = timeit(lambda: V.step(a, [(a, 1.0), (b, 'alpha')], dots=[('rr', a, a), ('rho', d, a)]))
+    line("krylov step  r -= alpha v ; r.r ; rt.r", med, 4 * 16 * n)
+    med, _ = timeit(lambda: V.step(None, dots=[('ts', a, b), ('tt', a, a)]))
+    line("krylov step  t.s ; t.t (no update)", med, 2 * 16 * n)
+    med, _ = timeit(lambda: lv.apply_A(a, b))
+    line("operator     y = A x", med, (2 * 48 + 56) * nc)          # field in, out, eta x3 (8 B) + zeta + 3 h
+    med, _ = timeit(lambda: lv.residual_sumsq(a, b))
+    line("true residual |b - A x|^2 (no store)", med, (2 * 48 + 56) * nc)
+    med, _ = timeit(lambda: V.copy(a, b))
+    line("copy", med, 2 * 16 * n)
+    # adjoint gradient gather
+    nx, ny, nz = grid.shape_cells
+    o1, o2 = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y
+    grad = torch.zeros(3 * nc, dtype=torch.float64, device='cuda')
+    vol = torch.from_numpy(np.ascontiguousarray(grid.cell_volumes)).cuda()
+    med, _ = timeit(lambda: _lib.check(lib.emg3d_dev_gradient_accumulate(
+        nx, ny, nz, 1, _ptr(a), _ptr(a, o1), _ptr(a, o2), _ptr(b), _ptr(b, o1), _ptr(b, o2), 0.0, 7.9e-6, _ptr(vol),
+        _ptr(grad), _ptr(grad, nc), _ptr(grad, 2 * nc), _stream()), 'grad'))
+    line("gradient gather  g += cells(re(b s mu0 e))", med, (2 * 48 + 8 + 2 * 24) * nc)
 
 
 if __name__ == '__main__':
