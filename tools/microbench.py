@@ -25,7 +25,7 @@ from bench import widths, BYTES_PER_CELL_SWEEP  # noqa: E402
 def make_level(n, case, stretch=1.03, shape=None, eta_real=False):
     shape = shape or (n, n, n)
     rng = np.random.default_rng(1)
-    h = [widths(m // 2, m // 4, 25., stretch) for m in shape]
+    h = [widths(m - 2 * (m // 4), m // 4, 25., stretch) for m in shape]
     grid = emg3d.TensorMesh(h, (0, 0, 0))
     vol = grid.cell_volumes.reshape(shape, order='F')
     smu0 = 2j * np.pi * 1.25663706127e-06
