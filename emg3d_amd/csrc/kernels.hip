@@ -83,6 +83,8 @@ int g_tile_fuse = 1;
 int g_line_lds = 1;
 // tiled point smoother: software prefetch of the next colour step's inputs (0 none, 1 source, 2 source + eta sums)
 int g_point_prefetch = 0;
+// residual kernel: planes a workgroup walks on large levels (1 = one plane per workgroup)
+int g_residual_zb = 8;
 // fused line kernel with the records in the global scratch (the largest levels): the instantiation
 // that is held to 256 registers, so that two workgroups share a CU and overlap their phases
 int g_line_occ2 = 0;
@@ -118,6 +120,21 @@ hipError_t allow_lds(const void *kernel, size_t bytes)
         ++nseen[dev];
     }
     return e;
+}
+
+// compute units of the current device
+int compute_units()
+{
+    constexpr int MAXDEV = 64;
+    static int cus[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
 }
 
 // ----------------------------------------------------------------------------- kernels --
@@ -797,20 +814,25 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
     else quad_backward<T, DIR, 1, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
-// Residual + per-block partial sums of |r|^2.
+// Residual + per-block partial sums of |r|^2. A workgroup walks `zb` consecutive planes: the plane
+// above the current one, fetched for the curl, is the next iteration's own plane and is still in
+// the CU's cache then -- with one plane per workgroup the three workgroups that need a plane run on
+// different XCDs at different times and each fetches it from HBM (PMC, 256^3: 399 B read per cell
+// against 144).
 template <class T>
-__global__ __launch_bounds__(256) void k_residual(emg::Level<T> L0, T *rx, T *ry, T *rz, double *partial, int nzp)
+__global__ __launch_bounds__(256) void k_residual(emg::Level<T> L0, T *rx, T *ry, T *rz, double *partial, int nzb, int zb)
 {
-    // grid.z = planes x right-hand sides; the residual buffers are stacked like the fields, and
+    // grid.z = plane blocks x right-hand sides; the residual buffers are stacked like the fields, and
     // source b owns the partial sums [b nblk, (b+1) nblk) (blockIdx.z runs over both)
-    const int b = blockIdx.z / nzp;
+    const int b = blockIdx.z / nzb;
     const emg::Level<T> L = emg::source_level(L0, b);
     if (rx) { rx += b * L0.bstride; ry += b * L0.bstride; rz += b * L0.bstride; }
     const int ix = blockIdx.x * blockDim.x + threadIdx.x;
     const int iy = blockIdx.y * blockDim.y + threadIdx.y;
-    const int iz = blockIdx.z - b * nzp;
+    const int z0 = (blockIdx.z - b * nzb) * zb, z1 = min(z0 + zb, L.nz + 1);
     double acc = 0.0;
-    if (ix <= L.nx && iy <= L.ny) acc = emg::residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
+    if (ix <= L.nx && iy <= L.ny)
+        for (int iz = z0; iz < z1; ++iz) acc += emg::residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
     if (partial) {
         // wave reduction (64 lanes), then across the 4 waves through LDS
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -1093,11 +1115,14 @@ int launch_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double 
 {
     emg::Level<T> L = to_level<T>(lv);
     const dim3 block = d3(emg::cell_block());
-    const dim3 grid = d3(emg::cell_grid(L.nx + 1, L.ny + 1, L.nz + 1));
+    dim3 grid = d3(emg::cell_grid(L.nx + 1, L.ny + 1, L.nz + 1));
+    // planes per workgroup: 8 where that still leaves every CU several workgroups, else 1
+    const int zb = (size_t)grid.x * grid.y * (grid.z / g_residual_zb) * L.batch >= 8u * (unsigned)compute_units() ? g_residual_zb : 1;
+    grid.z = cdiv((int)grid.z, zb);
     const size_t nblk = (size_t)grid.x * grid.y * grid.z;       // per right-hand side
     if (sumsq && (ws == nullptr || ws_len < nblk * L.batch)) return fail(EMG3D_ERR_SCRATCH, "residual: workspace too small");
     hipLaunchKernelGGL(k_residual<T>, dim3(grid.x, grid.y, grid.z * L.batch), block, 0, st, L, (T *)rx, (T *)ry, (T *)rz,
-                       sumsq ? ws : nullptr, (int)grid.z);
+                       sumsq ? ws : nullptr, (int)grid.z, zb);
     if (sumsq) hipLaunchKernelGGL(k_reduce_sum, dim3(L.batch), dim3(256), 0, st, ws, (int)nblk, sumsq);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1229,6 +1254,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "tile_fuse")) { g_tile_fuse = value; return 0; }
     if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
     if (!std::strcmp(name, "point_prefetch")) { g_point_prefetch = value; return 0; }
+    if (!std::strcmp(name, "residual_zb")) { g_residual_zb = value > 0 ? value : 1; return 0; }
     if (!std::strcmp(name, "line_occ2")) { g_line_occ2 = value; return 0; }
     if (!std::strcmp(name, "line_lpw")) {
         if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32)
@@ -1249,6 +1275,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "tile_fuse")) return g_tile_fuse;
     if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
     if (name && !std::strcmp(name, "point_prefetch")) return g_point_prefetch;
+    if (name && !std::strcmp(name, "residual_zb")) return g_residual_zb;
     if (name && !std::strcmp(name, "line_occ2")) return g_line_occ2;
     if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
     return -1;
