@@ -157,6 +157,23 @@ def around(lv, grid):
         nx, ny, nz, 1, _ptr(a), _ptr(a, o1), _ptr(a, o2), _ptr(b), _ptr(b, o1), _ptr(b, o2), 0.0, 7.9e-6, _ptr(vol),
         _ptr(grad), _ptr(grad, nc), _ptr(grad, 2 * nc), _stream()), 'grad'))
     line("gradient gather  g += cells(re(b s mu0 e))", med, (2 * 48 + 8 + 2 * 24) * nc)
+    # before a solve: source vector on the device, model re-gridding, eta / zeta
+    from emg3d_amd import fields, models
+    cx, cy, cz = (0.5 * (g[0] + g[-1]) for g in (grid.nodes_x, grid.nodes_y, grid.nodes_z))
+    pts = np.array([[cx - 50.3, cy + 3.1, cz - 7.7], [cx + 50.1, cy - 2.2, cz + 9.9]])
+    med, _ = timeit(lambda: fields.source_field_device(grid, pts, 1.0, out=a))
+    line("source vector of a 100 m dipole (incl. zero fill)", med, 16 * n)
+    model = emg3d.Model(grid, property_x=np.full(grid.shape_cells, 1.0), property_z=np.full(grid.shape_cells, 2.0),
+                        mapping='Resistivity')
+    sf = emg3d.Field(grid, frequency=1.0)
+    med, _ = timeit(lambda: models.VolumeModel(model, sf).device_arrays(torch.device('cuda')), reps=5, warm=1)
+    line("eta, zeta from the properties (incl. 2 x 134 MB upload)", med, (2 * 8 + 2 * 16 + 8) * nc)
+    h2 = [np.r_[g[0], 0.5 * (g[:-1:3] + g[1::3])[1:], g[-1]] for g in (grid.nodes_x, grid.nodes_y, grid.nodes_z)]
+    grid2 = emg3d.TensorMesh([np.diff(x) for x in h2], (h2[0][0], h2[1][0], h2[2][0]))
+    plan = models._VolumeAverage(grid, grid2)
+    vals = np.asfortranarray(10 ** np.random.default_rng(3).uniform(-1, 1, grid.shape_cells))
+    med, _ = timeit(lambda: plan(vals, True), reps=5, warm=1)
+    line(f"volume averaging {grid.shape_cells} -> {grid2.shape_cells}, log scale (host in / out)", med, 8 * (nc + grid2.n_cells))
 
 
 if __name__ == '__main__':
