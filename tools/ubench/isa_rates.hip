@@ -5,8 +5,9 @@
 #include <cstdio>
 
 #define N 256
-template <int MODE> __global__ void k(double *out, unsigned long long *cyc, double a_, double b_)
+template <int MODE> __global__ void k(double *out, unsigned long long *cyc, double a_, double b_, int active)
 {
+    if ((int)threadIdx.x >= active) return;      // partly filled wave: does the SIMD skip the empty quarter-passes?
     // per-lane operands: with wave-uniform (SGPR) operands a VOP3 instruction may need extra
     // moves (one constant-bus read per instruction on gfx9) and the count is off
     const double a = a_ + 1e-13 * threadIdx.x, b = b_ + 1e-13 * threadIdx.x;
@@ -57,14 +58,14 @@ template <int MODE> __global__ void k(double *out, unsigned long long *cyc, doub
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int MODE> void run(const char *name, int per_iter)
+template <int MODE> void run(const char *name, int per_iter, int active = 64)
 {
     double *out; unsigned long long *cyc, h[4];
     hipMalloc(&out, 4 * 64 * 8); hipMalloc(&cyc, 4 * 8);
-    hipLaunchKernelGGL(k<MODE>, dim3(4), dim3(64), 0, 0, out, cyc, 1.0000001, 1e-9);
-    hipLaunchKernelGGL(k<MODE>, dim3(4), dim3(64), 0, 0, out, cyc, 1.0000001, 1e-9);
+    hipLaunchKernelGGL(k<MODE>, dim3(4), dim3(64), 0, 0, out, cyc, 1.0000001, 1e-9, active);
+    hipLaunchKernelGGL(k<MODE>, dim3(4), dim3(64), 0, 0, out, cyc, 1.0000001, 1e-9, active);
     hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost);
-    printf("%-52s %7.2f clock64 ticks per instruction\n", name, (double)h[0] / (N * per_iter));
+    printf("%-52s %2d lanes %7.2f clock64 ticks per instruction\n", name, active, (double)h[0] / (N * per_iter));
     hipFree(out); hipFree(cyc);
 }
 
@@ -94,5 +95,11 @@ int main()
     run<2>("v_mov_b32_dpp quad_perm, dependent (per mov)", 16);
     run<3>("v_mov_b32_dpp quad_perm, independent (per mov)", 16);
     run<4>("fma -> dpp(lo,hi) -> fma ... (per instruction)", 12);
+    for (int active : {32, 16}) {
+        run<0>("v_fma_f64, dependent chain", 8, active);
+        run<1>("v_fma_f64, 8 independent chains", 8, active);
+        run<3>("v_mov_b32_dpp quad_perm, independent (per mov)", 16, active);
+        run<4>("fma -> dpp(lo,hi) -> fma ... (per instruction)", 12, active);
+    }
     return 0;
 }
