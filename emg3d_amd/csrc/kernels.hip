@@ -406,7 +406,8 @@ template <class T> struct QuadRow {
     }
 };
 
-constexpr int QD = emg::LINE_PAD;   // blocks in flight per line = padding granule
+// QD (template parameter of the walks below) = blocks in flight per line = padding granule of the
+// line's records: emg::line_pad(n0), 4 or 2
 
 // One half-chain of the two-sided line solve (stencil.h). HALF 0: the top half, standard
 // blocks k = 0 .. m-1 walked upwards; HALF 1: the bottom half, mirrored blocks walked from
@@ -504,7 +505,7 @@ template <class T, int HALF> struct LaneAddr {
 // branches around memory operations the compiler's s_waitcnt insertion falls back to
 // vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
 // last line walk the last line again but store into a dummy area behind the records.
-template <class T, int HALF>
+template <class T, int HALF, int QD>
 __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int qend, int j, const T *fac,
                                              const double *lfac, const VecRef<T> V, T *dummy, T *dummy4)
 {
@@ -552,14 +553,14 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
     }
 }
 
-template <class T>
+template <class T, int QD>
 __global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines, const T *fac, const double *lfac,
                                                      T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const VecRef<T> V = VecRef<T>::global(vec, nlines);
-    if (blockIdx.y == 0) quad_forward<T, 0>(n0, n0p, nlines, gt >> 2, nlines, gt & 3, fac, lfac, V, dummy, dummy);
-    else quad_forward<T, 1>(n0, n0p, nlines, gt >> 2, nlines, gt & 3, fac, lfac, V, dummy, dummy);
+    if (blockIdx.y == 0) quad_forward<T, 0, QD>(n0, n0p, nlines, gt >> 2, nlines, gt & 3, fac, lfac, V, dummy, dummy);
+    else quad_forward<T, 1, QD>(n0, n0p, nlines, gt >> 2, nlines, gt & 3, fac, lfac, V, dummy, dummy);
 }
 
 // Middle block of the two-sided solve (stencil.h: line_middle), by both half-waves:
@@ -626,7 +627,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 // and the ring's 160 are then not live together: the batched kernel must stay under 256
 // registers so that two workgroups share a CU); otherwise the ring fetch is in flight while
 // the middle block is solved.
-template <class T, int DIR, int HALF, bool MIDFIRST = false>
+template <class T, int DIR, int HALF, int QD, bool MIDFIRST = false>
 __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
                                               int qline, int qend, int j, const T *fac, const double *lfac,
                                               const VecRef<T> V, T *dummy, size_t boff = 0)
@@ -724,15 +725,15 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     }
 }
 
-template <class T, int DIR>
+template <class T, int DIR, int QD>
 __global__ __launch_bounds__(64) void k_line_backward(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                       const T *fac, const double *lfac, const T *vec, T *dummy)
 {
     const int gt = blockIdx.x * 64 + threadIdx.x;
     const VecRef<T> V = VecRef<T>::global(const_cast<T *>(vec), cntp * cntq);
     const int nl = cntp * cntq;
-    if (blockIdx.y == 0) quad_backward<T, DIR, 0>(L, colour, cntp, cntq, n0p, gt >> 2, nl, gt & 3, fac, lfac, V, dummy);
-    else quad_backward<T, DIR, 1>(L, colour, cntp, cntq, n0p, gt >> 2, nl, gt & 3, fac, lfac, V, dummy);
+    if (blockIdx.y == 0) quad_backward<T, DIR, 0, QD>(L, colour, cntp, cntq, n0p, gt >> 2, nl, gt & 3, fac, lfac, V, dummy);
+    else quad_backward<T, DIR, 1, QD>(L, colour, cntp, cntq, n0p, gt >> 2, nl, gt & 3, fac, lfac, V, dummy);
 }
 
 constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves + helper waves for the rhs phase
@@ -747,7 +748,7 @@ constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves +
 // (16 x n0p x 64 B), slot 4 in the global scratch -- for lines too long for mode 1 (128
 // blocks: 166 KB). The launcher picks the first mode that fits. In LDS the records never leave
 // the CU: no HBM/L2 round trips between the three phases.
-template <class T, int DIR, int VMODE, bool BATCH>
+template <class T, int DIR, int VMODE, bool BATCH, int QD = emg::LINE_PAD>
 __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                             int lpw, const T *fac, const double *lfac, T *vec,
                                                             T *dummy, size_t vstride)
@@ -805,13 +806,13 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
     const int half = wave & 1;
     const int qline = line0 + (wave >> 1) * 16 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
-    if (half == 0) quad_forward<T, 0>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
-    else quad_forward<T, 1>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
+    if (half == 0) quad_forward<T, 0, QD>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
+    else quad_forward<T, 1, QD>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
     __syncthreads();
     // the backward pass stores into the FIELD; its dummy slots must be global memory too, or
     // the address select mixes address spaces and the stores become flat instructions
-    if (half == 0) quad_backward<T, DIR, 0, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
-    else quad_backward<T, DIR, 1, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
+    if (half == 0) quad_backward<T, DIR, 0, QD, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
+    else quad_backward<T, DIR, 1, QD, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
 // Residual + per-block partial sums of |r|^2. A workgroup walks `zb` consecutive planes: the plane
@@ -959,25 +960,32 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         };
         const size_t smem1 = rec_bytes(lpw, 5);
         const size_t smem2 = rec_bytes(lpw, 4);
-        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, false>), lds_cu);
-        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false>), lds_cu);
-        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true>), lds_cu);
-        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true>), lds_cu);
-#define LC_LAUNCH(VM, SMEM)                                                                                              \
+        constexpr int P4 = emg::LINE_PAD, P2 = emg::LINE_PAD_SHORT;
+        const bool shortl = emg::line_pad(lc.n0) == P2;       // the granule the line's records were laid out with
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, false, P4>), lds_cu);
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false, P4>), lds_cu);
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true, P4>), lds_cu);
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true, P4>), lds_cu);
+#define LC_LAUNCH(VM, SMEM, QDV)                                                                                         \
     do {                                                                                                                 \
         if (L.batch > 1 || (g_line_occ2 && VM == 0))                                                                     \
-            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, true>), dim3(nwg, L.batch), dim3(LC_THREADS), SMEM, st, L, c,   \
-                               lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                     \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, true, QDV>), dim3(nwg, L.batch), dim3(LC_THREADS), SMEM, st, L, \
+                               c, lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                  \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, false>), dim3(nwg), dim3(LC_THREADS), SMEM, st, L, c, lc.cntp,  \
-                               lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                              \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, false, QDV>), dim3(nwg), dim3(LC_THREADS), SMEM, st, L, c,      \
+                               lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                     \
     } while (0)
-        if (fits(smem1))
-            LC_LAUNCH(1, smem1);
+        if (shortl) {              // (records of <= 6 blocks: a few KB, they fit whenever LDS records are on)
+            if (fits(smem1))
+                LC_LAUNCH(1, smem1, P2);
+            else
+                LC_LAUNCH(0, 0, P2);
+        } else if (fits(smem1))
+            LC_LAUNCH(1, smem1, P4);
         else if (fits(smem2))
-            LC_LAUNCH(2, smem2);
+            LC_LAUNCH(2, smem2, P4);
         else
-            LC_LAUNCH(0, 0);
+            LC_LAUNCH(0, 0, P4);
 #undef LC_LAUNCH
         return;
     }
@@ -990,9 +998,17 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                Lb, c, lc.cntp, lc.cntq, lc.n0p, vb);
         else
             hipLaunchKernelGGL((k_line_rhs<T, DIR>), bgp, bb, 0, st, Lb, c, lc.cntp, lc.cntq, vb);
-        hipLaunchKernelGGL(k_line_forward<T>, qg2, qb, 0, st, lc.n0, lc.n0p, lc.lines, f, lf, vb, vb + dummy_off);
-        hipLaunchKernelGGL((k_line_backward<T, DIR>), qg2, qb, 0, st, Lb, c, lc.cntp, lc.cntq, lc.n0p, f, lf,
-                           (const T *)vb, vb + dummy_off);
+        if (emg::line_pad(lc.n0) == emg::LINE_PAD_SHORT) {
+            hipLaunchKernelGGL((k_line_forward<T, emg::LINE_PAD_SHORT>), qg2, qb, 0, st, lc.n0, lc.n0p, lc.lines, f, lf, vb,
+                               vb + dummy_off);
+            hipLaunchKernelGGL((k_line_backward<T, DIR, emg::LINE_PAD_SHORT>), qg2, qb, 0, st, Lb, c, lc.cntp, lc.cntq, lc.n0p,
+                               f, lf, (const T *)vb, vb + dummy_off);
+        } else {
+            hipLaunchKernelGGL((k_line_forward<T, emg::LINE_PAD>), qg2, qb, 0, st, lc.n0, lc.n0p, lc.lines, f, lf, vb,
+                               vb + dummy_off);
+            hipLaunchKernelGGL((k_line_backward<T, DIR, emg::LINE_PAD>), qg2, qb, 0, st, Lb, c, lc.cntp, lc.cntq, lc.n0p, f,
+                               lf, (const T *)vb, vb + dummy_off);
+        }
     }
 }
 

@@ -819,15 +819,23 @@ template <class T> EMG_HD void ldlt5_solve(const T (&C)[10], const T (&dinv)[5],
 //         the 21 packed entries of T_Q (15 + 6)
 //   lfac: k <= m: B_k; k >= m+1: U_k        (j = 0..3: first row, j = 4..7: diagonal)
 //   vec : slot (k, 0) belongs to E0(k), slot (k, j) to t(k+1)_j -- whatever the grouping
-// m = line_mid(n0) is a multiple of LINE_PAD; behind block n0-1 the bottom half is padded
-// with identity blocks (T = 1, U = 0, rhs = 0) to a multiple of LINE_PAD, so that both
-// half-walks run a LINE_PAD-times unrolled, branch-free software pipeline.
-constexpr int LINE_PAD = 4;
-EMG_HD int line_mid(int n0) { return (n0 / 2) / LINE_PAD * LINE_PAD; }
+// m = line_mid(n0) is a multiple of P = line_pad(n0); behind block n0-1 the bottom half is padded
+// with identity blocks (T = 1, U = 0, rhs = 0) to a multiple of P, so that both half-walks run a
+// P-times unrolled, branch-free software pipeline. P = LINE_PAD = 4 blocks in flight per line;
+// lines of at most LINE_SHORT blocks use P = 2: with four, a 4-block line (coarse levels of a
+// semicoarsened hierarchy have thousands of launches of those) would walk 2 real + 2 identity
+// blocks in one half and none in the other.
+constexpr int LINE_PAD = 4, LINE_PAD_SHORT = 2, LINE_SHORT = 6;
+EMG_HD int line_pad(int n0) { return n0 <= LINE_SHORT ? LINE_PAD_SHORT : LINE_PAD; }
+EMG_HD int line_mid(int n0)
+{
+    const int p = line_pad(n0);
+    return (n0 / 2) / p * p;
+}
 EMG_HD int line_padded(int n0)
 {
-    const int m = line_mid(n0);
-    return m + 2 + (n0 - 2 - m + LINE_PAD - 1) / LINE_PAD * LINE_PAD;
+    const int m = line_mid(n0), p = line_pad(n0);
+    return m + 2 + (n0 - 2 - m + p - 1) / p * p;
 }
 
 // packed index of T(r,m) = T(m,r)

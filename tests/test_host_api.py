@@ -25,7 +25,7 @@ def test_library_loads_and_exports_all_declared_symbols():
     # pure-arithmetic helpers of the ABI work without a device
     assert lib.emg3d_gs_scratch_bytes(0, 8, 8, 8, 1) == 0
     # records per line of the two-sided factorisation (stencil.h: line_padded):
-    # n0 = 8 -> 4 top + 2 middle + 2 bottom padded to 4 = 10;  n0 = 5 -> 0 + 2 + 3 -> 4 = 6
+    # n0 = 8 -> 4 top + 2 middle + 2 bottom padded to 4 = 10;  n0 = 5 (granule 2) -> 2 + 2 + 1 -> 2 = 6
     assert lib.emg3d_gs_scratch_bytes(1, 8, 6, 4, 1) == (5 * 10 * 3 * 2 + 80) * 16
     assert lib.emg3d_line_fac_bytes(1, 8, 6, 4, 1) == 15 * 10 * 5 * 3 * 16
     assert lib.emg3d_line_lfac_bytes(3, 8, 6, 5) == 8 * 6 * 7 * 5 * 8
