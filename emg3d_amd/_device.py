@@ -275,7 +275,7 @@ class DeviceLevel:
         return w.sumsq
 
     def zero_field(self):
-        """e <- 0 (hipMemsetAsync on the stream)."""
+        """e <- 0 (a fill kernel on the stream)."""
         _lib.check(_lib.lib().emg3d_dev_zero(_ptr(self.e), self.e.numel() * self.e.element_size(), _stream()),
                    'emg3d_dev_zero')
 

@@ -247,7 +247,8 @@ int emg3d_dev_krylov_step(size_t n, int is_complex, void *y, int nterms, const v
 /* The Krylov operator (emg3d/solver.py:686-702): out = A x with x = lv->ex|ey|ez (lv->s* unused);
  * entries core.amat_x never touches (upper boundary) are set to zero. */
 int emg3d_dev_apply_operator(const emg3d_level *lv, void *ox, void *oy, void *oz, void *stream);
-/* hipMemsetAsync / device-to-device hipMemcpyAsync on the stream */
+/* zero fill (a kernel of the library: as a hipMemsetAsync node of a captured graph it was seen to
+ * race with the neighbouring kernels) / device-to-device hipMemcpyAsync, on the stream */
 int emg3d_dev_zero(void *p, size_t bytes, void *stream);
 int emg3d_dev_copy(void *dst, const void *src, size_t bytes, void *stream);
 
