@@ -388,6 +388,13 @@ def run_gpu(args, rank, world):
         stats = b.kernel_stats()
         n0 = b.grid.n_cells
         names = {0: 'k_gs_point', 1: 'k_gs_line<x>', 2: 'k_gs_line<y>', 3: 'k_gs_line<z>'}
+        # the HIP kernel behind each label (csrc/kernels.hip; what rocprofv3 lists)
+        from emg3d_amd import _lib
+        nx_, ny_, nz_ = b.grid.shape_cells
+        tmin = _lib.lib().emg3d_get_option(b'point_tile_min')
+        tiled = tmin > 0 and (nx_ - 1) * (ny_ - 1) * (nz_ - 1) >= tmin and (nx_ + 1) * (ny_ + 1) * (nz_ + 1) < 2 ** 31
+        hip_names = {0: 'k_gs_point_tile' if tiled else 'k_gs_point', 1: 'k_line_colour<T, DIR=0, ...>',
+                     2: 'k_line_colour<T, DIR=1, ...>', 3: 'k_line_colour<T, DIR=2, ...>'}
         dom = max(stats, key=lambda k: stats[k]['ms'])
         bytes_per_launch = BYTES_PER_CELL_SWEEP[b.case] * n0 / 4.0
         ms_launch = stats[dom]['ms'] / stats[dom]['launches']
@@ -407,7 +414,7 @@ def run_gpu(args, rank, world):
                        'rel_error_after_run': l2,
                        'parallelism': f'{world} independent sources, 1 per GPU'},
             'roofline': {
-                'bound': 'hbm', 'kernel': names[dom],
+                'bound': 'hbm', 'kernel': names[dom], 'hip_kernel': hip_names[dom],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload, names[dom]),
                 'bytes_per_launch': bytes_per_launch, 'ms_per_launch': ms_launch,
