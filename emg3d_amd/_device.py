@@ -235,6 +235,25 @@ class DeviceLevel:
         _lib.check(lib.emg3d_dev_gauss_seidel(self._cref, lr, nu, fac, lfac, scr, nbytes, _stream()),
                    'emg3d_dev_gauss_seidel')
 
+    def keep_field(self):
+        """Copy e aside (for ``extrapolate_field``)."""
+        if self.__dict__.get('_e_kept') is None:
+            self._e_kept = torch.empty_like(self.e)
+        _lib.check(_lib.lib().emg3d_dev_copy(_ptr(self._e_kept), _ptr(self.e), self.e.numel() * self.e.element_size(),
+                                             _stream()), 'emg3d_dev_copy')
+
+    def extrapolate_field(self, omega):
+        """e <- e_kept + omega (e - e_kept): one fused update (emg3d_dev_krylov_step with two
+        immediate coefficients; the level's reduction workspace doubles as its unused scalar table)."""
+        xs = (ctypes.c_void_p * 2)(self._e_kept.data_ptr(), self.e.data_ptr())
+        slots = (ctypes.c_int * 2)(-1, -1)
+        scales = (ctypes.c_double * 2)(1.0 - omega, omega)
+        none_p, none_i = (ctypes.c_void_p * 1)(), (ctypes.c_int * 1)()
+        w = self.work
+        _lib.check(_lib.lib().emg3d_dev_krylov_step(
+            self.e.numel(), int(self.is_complex), _ptr(self.e), 2, xs, slots, scales, 0, none_p, none_p, none_i, 0, none_i,
+            _ptr(w.ws), _ptr(w.ws), w.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
+
     def residual(self, store=True, norm=False):
         """r = s - A e into self.r (store) and/or its l2-norm (norm; synchronises)."""
         lib = _lib.lib()

@@ -40,7 +40,15 @@ def __dir__():
 # keywords of `solve` that are not solver settings: name -> default
 _SOLVE_EXTRAS = {'always_return': False, 'plain': False, 'efield': None, 'hierarchy': None,
                  '_download': True,           # False: the result stays in hierarchy.top.e only
-                 '_sparse_source': False}     # the source goes up as its few non-zeros
+                 '_sparse_source': False,     # the source goes up as its few non-zeros
+                 'smoother_omega': 1.0}       # != 1: extrapolated smoothing calls (_cycle.smooth_level)
+
+
+def _check_omega(omega):
+    omega = float(omega)
+    if not 0.0 < omega < 2.0:
+        raise ValueError(f"`smoother_omega` must lie in (0, 2). Provided: {omega}.")
+    return omega
 
 
 def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=True, verb=0,
@@ -59,7 +67,11 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
 
     Not in the reference: ``hierarchy=`` (a ``Hierarchy`` built for the same model, grid and
     frequency) reuses the device-resident levels, line factorisations and captured graphs of
-    an earlier solve -- what several sources at one frequency share.
+    an earlier solve -- what several sources at one frequency share; ``smoother_omega=1.0``: a
+    value != 1 extrapolates every smoothing call, e <- e_before + omega (e_after - e_before) --
+    same solution, and on models where the four-colour ordering costs cycles against the
+    reference's sequential sweeps, fewer of them (1.2-1.3: 0-17 % in DESIGN.md 4.1; too large a
+    value diverges).
 
     Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``).
     """
@@ -76,6 +88,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
             "Source field is missing frequency information; Create "
             "it with `emg3d.fields.get_source_field`, or initiate it "
             "with `emg3d.fields.Field`, providing frequency information.")
+    var.smoother_omega = _check_omega(extra['smoother_omega'])
     var.sparse_source = bool(extra['_sparse_source']) and getattr(sfield, '_sparse', None) is not None
     var.download = bool(extra['_download'])
     var.l2_refe = _host_norm(sfield._sparse[1] if var.sparse_source else sfield.field)
@@ -215,6 +228,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     receiver_method = kwargs.pop('receiver_method', 'cubic')
     keep_fields = kwargs.pop('keep_fields', True)
     hierarchy = kwargs.pop('hierarchy', None)            # a Hierarchy(vmodel, batch=len(sfields)) to reuse
+    omega = _check_omega(kwargs.pop('smoother_omega', 1.0))     # extrapolated smoothing calls, as in solve()
     sfields = list(sfields)
     nb = len(sfields)
     if nb == 0:
@@ -227,8 +241,10 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
             raise ValueError("solve_batch: all sources must share grid and frequency.")
     vmodel = models.VolumeModel(model, first)
     def new_var():
-        return MGParameters(sslsolver=sslsolver, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
-                            shape_cells=model.shape, verb=verb, **kwargs)
+        v = MGParameters(sslsolver=sslsolver, semicoarsening=semicoarsening, linerelaxation=linerelaxation,
+                         shape_cells=model.shape, verb=verb, **kwargs)
+        v.smoother_omega = omega
+        return v
     vars_ = [new_var() for _ in sfields]
     var = svar = new_var()             # carries the structure of the cycle, shared by all sources
     if var.sslsolver not in (None, False, 'bicgstab') or (var.sslsolver and not var.cycle):
@@ -243,7 +259,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         for b, sf in enumerate(sfields):
             ef, info = solve(model, sf, sslsolver=sslsolver, semicoarsening=semicoarsening,
                              linerelaxation=linerelaxation, verb=verb, return_info=True, always_return=True,
-                             **kwargs)
+                             smoother_omega=omega, **kwargs)
             if rec_of(b) is not None:
                 info['responses'] = fields.get_receiver(ef, rec_of(b), receiver_method)
             out.append((ef if keep_fields else None, info))

@@ -1425,3 +1425,29 @@ def test_source_field_on_the_device_vs_host(freq):
     hier = solver.Hierarchy(emg3d.models.VolumeModel(model, sf))
     hier.put_source(sf, hier.top.s, sparse=True)
     assert relerr(hier.top.s.cpu().numpy(), sf.field) < 1e-13
+
+
+@pytest.mark.gpu
+def test_extrapolated_smoothing_same_solution_fewer_cycles():
+    """solve(..., smoother_omega=1.3): every smoothing call is extrapolated (not in the reference;
+    default 1 = the reference's smoothing). Same fixed point -- the converged field agrees with the
+    plain solve to the tolerance -- and on the tri-axial workload, where the four-colour ordering
+    costs cycles, it takes fewer; a batch gives the fields of the single solves."""
+    import bench
+    wl = bench.workload('triaxial64')
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **{k: np.asfortranarray(v) for k, v in wl['res'].items()})
+    sf = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    opts = dict(sslsolver=False, tol=1e-9, maxit=60, return_info=True, **wl['opts'])
+    e1, i1 = emg3d.solve(model, sf, **opts)
+    e2, i2 = emg3d.solve(model, sf, smoother_omega=1.3, **opts)
+    assert i1['exit'] == 0 and i2['exit'] == 0
+    assert i2['it_mg'] < i1['it_mg'], (i1['it_mg'], i2['it_mg'])
+    assert np.linalg.norm(e1.field - e2.field) <= 2e-8 * np.linalg.norm(e1.field)
+    sf2 = emg3d.get_source_field(grid, (150., -100., 50., 30., 10.), wl['frequency'])
+    e3, i3 = emg3d.solve(model, sf2, smoother_omega=1.3, **opts)
+    opts_b = {k: v for k, v in opts.items() if k != 'return_info'}
+    (b2, ib2), (b3, ib3) = emg3d.solve_batch(model, [sf, sf2], smoother_omega=1.3, **opts_b)
+    assert ib2['it_mg'] == i2['it_mg'] and ib3['it_mg'] == i3['it_mg']
+    assert np.linalg.norm(b2.field - e2.field) <= 1e-12 * np.linalg.norm(e2.field)
+    assert np.linalg.norm(b3.field - e3.field) <= 1e-12 * np.linalg.norm(e3.field)

@@ -283,3 +283,11 @@ def test_residual_source_field_vs_reference(golden_gradient):
     dense = np.zeros_like(rf.field)
     dense[idx] = val
     assert np.array_equal(dense, rf.field)
+
+
+def test_smoother_omega_is_validated():
+    from emg3d_amd import solver
+    assert solver._check_omega(1) == 1.0 and solver._check_omega(1.25) == 1.25
+    for bad in (0, 2, -0.5, 2.5):
+        with pytest.raises(ValueError, match="smoother_omega"):
+            solver._check_omega(bad)
