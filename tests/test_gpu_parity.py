@@ -1123,6 +1123,18 @@ def test_full_size_per_sweep_parity_vs_oracle(shape, case):
         assert relerr(got, want) < 2e-12, (shape, fn)
         lv._factors.pop(lr, None)                   # free the 5 GB of line factors per direction
         torch.cuda.empty_cache()
+    # the residual on the same level (at 256^3 a workgroup walks 8 planes, at 128^3 one) and its
+    # norm, and the Krylov operator, against core.amat_x of the oracle
+    og = mg_ref.Grid(grid.h, grid.origin)
+    S, E = mg_ref.Field(og, s.copy()), mg_ref.Field(og, e0)
+    ocore.amat_x(S.fx, S.fy, S.fz, E.fx, E.fy, E.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h)
+    lv.e.copy_(torch.from_numpy(e0))
+    norm = lv.residual(store=True, norm=True)
+    assert relerr(lv.r.cpu().numpy(), S.field) < 1e-13
+    assert norm == pytest.approx(np.linalg.norm(S.field), rel=1e-12)
+    out = torch.empty_like(lv.e)
+    lv.apply_A(lv.e, out)
+    assert relerr(out.cpu().numpy(), s - S.field) < 1e-12          # A e = s - (s - A e)
 
 
 @pytest.mark.parametrize('shape,lr', [
