@@ -172,7 +172,7 @@ __device__ __forceinline__ void lds_barrier()
 // PF: software prefetch -- the global inputs (source; PF = 2: eta sums too) of the NEXT colour
 // step are requested before the current node is solved, so their latency overlaps the ~600
 // fp64 instructions of the 6x6 solve inside the wave, not only across waves.
-template <class T, class TB, int ST, bool BATCH, int PF>
+template <class T, class TB, int ST, bool BATCH, int PFV>
 __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> L, const void *pst, emg::TilePair P,
                                                                   int colours, int nsteps)
 {
@@ -205,6 +205,34 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
         if (ST == 0) emg::point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
         else emg::tile_pst_load<T, TB, ST == 3>(pst, ntx, nty, tx, ty, tz, colour, t, in);
     };
+    // PFV = 3: paired source loads. A thread's four nodes (one per node colour) are the 2 x 2
+    // patch (x0 + 2 jx + {0,1}, y0 + 2 jy + {0,1}) of its plane; the two nodes of a row differ
+    // in the low colour bit. Fetched per node, the source values of a row are stride-2 gathers
+    // that touch every cache line of the row in BOTH steps. Here the first of the two steps
+    // fetches the values of both nodes (same lines, same instruction stream) and holds the
+    // partner's six values (24 registers per row) until its step comes.
+    constexpr bool PAIR = PFV == 3;
+    constexpr int PF = PAIR ? 0 : PFV;
+    T held_lo[6], held_hi[6];                  // partner values of the row with colour bit 1 = 0 / 1
+    int held_lo_c = -1, held_hi_c = -1;        // the colour they belong to (-1: none)
+    auto pair_source = [&](int ix, int iy, int iz, int colour, bool ok, T (&held)[6], int &held_c, emg::PointIn<T> &in) {
+        if (held_c == colour) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) in.s[r] = held[r];
+            held_c = -1;
+            return;
+        }
+        emg::point_load_source<T>(L, ix, iy, iz, in);
+        int px, py, pz;
+        const bool pok = emg::tile_node<TB>(L.nx, L.ny, L.nz, x0, y0, z0, colour ^ 1, t, px, py, pz);
+        if (!pok) { px = ix; py = iy; pz = iz; }
+        (void)ok;
+        emg::PointIn<T> q;
+        emg::point_load_source<T>(L, px, py, pz, q);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) held[r] = q.s[r];
+        held_c = colour ^ 1;
+    };
     emg::PointIn<T> in;
     int ix, iy, iz, colour;
     bool ok = node(0, ix, iy, iz, colour);
@@ -216,7 +244,10 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
     // waits for the inputs of its next node, the other one computes
 #pragma unroll 1
     for (int cc = 0; cc < nsteps; ++cc) {     // node colours, two bits each (4, or 7-8 for two fused sweeps)
-        if (PF < 1) emg::point_load_source<T>(L, ix, iy, iz, in);
+        if (PAIR) {
+            if (colour & 2) pair_source(ix, iy, iz, colour, ok, held_hi, held_hi_c, in);
+            else pair_source(ix, iy, iz, colour, ok, held_lo, held_lo_c, in);
+        } else if (PF < 1) emg::point_load_source<T>(L, ix, iy, iz, in);
         if (PF < 2) load_eta(ix, iy, iz, colour, in);
         emg::point_load_zeta<T>(emg::ZetaTile<E>{ed}, ix, iy, iz, in);
         // the next step's node and its global inputs (the last step asks for its own again)
@@ -397,7 +428,17 @@ template <class T> struct QuadRow {
 #pragma unroll
         for (int r = 0; r < 5; ++r) t[r] = *reinterpret_cast<const T *>(f + a.ft[r]);
         t44 = *reinterpret_cast<const T *>(f + a.ft[5]);
-        v = *a.pvj(k);
+        if constexpr (A::split) {
+            // split records: the slot is in LDS or in the global scratch, depending on the row --
+            // both are read (the one that does not apply at a fixed valid address), no branch
+            const bool in = a.in_lds(k);
+            const T *const pl = in ? a.pvj(k) : a.ldum;
+            const T *const pg = in ? a.gdum : a.gpvj(k);
+            const T vl = *pl, vg = *pg;
+            v = in ? vl : vg;
+        } else {
+            v = *a.pvj(k);
+        }
         v4 = *a.pv4(k);
         bA = *reinterpret_cast<const double *>(lf + a.la);
         bD = *reinterpret_cast<const double *>(lf + a.ld);
@@ -437,6 +478,12 @@ template <class T> struct VecRef {
     int stride, line0, width;
     T *base4;
     int stride4, line04;
+    // split records (fused kernel, VMODE 3): rows klo <= k < khi keep their slots 0..3 in LDS
+    // (`base`, shifted by -klo rows, width 4), all other rows in the global scratch (`gbase`, laid
+    // out like VecRef::global); slot 4 of every row is in the global scratch
+    T *gbase;
+    int gstride, klo, khi;
+    __device__ __forceinline__ T *pg(int k, int line, int r) const { return gbase + ((size_t)k * gstride + line) * 5 + r; }
     __device__ __forceinline__ T *p(int k, int line, int r) const
     {
         return base + ((size_t)k * stride + (line - line0)) * width + r;
@@ -447,7 +494,7 @@ template <class T> struct VecRef {
     }
     static __device__ __forceinline__ VecRef global(T *vec, int nlines)
     {
-        return VecRef{vec, nlines, 0, 5, vec, nlines, 0};
+        return VecRef{vec, nlines, 0, 5, vec, nlines, 0, vec, nlines, 0, 0};
     }
 };
 // Addresses of one lane inside the half-chain loops, split into a per-block part that is
@@ -455,7 +502,8 @@ template <class T> struct VecRef {
 // loop-invariant, non-negative 32-bit per-lane part. Without the split every load of every
 // step pays 64-bit per-lane multiplies (v_mad_u64_u32: quarter rate) -- a quarter of the
 // issue slots of a step.
-template <class T, int HALF> struct LaneAddr {
+template <class T, int HALF, bool SPLIT = false> struct LaneAddr {
+    static constexpr bool split = SPLIT;
     const char *fac, *lfac;      // uniform
     size_t frow, lrow;           // bytes of one block row of the factor arrays (all lines)
     unsigned ft[6];              // lane byte offsets in a fac row: T(j,(j+r)&3) r=0..3, T(j,4), T(4,4)
@@ -463,6 +511,13 @@ template <class T, int HALF> struct LaneAddr {
     char *vb, *vb4;              // uniform bases of the vec slots 0..3 / slot 4
     size_t vrow, vrow4;          // bytes of one block row of the records
     unsigned vj, v4;             // lane byte offsets of slot j / slot 4
+    // SPLIT: the global home of slots 0..3, the row range held in LDS, this lane's row offset, and
+    // the fixed addresses read when a slot lives in the other space
+    char *gvb;
+    size_t gvrow;
+    unsigned gvj;
+    int klo, khi, radd;
+    const T *ldum, *gdum;
     __device__ __forceinline__ LaneAddr(const T *f, const double *lf, int nlines, int line, int j, const VecRef<T> &V)
     {
         fac = reinterpret_cast<const char *>(f);
@@ -489,6 +544,25 @@ template <class T, int HALF> struct LaneAddr {
         vrow4 = (size_t)V.stride4 * 5 * sizeof(T);
         vj = (unsigned)(((line - V.line0) * V.width + j) * sizeof(T)) + ((HALF && j == 0) ? (unsigned)vrow : 0u);
         v4 = (unsigned)(((line - V.line04) * 5 + 4) * sizeof(T));
+        if (SPLIT) {
+            gvb = reinterpret_cast<char *>(V.gbase);
+            gvrow = (size_t)V.gstride * 5 * sizeof(T);
+            gvj = (unsigned)((line * 5 + j) * sizeof(T));
+            klo = V.klo; khi = V.khi;
+            radd = (HALF && j == 0) ? 1 : 0;
+            ldum = reinterpret_cast<const T *>(vb + (size_t)V.klo * vrow + (unsigned)(((line - V.line0) * V.width + j) * sizeof(T)));
+            gdum = reinterpret_cast<const T *>(gvb + gvj);
+        }
+    }
+    // SPLIT: is this lane's slot of block k (record row k, or k-1 (+1 for lane 0) in a mirrored half) in LDS?
+    __device__ __forceinline__ bool in_lds(int k) const
+    {
+        const int row = (HALF ? k - 1 : k) + radd;
+        return row >= klo && row < khi;
+    }
+    __device__ __forceinline__ T *gpvj(int k) const
+    {
+        return reinterpret_cast<T *>(gvb + (size_t)((HALF ? k - 1 : k) + radd) * gvrow + gvj);
     }
     __device__ __forceinline__ T *pvj(int k) const
     {
@@ -505,7 +579,7 @@ template <class T, int HALF> struct LaneAddr {
 // branches around memory operations the compiler's s_waitcnt insertion falls back to
 // vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
 // last line walk the last line again but store into a dummy area behind the records.
-template <class T, int HALF, int QD>
+template <class T, int HALF, int QD, bool SPLIT = false>
 __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int qend, int j, const T *fac,
                                              const double *lfac, const VecRef<T> V, T *dummy, T *dummy4)
 {
@@ -518,7 +592,7 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
     T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
     T *const dslot4 = dummy4 + ((threadIdx.x & 63) >> 2) * 5;
     QuadRow<T> ring[QD];
-    const LaneAddr<T, HALF> LA(fac, lfac, nlines, line, j, V);
+    const LaneAddr<T, HALF, SPLIT> LA(fac, lfac, nlines, line, j, V);
     auto fetch = [&](QuadRow<T> &q, int i) { q.load(LA, W.fwd(W.clampi(i))); };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
@@ -544,9 +618,18 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
             const T w4 = emg::mad(q.t44, c4, quad_sum(q.t[4] * cj));
             wsel = nz * wn + is0 * w4;
             w4p = w4;
-            T *const oj = active ? LA.pvj(k) : dslot + j;
             T *const o4 = active ? LA.pv4(k) : dslot4 + 4;
-            *oj = wn;
+            if constexpr (SPLIT) {
+                // (dummy: LDS, dummy4: global -- one store into either space, the idle one to its dummy slot)
+                const bool in = LA.in_lds(k);
+                T *const ol = (active && in) ? LA.pvj(k) : dslot + j;
+                T *const og = (active && !in) ? LA.gpvj(k) : dslot4 + j;
+                *ol = wn;
+                *og = wn;
+            } else {
+                T *const oj = active ? LA.pvj(k) : dslot + j;
+                *oj = wn;
+            }
             *o4 = w4;
             fetch(ring[d], i0 + d + QD);
         }
@@ -627,7 +710,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 // and the ring's 160 are then not live together: the batched kernel must stay under 256
 // registers so that two workgroups share a CU); otherwise the ring fetch is in flight while
 // the middle block is solved.
-template <class T, int DIR, int HALF, int QD, bool MIDFIRST = false>
+template <class T, int DIR, int HALF, int QD, bool MIDFIRST = false, bool SPLIT = false>
 __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
                                               int qline, int qend, int j, const T *fac, const double *lfac,
                                               const VecRef<T> V, T *dummy, size_t boff = 0)
@@ -653,7 +736,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     T *const dj = dslot + j, *const d4 = dslot + 4;
 
     QuadRow<T> ring[QD];
-    const LaneAddr<T, HALF> LA(fac, lfac, nlines, line, j, V);
+    const LaneAddr<T, HALF, SPLIT> LA(fac, lfac, nlines, line, j, V);
     auto fetch = [&](QuadRow<T> &q, int i) {
         q.load(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));   // a half without blocks still prefetches
     };
@@ -779,6 +862,13 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
         V = VecRef<T>{lvec, lpw, line0, 4, vec, nlines, 0};
         dum = lvec + (size_t)lpw * n0p * 4;
         dum4 = dummy;
+    } else if (VMODE == 3) {
+        // lines too long for mode 2: the rows around the middle block in LDS, the outer rows in the
+        // global scratch (launch.h: line_split_rows)
+        const emg::LineSplit sp = emg::line_split_rows(A.n0(), n0p, lpw, sizeof(T));
+        V = VecRef<T>{lvec - (size_t)sp.klo * lpw * 4, lpw, line0, 4, vec, nlines, 0, vec, nlines, sp.klo, sp.khi};
+        dum = lvec + (size_t)lpw * (sp.khi - sp.klo) * 4;
+        dum4 = dummy;
     } else {
         V = VecRef<T>::global(vec, nlines);
         dum = dum4 = dummy;
@@ -793,8 +883,13 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
         T rhs[5];
         emg::line_rhs<T, DIR>(A, min(k, A.n0() - 1), i1, i2, rhs);
         const double keep = k < A.n0() ? 1.0 : 0.0;            // identity padding blocks: rhs = 0
+        if (VMODE == 3 && (k < V.klo || k >= V.khi)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *V.p(k, lid, r) = keep * rhs[r];
+            for (int r = 0; r < 4; ++r) *V.pg(k, lid, r) = keep * rhs[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *V.p(k, lid, r) = keep * rhs[r];
+        }
         *V.p4(k, lid) = keep * rhs[4];
     }
     __syncthreads();
@@ -806,13 +901,14 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
     const int half = wave & 1;
     const int qline = line0 + (wave >> 1) * 16 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
-    if (half == 0) quad_forward<T, 0, QD>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
-    else quad_forward<T, 1, QD>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
+    constexpr bool SPLIT = VMODE == 3;
+    if (half == 0) quad_forward<T, 0, QD, SPLIT>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
+    else quad_forward<T, 1, QD, SPLIT>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
     __syncthreads();
     // the backward pass stores into the FIELD; its dummy slots must be global memory too, or
     // the address select mixes address spaces and the stores become flat instructions
-    if (half == 0) quad_backward<T, DIR, 0, QD, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
-    else quad_backward<T, DIR, 1, QD, BATCH>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
+    if (half == 0) quad_backward<T, DIR, 0, QD, BATCH, SPLIT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
+    else quad_backward<T, DIR, 1, QD, BATCH, SPLIT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
 // Residual + per-block partial sums of |r|^2. A workgroup walks `zb` consecutive planes: the plane
@@ -955,8 +1051,13 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
             while (lpw > 4 && rec_bytes(lpw, 4) > lds_cu) lpw /= 2;
         }
         const unsigned nwg = cdiv(lc.lines, lpw);
+        // (the QD = 4 kernels hold more than 256 registers: one workgroup per CU whatever its LDS use,
+        // so their records go to LDS whenever they fit; the short-line kernels share a CU and keep
+        // their records in LDS only while every workgroup of the launch gets a CU at once)
+        const bool one_per_cu = emg::line_pad(lc.n0) == emg::LINE_PAD && L.batch == 1;
         auto fits = [&](size_t smem) {
-            return g_line_lds && smem <= lds_cu && (g_line_lds == 2 || (size_t)nwg <= 256 * (lds_cu / smem));
+            return g_line_lds && smem <= lds_cu &&
+                   (g_line_lds >= 2 || one_per_cu || (size_t)nwg <= 256 * (lds_cu / smem));
         };
         const size_t smem1 = rec_bytes(lpw, 5);
         const size_t smem2 = rec_bytes(lpw, 4);
@@ -966,6 +1067,7 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false, P4>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true, P4>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true, P4>), lds_cu);
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 3, false, P4>), lds_cu);
 #define LC_LAUNCH(VM, SMEM, QDV)                                                                                         \
     do {                                                                                                                 \
         if (L.batch > 1 || (g_line_occ2 && VM == 0))                                                                     \
@@ -984,7 +1086,16 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
             LC_LAUNCH(1, smem1, P4);
         else if (fits(smem2))
             LC_LAUNCH(2, smem2, P4);
-        else
+        else if (g_line_lds >= 3 && L.batch == 1 && !g_line_occ2 && lpw == 16) {
+            // line_lds = 3 (experiment): lines too long for mode 2 keep the record rows around the
+            // middle block in LDS, the outer rows in the global scratch (mode 3)
+            const emg::LineSplit sp = emg::line_split_rows(lc.n0, lc.n0p, lpw, sizeof(T));
+            if (sp.lds_bytes > 0)
+                hipLaunchKernelGGL((k_line_colour<T, DIR, 3, false, P4>), dim3(nwg), dim3(LC_THREADS), sp.lds_bytes, st, L, c,
+                                   lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);
+            else
+                LC_LAUNCH(0, 0, P4);
+        } else
             LC_LAUNCH(0, 0, P4);
 #undef LC_LAUNCH
         return;
@@ -1039,13 +1150,13 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             // eta sums: tile-major buffer (stored halves when the level's eta are purely imaginary
             // or the field is real), or formed on the fly when fac == NULL
             const int st = !fac ? 0 : (pst_stored_half<T>(L.flags) ? 3 : 2);
-            int pf = (g_point_prefetch >= 0 && g_point_prefetch <= 2) ? g_point_prefetch : 0;
-            if (st == 0 && pf > 1) pf = 1;      // 24 eta loads per node in flight twice do not fit the registers
+            int pf = (g_point_prefetch >= 0 && g_point_prefetch <= 3) ? g_point_prefetch : 0;
+            if (st == 0 && pf == 2) pf = 1;      // 24 eta loads per node in flight twice do not fit the registers
 #define PT_ROW(B, PF_)                                                                                         \
     {(const void *)&k_gs_point_tile<T, TB, 0, B, PF_>, (const void *)&k_gs_point_tile<T, TB, 2, B, PF_>,          \
      (const void *)&k_gs_point_tile<T, TB, 3, B, PF_>}
-            const void *kfn[2][3][3] = {{PT_ROW(false, 0), PT_ROW(false, 1), PT_ROW(false, 2)},
-                                        {PT_ROW(true, 0), PT_ROW(true, 1), PT_ROW(true, 2)}};
+            const void *kfn[2][4][3] = {{PT_ROW(false, 0), PT_ROW(false, 1), PT_ROW(false, 2), PT_ROW(false, 3)},
+                                        {PT_ROW(true, 0), PT_ROW(true, 1), PT_ROW(true, 2), PT_ROW(true, 3)}};
 #undef PT_ROW
             const void *kern = kfn[L.batch > 1 ? 1 : 0][pf][st == 0 ? 0 : st - 1];
             HIP_TRY(allow_lds(kern, smem));

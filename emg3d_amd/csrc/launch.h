@@ -499,6 +499,26 @@ inline int line_n0(int dir, int nx, int ny, int nz) { return dir == 0 ? nx : dir
 // quads of the last wave of the forward / backward kernels (16 quads x 5 entries)
 constexpr int LINE_DUMMY = 80;
 
+// Split records of the fused line kernel (k_line_colour, VMODE 3) for lines whose records do not
+// fit the LDS of a CU even with slot 4 left out: the `rows` record rows around the middle block
+// keep their slots 0..3 in LDS, the outer rows stay in the global scratch. Host and device use
+// this one rule. rows = 0: not applicable (the window must hold the rows the middle block reads).
+struct LineSplit { int klo, khi; size_t lds_bytes; };
+EMG_HD LineSplit line_split_rows(int n0, int n0p, int lpw, size_t elem_bytes)
+{
+    const size_t lds_cu = 160 * 1024;
+    int rows = (int)((lds_cu / elem_bytes - LINE_DUMMY) / ((size_t)lpw * 4));
+    rows &= ~1;
+    if (rows > n0p) rows = n0p;
+    const int mk = line_mid(n0);
+    int klo = mk + 1 - rows / 2;
+    if (klo > n0p - rows) klo = n0p - rows;
+    if (klo < 0) klo = 0;
+    LineSplit sp{klo, klo + rows, ((size_t)lpw * rows * 4 + LINE_DUMMY) * elem_bytes};
+    if (rows < 8 || sp.klo > mk - 1 || sp.khi < mk + 3 || sp.khi > n0p) sp = LineSplit{0, 0, 0};
+    return sp;
+}
+
 // Geometry of one colour class of one direction on one level.
 struct LineClass {
     int n0, n0p, cntp, cntq, lines;   // blocks per line (real, padded), lines along p / q, total
