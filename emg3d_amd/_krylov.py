@@ -1,4 +1,4 @@
-"""Device BiCGSTAB and CGS around the multigrid preconditioner.
+"""Device BiCGSTAB, CGS and GCROT(m,k) around the multigrid preconditioner.
 
 The reference hands ``scipy.sparse.linalg.bicgstab / cgs / gcrotmk`` a host ``LinearOperator``
 and a host preconditioner (emg3d/solver.py:652-784). Here the vectors never leave HBM: every
@@ -26,14 +26,29 @@ class Vectors:
 
     NSLOTS = 32
 
-    def __init__(self, top, n=None):
+    def __init__(self, top, n=None, nslots=None):
         self.top = top
         self.n = top.e.numel() if n is None else int(n)       # (n: one right-hand side of a batch)
         self.is_complex = top.is_complex
+        if nslots is not None:
+            self.NSLOTS = int(nslots)
         self.table = torch.zeros(2 * self.NSLOTS, dtype=torch.float64, device=top.device)
         self.ws = torch.empty(_lib.lib().emg3d_krylov_ws_len(), dtype=torch.float64, device=top.device)
         self._names = {}
         self._host = torch.empty(2 * self.NSLOTS, dtype=torch.float64).pin_memory()
+        self._stage = torch.empty(2 * self.NSLOTS, dtype=torch.float64).pin_memory()
+
+    def put(self, names, values):
+        """Host scalars into the table slots ``names`` (coefficients the host computed from a small
+        dense problem): consecutive slots, one small copy."""
+        s0 = self.slot(names[0])
+        for i, nm in enumerate(names):
+            assert self.slot(nm) == s0 + i, 'put: the slots must be consecutive'
+        torch.cuda.current_stream().synchronize()        # (the staging buffer may still be in flight)
+        h = self._stage.numpy()
+        for i, v in enumerate(values):
+            h[2 * i], h[2 * i + 1] = np.real(v), np.imag(v)
+        self.table[2 * s0:2 * (s0 + len(names))].copy_(self._stage[:2 * len(names)], non_blocking=True)
 
     def new(self):
         return torch.empty(self.n, dtype=self.top.dtype, device=self.top.device)
@@ -202,6 +217,142 @@ def cgs(hier, b, x, var, run_cycles, callback):
         rr, rho = V.read('rr', 'rho')
         callback(float(np.sqrt(abs(rr))))          # = |b - A x|, what the reference's callback evaluates
     return var.ssl_maxit
+
+
+def _combine(V, out, vecs, names):
+    """out = sum_i table[names[i]] * vecs[i] (any number of terms, four per launch)."""
+    terms = [(v, nm) for v, nm in zip(vecs, names)]
+    V.step(out, terms[:4])
+    for i in range(4, len(terms), 3):
+        V.step(out, [(out, 1.0)] + terms[i:i + 3])
+
+
+def gcrotmk(hier, b, x, var, run_cycles, callback, m=20, k=None):
+    """Flexible GCROT(m,k) (de Sturler 1999; Hicken & Zingg 2010) as scipy.sparse.linalg.gcrotmk
+    iterates it with its defaults (m = 20 inner FGMRES steps, k = m recycled pairs, the oldest pair
+    dropped): the vectors -- up to m + k Arnoldi vectors and as many preconditioned ones, k pairs
+    (c, u) -- stay in HBM; the modified Gram-Schmidt sweep of an inner step is a chain of fused
+    launches (subtract the previous projection, inner product with the next vector: csrc/krylov.h)
+    whose coefficients the host reads ONCE per inner step; the small dense problems (QR update of
+    the Hessenberg matrix, least squares) run on the host with SciPy's own routines, exactly as in
+    scipy/sparse/linalg/_isolve/_gcrotmk.py. ``callback(l2)``: at the start of every outer
+    iteration with the true residual norm, as the reference's callback evaluates it. Returns the
+    SciPy status: 0 converged, else the number of outer iterations."""
+    from numpy.linalg import LinAlgError
+    from scipy.linalg import qr_insert, lstsq
+    top = hier.top
+    k = m if k is None else k
+    nproj = m + 2 * k + 2                                 # Gram-Schmidt coefficients of one inner step
+    V = Vectors(top, nslots=2 * nproj + 16)
+    psolve = _preconditioner(top, var, run_cycles, V)
+    dt = np.complex128 if V.is_complex else np.float64
+    a_names = [f'a{i}' for i in range(nproj)]             # projections of one inner step
+    c_names = [f'c{i}' for i in range(nproj)]             # host coefficients of a linear combination
+    for nm in a_names + c_names:
+        V.slot(nm)
+    eps = np.finfo(np.float64).eps
+    CU = []
+    r = V.new()
+
+    top.apply_A(x, r)
+    V.step(r, [(b, 1.0), (r, -1.0)], dots=[('bb', b, b), ('rr', r, r)])
+    bb, rr = V.read('bb', 'rr')
+    b_norm = float(np.sqrt(abs(bb)))
+    if b_norm == 0:
+        V.copy(x, b)
+        return 0
+    beta_tol = max(1e-30, var.tol * b_norm)
+
+    def fgmres(v0, ml, atol, cs):
+        vs, zs = [v0], []
+        B = np.zeros((len(cs), ml), dtype=dt)
+        Q, R = np.ones((1, 1), dtype=dt), np.zeros((1, 0), dtype=dt)
+        breakdown = False
+        for j in range(ml):
+            z, w = V.new(), V.new()
+            psolve(vs[-1], z)
+            top.apply_A(z, w)
+            basis = cs + vs
+            # w_norm, then w -= (q_i . w) q_i for the c's, then the v's, one after the other
+            V.step(None, dots=[('wn', w, w), (a_names[0], basis[0], w)])
+            for i in range(1, len(basis)):
+                V.step(w, [(w, 1.0), (basis[i - 1], (a_names[i - 1], -1.0))], dots=[(a_names[i], basis[i], w)])
+            V.step(w, [(w, 1.0), (basis[-1], (a_names[len(basis) - 1], -1.0))], dots=[('hh', w, w)])
+            got = V.read('wn', 'hh', *a_names[:len(basis)])
+            w_norm, hlast, alphas = float(np.sqrt(abs(got[0]))), float(np.sqrt(abs(got[1]))), got[2:]
+            B[:, j] = alphas[:len(cs)]
+            hcur = np.zeros(j + 2, dtype=dt)
+            hcur[:j + 1] = alphas[len(cs):]
+            hcur[j + 1] = hlast
+            with np.errstate(over='ignore', divide='ignore'):
+                alpha = 1 / hlast
+            if np.isfinite(alpha):
+                V.step(w, [(w, float(alpha))])
+            if not (hlast > eps * w_norm):
+                breakdown = True
+            vs.append(w)
+            zs.append(z)
+            Q2 = np.zeros((j + 2, j + 2), dtype=dt, order='F')
+            Q2[:j + 1, :j + 1] = Q
+            Q2[j + 1, j + 1] = 1
+            R2 = np.zeros((j + 2, j), dtype=dt, order='F')
+            R2[:j + 1, :] = R
+            Q, R = qr_insert(Q2, R2, hcur, j, which='col', overwrite_qru=True, check_finite=False)
+            res = abs(Q[0, -1])
+            if res < atol or breakdown:
+                break
+        if not np.isfinite(R[j, j]):
+            raise LinAlgError()
+        y, _, _, _ = lstsq(R[:j + 1, :j + 1], Q[0, :j + 1].conj())
+        return Q, R, B[:, :j + 1], vs, zs, y
+
+    j_outer = -1
+    for j_outer in range(var.ssl_maxit):
+        sumsq = top.residual_sumsq(x, b)                 # the reference's callback: |b - A x|
+        (rr,), l2 = V.read('rr', extra=sumsq)
+        callback(float(np.sqrt(l2[0])))
+        beta = float(np.sqrt(abs(rr)))
+        if beta <= beta_tol and (j_outer > 0 or CU):
+            top.apply_A(x, r)
+            V.step(r, [(b, 1.0), (r, -1.0)], dots=[('rr', r, r)])
+            beta = float(np.sqrt(abs(V.read('rr')[0])))
+        if beta <= beta_tol:
+            j_outer = -1
+            break
+        ml = m + max(k - len(CU), 0)
+        cs = [c for c, _ in CU]
+        v0 = V.new()
+        V.step(v0, [(r, 1.0 / beta)])
+        try:
+            Q, R, B, vs, zs, y = fgmres(v0, ml, beta_tol / beta, cs)
+        except LinAlgError:
+            break
+        y = y * beta
+        # ux = Z y - U (B y);  cx = V (Q R y)
+        by = B.dot(y)
+        ux, cx = V.new(), V.new()
+        coef = list(y) + [-v for v in by]
+        V.put(c_names[:len(coef)], coef)
+        _combine(V, ux, zs[:len(y)] + [u for _, u in CU], c_names[:len(coef)])
+        with np.errstate(invalid='ignore'):
+            hy = Q.dot(R.dot(y))
+        V.put(c_names[:len(hy)], list(hy))
+        _combine(V, cx, vs[:len(hy)], c_names[:len(hy)])
+        V.step(None, dots=[('cc', cx, cx)])
+        cc = abs(V.read('cc')[0])
+        with np.errstate(divide='ignore', invalid='ignore'):
+            alpha = 1.0 / np.sqrt(cc)
+        if not np.isfinite(alpha):
+            continue
+        V.step(cx, [(cx, float(alpha))])
+        V.step(ux, [(ux, float(alpha))], dots=[('gamma', cx, r)])
+        V.step(r, [(r, 1.0), (cx, ('gamma', -1.0))], dots=[('rr', r, r)])     # r -= gamma cx
+        V.step(x, [(x, 1.0), (ux, 'gamma')])                                  # x += gamma ux
+        while len(CU) >= k and CU:                       # truncate='oldest'
+            del CU[0]
+        CU.append((cx, ux))
+        del vs, zs
+    return j_outer + 1
 
 
 def bicgstab_batch(hier, var_cycle, vars_, live, precondition, callback):

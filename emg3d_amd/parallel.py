@@ -262,8 +262,8 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
                 stream.synchronize()
         return (s, f), (efield if keep_fields else None, info)
 
-    # batched: multigrid, or BiCGSTAB + multigrid (the default of `solve`); cgs / gcrotmk run on
-    # the host through SciPy, pair by pair
+    # batched: multigrid, or BiCGSTAB + multigrid (the default of `solve`); cgs / gcrotmk run
+    # pair by pair (on the device as well)
     if (batch > 1 and solve_fn is solve and
             dict(solver_opts or {}).get('sslsolver', True) in (True, False, None, 'bicgstab') and
             dict(solver_opts or {}).get('cycle', 'F') is not None):

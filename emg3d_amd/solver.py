@@ -512,21 +512,19 @@ def _coarse_correction_graphed(clv, var, new_cycmax):
 def krylov(model, sfield, efield, var, hierarchy=None):
     """Krylov subspace solver with multigrid preconditioner (emg3d/solver.py:652-784).
 
-    ``bicgstab`` (the default of ``solve``) and ``cgs`` run entirely on the device
+    ``bicgstab`` (the default of ``solve``), ``cgs`` and ``gcrotmk`` run entirely on the device
     (emg3d_amd/_krylov.py): vectors stay in HBM, their updates and inner products are the fused
     kernels of csrc/krylov.h with the recurrence scalars in device memory, the operator is
     ``emg3d_dev_apply_operator``, the preconditioner the multigrid cycle on the same hierarchy.
-    ``gcrotmk`` uses SciPy on the host, as the reference does, with device operator /
-    preconditioner applications (vectors cross PCIe per call).
+    Iterations, stopping rules and status codes are SciPy's (the reference's solvers); GCROT's
+    small dense problems (Hessenberg QR, least squares) are solved on the host with SciPy's own
+    routines.
     """
     from emg3d_amd import _krylov
     hier = hierarchy or Hierarchy(model)
-    device_solver = {'bicgstab': _krylov.bicgstab, 'cgs': _krylov.cgs}.get(var.sslsolver)
+    device_solver = {'bicgstab': _krylov.bicgstab, 'cgs': _krylov.cgs, 'gcrotmk': _krylov.gcrotmk}[var.sslsolver]
     try:
-        if device_solver is not None:
-            status = _krylov_on_device(device_solver, hier, sfield, efield, var)
-        else:
-            status = _scipy_krylov(hier, model, sfield, efield, var)
+        status = _krylov_on_device(device_solver, hier, sfield, efield, var)
     except _ConvergenceError:            # the preconditioner diverged or stagnated
         status = -1
         efield.field[:] = 0
@@ -579,42 +577,6 @@ def _krylov_on_device(method, hier, sfield, efield, var):
         else:
             out[:] = x.cpu().numpy()
     return status
-
-
-def _scipy_krylov(hier, model, sfield, efield, var):
-    """gcrotmk through SciPy on the host (emg3d/solver.py:685-768)."""
-    import scipy.sparse.linalg as ssl
-
-    top = hier.top
-    frequency = sfield._frequency
-    grid = sfield.grid
-    dt = sfield.field.dtype
-
-    def amatvec(x):
-        xt = torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).to(hier.device)
-        return top.apply_A(xt, torch.empty_like(xt)).cpu().numpy()
-
-    A = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=dt, matvec=amatvec)
-
-    def mg_matvec(b):
-        s = fields.Field(grid, np.asarray(b, dtype=dt), frequency=frequency)
-        e = fields.Field(grid, dtype=dt, frequency=frequency)
-        multigrid(model, s, e, var, hierarchy=hier)
-        return e.field
-
-    M = None
-    if var.cycle:
-        M = ssl.LinearOperator(shape=(sfield.field.size,) * 2, dtype=dt, matvec=mg_matvec)
-
-    def callback(x):
-        hier.upload(sfield, fields.Field(grid, np.asarray(x, dtype=dt)))
-        _krylov_callback(var, top.residual(store=False, norm=True))
-
-    x, i = getattr(ssl, var.sslsolver)(
-        A=A, b=sfield.field, x0=efield.field.copy(), rtol=var.tol, maxiter=var.ssl_maxit,
-        atol=1e-30, M=M, callback=callback)
-    efield.field[:] = x
-    return i
 
 
 # ----------------------------------------- host-object wrappers (reference signatures) ---
