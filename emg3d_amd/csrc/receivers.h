@@ -177,16 +177,28 @@ __global__ __launch_bounds__(256) void k_volume_average(const double *v, int nx,
     const int oy = blockIdx.y * blockDim.y + threadIdx.y;
     const int oz = blockIdx.z;
     if (ox >= mx || oy >= my) return;
+    // logscale == 2: the ADJOINT of the (linear) averaging, for the gradient's way back from a
+    // computational grid (reference maps._interp_volume_average_adj, emg3d/maps.py:722-750): the
+    // tables are the transposed ones (segments grouped by the cell of the ORIGINAL grid, which is
+    // the output here), `v` lives on the averaged grid together with ITS cell volumes `vol`, and
+    // the result is ADDED to `out`:  out_i += sum_o (overlap_io / vol_o) v_o
+    const bool adjoint = logscale == 2;
     double acc = 0.0;
     for (int a = sz[oz]; a < sz[oz + 1]; ++a)
         for (int b = sy[oy]; b < sy[oy + 1]; ++b) {
             const double w_zy = wz[a] * wy[b];
-            const double *row = v + (size_t)nx * (iny[b] + (size_t)ny * inz[a]);
-            // logscale: the average of log10(value), returned as 10 ** average (maps.py:346-358)
-            for (int c = sx[ox]; c < sx[ox + 1]; ++c) acc += w_zy * wx[c] * (logscale ? log10(row[inx[c]]) : row[inx[c]]);
+            const size_t roff = (size_t)nx * (iny[b] + (size_t)ny * inz[a]);
+            const double *row = v + roff;
+            // logscale == 1: the average of log10(value), returned as 10 ** average (maps.py:346-358)
+            if (adjoint) {
+                for (int c = sx[ox]; c < sx[ox + 1]; ++c) acc += w_zy * wx[c] * (row[inx[c]] / vol[roff + inx[c]]);
+            } else {
+                for (int c = sx[ox]; c < sx[ox + 1]; ++c) acc += w_zy * wx[c] * (logscale ? log10(row[inx[c]]) : row[inx[c]]);
+            }
         }
     const size_t o = (size_t)ox + (size_t)mx * (oy + (size_t)my * oz);
-    out[o] = logscale ? pow(10.0, acc / vol[o]) : acc / vol[o];
+    if (adjoint) out[o] += acc;
+    else out[o] = logscale ? pow(10.0, acc / vol[o]) : acc / vol[o];
 }
 
 }  // namespace

@@ -19,8 +19,12 @@ forward solves of ``parallel.compute``:
       7. all-reduce of the cell gradient and of the misfit over the ranks (RCCL)
       8. anisotropy bookkeeping and the derivative chain of the property mapping (host, one pass)
 
-Limits as in the reference: electric point receivers, no epsilon_r / mu_r; and, here, the
-computational grid must be the model grid (the reference maps back with discretize).
+Computational grids that differ from the model grid (``grids=``): the model goes to the pair's grid
+by volume averaging (``Model.interpolate_to_grid``), the cell gradient comes back through the
+adjoint of the linear averaging (``models._VolumeAverage.adjoint_add``; the reference takes that
+operator from discretize, ``maps._interp_volume_average_adj``, emg3d/maps.py:722-750).
+
+Limits as in the reference: no epsilon_r / mu_r; here, electric point receivers only.
 """
 import numpy as np
 
@@ -70,7 +74,7 @@ def _receiver_tuple(receivers):
 
 
 def misfit_and_gradient(model, sources, frequencies, receivers, observed, weights=None, solver_opts=None,
-                        tol_gradient=1e-5, costs=None):
+                        tol_gradient=1e-5, costs=None, grids=None, interpolate_opts=None):
     """Misfit ``sum w |synthetic - observed|^2 / 2`` and its adjoint-state gradient with respect to
     the model properties (shape (nx, ny, nz) for isotropic models, (2, ...) HTI / VTI, (3, ...)
     tri-axial, as ``Simulation.gradient``).
@@ -78,6 +82,11 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
     sources: dict name -> source coordinates; frequencies: dict name -> Hz; receivers: sequence of
     (x, y, z, azimuth, elevation) electric point receivers; observed / weights: dict
     (source name, frequency name) -> one value per receiver (NaN: no data; weights default 1).
+    grids: the computational grid of the pairs, if it is not the model's: one TensorMesh for all, or
+    a dict (source name, frequency name) -> TensorMesh (pairs that are missing use the model grid);
+    interpolate_opts: passed to ``Model.interpolate_to_grid`` (default: averaging on a log10 scale, as
+    in the reference -- the way back is the adjoint of the LINEAR averaging either way, exact for
+    ``{'log': False}`` with a conductivity model).
     With an initialised process group the pairs are sharded over the ranks and both results are
     all-reduced: every rank returns the complete misfit and gradient."""
     import torch
@@ -87,7 +96,7 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
     for name, prop in (('el. permittivity', model.epsilon_r), ('magn. permeability', model.mu_r)):
         if prop is not None and not np.allclose(prop, 1.0):
             raise NotImplementedError(f"Gradient not implemented for {name}.")
-    grid = model.grid
+    mgrid = model.grid
     opts = dict(solver_opts or {})
     opts.setdefault('sslsolver', True)
     rec = _receiver_tuple(receivers)
@@ -95,23 +104,37 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
     rank, world = parallel.rank_and_world()
     mine = parallel.shard(len(pairs), rank, world, costs)
     dev = torch.device('cuda', torch.cuda.current_device())
-    nx, ny, nz = grid.shape_cells
-    ncell = grid.n_cells
+    ncell = mgrid.n_cells
     grad = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
-    vol = torch.from_numpy(np.ascontiguousarray(grid.cell_volumes, dtype=np.float64)).to(dev)
     misfit = 0.0
     hierarchies = {}
+    on_grid = {}                 # per computational grid: (grid, model on it, cell volumes, averaging plan)
     info = {}
+
+    def computational(pair):
+        g = grids.get(pair) if isinstance(grids, dict) else grids
+        if g is None or g == mgrid:
+            g = mgrid
+        key = id(g) if g is not mgrid else 0
+        if key not in on_grid:
+            vol = torch.from_numpy(np.ascontiguousarray(g.cell_volumes, dtype=np.float64)).to(dev)
+            plan = None if g is mgrid else models._VolumeAverage(mgrid, g)
+            on_grid[key] = (g, model.interpolate_to_grid(g, **(interpolate_opts or {})), vol, plan)
+        return (key,) + on_grid[key]
+
     for i in mine:
         sname, fname = pairs[i]
         freq = frequencies[fname]
+        gkey, grid, gmodel, vol, plan = computational((sname, fname))
+        nx, ny, nz = grid.shape_cells
         sfield = fields.get_source_field(grid, sources[sname], freq)
-        hier = hierarchies.get(complex(sfield.sval))
+        hkey = (complex(sfield.sval), gkey)
+        hier = hierarchies.get(hkey)
         if hier is None:
-            hierarchies.clear()                       # one frequency at a time in HBM
-            hier = hierarchies[complex(sfield.sval)] = solver.Hierarchy(models.VolumeModel(model, sfield))
+            hierarchies.clear()                       # one (frequency, grid) at a time in HBM
+            hier = hierarchies[hkey] = solver.Hierarchy(models.VolumeModel(gmodel, sfield))
         top = hier.top
-        _, finfo = solver.solve(model, sfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
+        _, finfo = solver.solve(gmodel, sfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
                                 _sparse_source=True, **opts)
         e_fwd = torch.empty_like(top.e)
         _lib.check(_lib.lib().emg3d_dev_copy(_ptr(e_fwd), _ptr(top.e), top.e.numel() * top.e.element_size(), _stream()),
@@ -124,14 +147,23 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
         have = ~np.isnan(residual)
         misfit += float(np.sum(w[have] * (residual[have].conj() * residual[have])).real) / 2
         rfield = residual_source_field(grid, freq, receivers, residual, w)
-        _, binfo = solver.solve(model, rfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
+        _, binfo = solver.solve(gmodel, rfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
                                 _sparse_source=True, **{**opts, 'tol': tol_gradient})
         smu0 = complex(sfield.smu0)
         o1, o2 = grid.n_edges_x, grid.n_edges_x + grid.n_edges_y
+        if plan is None:
+            gtarget, nc = grad, ncell
+        else:                                          # cell gradient on the computational grid first
+            nc = grid.n_cells
+            gtarget = torch.empty(3 * nc, dtype=torch.float64, device=dev)
+            _lib.check(_lib.lib().emg3d_dev_zero(_ptr(gtarget), gtarget.numel() * 8, _stream()), 'emg3d_dev_zero')
         _lib.check(_lib.lib().emg3d_dev_gradient_accumulate(
             nx, ny, nz, int(top.is_complex), _ptr(e_fwd), _ptr(e_fwd, o1), _ptr(e_fwd, o2),
             _ptr(top.e), _ptr(top.e, o1), _ptr(top.e, o2), smu0.real, smu0.imag, _ptr(vol),
-            _ptr(grad), _ptr(grad, ncell), _ptr(grad, 2 * ncell), _stream()), 'emg3d_dev_gradient_accumulate')
+            _ptr(gtarget), _ptr(gtarget, nc), _ptr(gtarget, 2 * nc), _stream()), 'emg3d_dev_gradient_accumulate')
+        if plan is not None:                           # ... and back to the model grid: grad += P^T g
+            for k in range(3):
+                plan.adjoint_add(gtarget[k * nc:(k + 1) * nc], grad[k * ncell:(k + 1) * ncell])
         info[(sname, fname)] = {'forward': finfo, 'backward': binfo, 'synthetic': synthetic}
     # the one collective of the path: sum over the ranks
     tm = torch.tensor([misfit], dtype=torch.float64, device=dev)
@@ -143,7 +175,7 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
         dist.all_reduce(m)
         grad, tm = g, m
     misfit = float(tm.cpu()[0])
-    g3 = np.stack([grad[k * ncell:(k + 1) * ncell].cpu().numpy().reshape((nx, ny, nz), order='F') for k in range(3)])
+    g3 = np.stack([grad[k * ncell:(k + 1) * ncell].cpu().numpy().reshape(mgrid.shape_cells, order='F') for k in range(3)])
 
     # anisotropy bookkeeping + derivative chain of the mapping (simulations.py:1070-1090)
     chain = _DCHAIN[model.mapping]

@@ -148,6 +148,31 @@ class _VolumeAverage:
             'emg3d_dev_volume_average')
         return out.cpu().numpy().reshape(self.shape_out, order='F')
 
+    def adjoint_add(self, nval, oval):
+        """oval += P^T nval for device arrays: ``nval`` on the new grid (cells, F-order), ``oval`` on
+        the original grid -- P the linear averaging this plan applies (``log=False``). The gradient's
+        way back from a computational grid to the model grid (reference
+        ``maps._interp_volume_average_adj``, emg3d/maps.py:722-750, which takes the operator from
+        discretize; here it is the transpose of the plan's own tables: the same kernel walks the
+        segments grouped by ORIGINAL cell)."""
+        from emg3d_amd import _lib
+        from emg3d_amd._device import _ptr, _stream
+        if not hasattr(self, 'tabs_t'):
+            import torch
+            self.tabs_t = []
+            for (seg, w, cell_in), n_in in zip(self.tabs, self.shape_in):
+                seg, w, cell_in = seg.cpu().numpy(), w.cpu().numpy(), cell_in.cpu().numpy()
+                cell_out = np.repeat(np.arange(seg.size - 1, dtype=np.int32), np.diff(seg))
+                order = np.argsort(cell_in, kind='stable')
+                seg_t = np.searchsorted(cell_in[order], np.arange(n_in + 1), side='left').astype(np.int32)
+                self.tabs_t.append([torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+                                    for a in (seg_t, w[order], cell_out[order])])
+        (sx, wx, ix), (sy, wy, iy), (sz, wz, iz) = self.tabs_t
+        _lib.check(_lib.lib().emg3d_dev_volume_average(
+            _ptr(nval), *self.shape_out, _ptr(sx), _ptr(sy), _ptr(sz), _ptr(wx), _ptr(wy), _ptr(wz),
+            _ptr(ix), _ptr(iy), _ptr(iz), _ptr(self.vol), *self.shape_in, _ptr(oval), 2, _stream()),
+            'emg3d_dev_volume_average')
+
 
 class VolumeModel:
     """Volume-integrated eta_{x,y,z} and zeta for one frequency (taken from `sfield`);

@@ -296,7 +296,12 @@ int emg3d_dev_gradient_accumulate(int nx, int ny, int nz, int is_complex, const 
  * the host supplies maps._volume_average_weights (maps.py:619-664) grouped by output cell:
  * seg* (m+1 offsets), w* (segment lengths), in* (input cell of each segment); new_vol = output
  * cell volumes. Same additions in the same order as the reference: bit-identical. log10_scale = 1:
- * the values are averaged on a log10 scale (maps.interpolate(log=True), emg3d/maps.py:346-358). */
+ * the values are averaged on a log10 scale (maps.interpolate(log=True), emg3d/maps.py:346-358).
+ * log10_scale = 2: the ADJOINT of the linear averaging (maps._interp_volume_average_adj,
+ * emg3d/maps.py:722-750 -- the gradient's way back from a computational grid): the tables are the
+ * transposed ones (grouped by ORIGINAL cell = output cell of this call), `values` and `new_vol`
+ * both live on the averaged grid (nx,ny,nz), and out (mx,my,mz) is ACCUMULATED:
+ * out_i += sum_o overlap_io / new_vol_o * values_o. */
 int emg3d_dev_volume_average(const double *values, int nx, int ny, int nz, const int32_t *segx,
                              const int32_t *segy, const int32_t *segz, const double *wx,
                              const double *wy, const double *wz, const int32_t *inx,
