@@ -371,10 +371,9 @@ class DeviceLevel:
         link = self.child(sc_dir)
         c = link['level']
         nx, ny, nz = self.grid.shape_cells
-        _lib.check(_lib.lib().emg3d_dev_restrict_batch(
-            *c.parts(c.s), *self.parts(self.r), *link['wptr'], nx, ny, nz, sc_dir,
+        _lib.check(_lib.lib().emg3d_dev_restrict_clear_batch(
+            *c.parts(c.s), *c.parts(c.e), *self.parts(self.r), *link['wptr'], nx, ny, nz, sc_dir,
             self.is_complex, self.batch, self.grid.n_edges, c.grid.n_edges, _stream()), 'emg3d_dev_restrict')
-        c.zero_field()
         return c
 
     def prolong_from(self, sc_dir):

@@ -75,6 +75,7 @@ SIGNATURES = {
     'emg3d_dev_restrict': (_ci, [_vp] * 15 + [_ci] * 5 + [_vp]),
     'emg3d_dev_prolong': (_ci, [_vp] * 12 + [_ci] * 5 + [_vp]),
     'emg3d_dev_restrict_batch': (_ci, [_vp] * 15 + [_ci] * 6 + [_sz, _sz, _vp]),
+    'emg3d_dev_restrict_clear_batch': (_ci, [_vp] * 18 + [_ci] * 6 + [_sz, _sz, _vp]),
     'emg3d_dev_prolong_batch': (_ci, [_vp] * 12 + [_ci] * 6 + [_sz, _sz, _vp]),
     'emg3d_dev_restrict_param': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'emg3d_dev_pec_zero': (_ci, [_vp] * 3 + [_ci] * 4 + [_vp]),

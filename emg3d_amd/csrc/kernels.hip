@@ -969,6 +969,7 @@ template <class T> __global__ __launch_bounds__(256) void k_restrict(emg::Restri
     if (cix >= R.cnxn || ciy >= R.cnyn) return;
     R.rx += b * R.fstride; R.ry += b * R.fstride; R.rz += b * R.fstride;
     R.crx += b * R.cstride; R.cry += b * R.cstride; R.crz += b * R.cstride;
+    if (R.cex) { R.cex += b * R.cstride; R.cey += b * R.cstride; R.cez += b * R.cstride; }
     emg::restrict_node<T>(R, cix, ciy, ciz);
 }
 
@@ -1258,13 +1259,14 @@ int launch_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double 
 template <class T>
 int launch_restrict(void *crx, void *cry, void *crz, const void *rx, const void *ry, const void *rz,
                     const double *const w[9], int nx, int ny, int nz, int sc_dir, hipStream_t st, int batch = 1,
-                    size_t fstride = 0, size_t cstride = 0)
+                    size_t fstride = 0, size_t cstride = 0, void *cex = nullptr, void *cey = nullptr, void *cez = nullptr)
 {
     const ScDirs f = sc_flags(sc_dir);
     if ((f.cx && nx % 2) || (f.cy && ny % 2) || (f.cz && nz % 2))
         return fail(EMG3D_ERR_BADARG, "restrict: odd cell count in a coarsened direction");
     emg::Restrict<T> R = emg::make_restrict<T>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir);
     R.batch = batch > 1 ? batch : 1; R.fstride = fstride; R.cstride = cstride;
+    R.cex = (T *)cex; R.cey = (T *)cey; R.cez = (T *)cez;
     const emg::Dim3 g = emg::cell_grid(R.cnxn, R.cnyn, R.cnzn);
     hipLaunchKernelGGL(k_restrict<T>, dim3(g.x, g.y, g.z * R.batch), d3(emg::cell_block()), 0, st, R);
     HIP_TRY(hipGetLastError());
@@ -1568,6 +1570,22 @@ int emg3d_dev_restrict_batch(void *crx, void *cry, void *crz, const void *rx, co
                                               fine_stride, coarse_stride)
                       : launch_restrict<double>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir, (hipStream_t)stream,
                                                 batch, fine_stride, coarse_stride);
+}
+
+int emg3d_dev_restrict_clear_batch(void *crx, void *cry, void *crz, void *cex, void *cey, void *cez, const void *rx,
+                                   const void *ry, const void *rz, const double *wxl, const double *wx0,
+                                   const double *wxr, const double *wyl, const double *wy0, const double *wyr,
+                                   const double *wzl, const double *wz0, const double *wzr, int nx, int ny, int nz,
+                                   int sc_dir, int is_complex, int batch, size_t fine_stride, size_t coarse_stride,
+                                   void *stream)
+{
+    if (sc_dir < 0 || sc_dir > 6) return fail(EMG3D_ERR_BADARG, "restrict: sc_dir must be 0..6");
+    if (!cex || !cey || !cez) return fail(EMG3D_ERR_BADARG, "restrict_clear: coarse field missing");
+    const double *const w[9] = {wxl, wx0, wxr, wyl, wy0, wyr, wzl, wz0, wzr};
+    return is_complex ? launch_restrict<cplx>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir, (hipStream_t)stream, batch,
+                                              fine_stride, coarse_stride, cex, cey, cez)
+                      : launch_restrict<double>(crx, cry, crz, rx, ry, rz, w, nx, ny, nz, sc_dir, (hipStream_t)stream,
+                                                batch, fine_stride, coarse_stride, cex, cey, cez);
 }
 
 int emg3d_dev_prolong_batch(void *ex, void *ey, void *ez, const void *cex, const void *cey, const void *cez,

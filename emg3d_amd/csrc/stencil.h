@@ -1272,6 +1272,7 @@ template <class T> struct Restrict {
     int cnxn, cnyn, cnzn;        // COARSE node counts
     const T *rx, *ry, *rz;       // fine residual
     T *crx, *cry, *crz;          // coarse source
+    T *cex = nullptr, *cey = nullptr, *cez = nullptr;   // optional: coarse FIELD, set to zero (solver.py:941)
     const double *wx[3], *wy[3], *wz[3];
     int batch = 1;               // right-hand sides (Level::batch); strides in elements
     size_t fstride = 0, cstride = 0;
@@ -1304,6 +1305,7 @@ template <class T> EMG_HD void restrict_node(const Restrict<T> &R, int cix, int 
             acc += wys[a] * inner;
         }
         R.crx[cix + (cnx - 1) * (ciy + cny * ciz)] = acc;
+        if (R.cex) R.cex[cix + (cnx - 1) * (ciy + cny * ciz)] = zero<T>();
     }
     if (ciy < cny - 1) {   // y-edges: fine shape (nx, ny-1, nz)
         T acc = zero<T>();
@@ -1317,6 +1319,7 @@ template <class T> EMG_HD void restrict_node(const Restrict<T> &R, int cix, int 
             acc += wxs[a] * inner;
         }
         R.cry[cix + cnx * (ciy + (cny - 1) * ciz)] = acc;
+        if (R.cey) R.cey[cix + cnx * (ciy + (cny - 1) * ciz)] = zero<T>();
     }
     if (ciz < R.cnzn - 1) {   // z-edges: fine shape (nx, ny, nz-1)
         T acc = zero<T>();
@@ -1330,6 +1333,7 @@ template <class T> EMG_HD void restrict_node(const Restrict<T> &R, int cix, int 
             acc += wxs[a] * inner;
         }
         R.crz[cix + cnx * (ciy + cny * ciz)] = acc;
+        if (R.cez) R.cez[cix + cnx * (ciy + cny * ciz)] = zero<T>();
     }
 }
 

@@ -211,6 +211,15 @@ int emg3d_dev_restrict_batch(void *crx, void *cry, void *crz, const void *rx, co
                              const double *wz0, const double *wzr, int nx, int ny, int nz, int sc_dir,
                              int is_complex, int batch, size_t fine_stride, size_t coarse_stride,
                              void *stream);
+/* the same restriction that also sets the coarse FIELD ce* to zero -- the start value of the coarse
+ * solve (emg3d/solver.py:941) -- in the same pass over the coarse edges (no separate fill launch) */
+int emg3d_dev_restrict_clear_batch(void *crx, void *cry, void *crz, void *cex, void *cey, void *cez,
+                                   const void *rx, const void *ry, const void *rz, const double *wxl,
+                                   const double *wx0, const double *wxr, const double *wyl,
+                                   const double *wy0, const double *wyr, const double *wzl,
+                                   const double *wz0, const double *wzr, int nx, int ny, int nz,
+                                   int sc_dir, int is_complex, int batch, size_t fine_stride,
+                                   size_t coarse_stride, void *stream);
 int emg3d_dev_prolong_batch(void *ex, void *ey, void *ez, const void *cex, const void *cey,
                             const void *cez, const int32_t *ilx, const int32_t *ily, const int32_t *ilz,
                             const double *wx, const double *wy, const double *wz, int nx, int ny, int nz,
