@@ -268,6 +268,82 @@ def get_point_source_field(grid, coordinates, frequency, strength=1.0):
     return sfield
 
 
+def get_magnetic_point_source_field(grid, coordinates, frequency, strength=1.0):
+    """Source field of a magnetic POINT dipole ``(x, y, z, azimuth, elevation)`` -- the adjoint source
+    of a magnetic point receiver (reference ``_point_vector_magnetic``, emg3d/fields.py:749-789, behind
+    ``TxMagneticPoint``, emg3d/electrodes.py:715): the transpose of "magnetic field from the electric
+    field, interpolated linearly to the point", i.e. of ``get_receiver(get_magnetic_field(model, e),
+    ..., 'linear')`` as a linear map of e. The reference builds it from discretize's face
+    interpolation and edge curl; here it is the transpose of this package's own operators
+    (``emg3d_dev_magnetic_field`` = the reference's ``_edge_curl_factor``, fields.py:941-1009, and the
+    linear receiver interpolation), entry by entry -- mu_r = 1, as the reference requires for it."""
+    c = np.asarray(coordinates, dtype=float)
+    if frequency is None:
+        raise ValueError("The magnetic point source needs a frequency.")
+    sfield = Field(grid, frequency=frequency)
+    hshapes = Field(grid, frequency=frequency, electric=False)._shapes
+    direction = _rotation(c[3], c[4])
+    nx, ny, nz = grid.shape_cells
+    hx, hy, hz = grid.h
+    vol = grid.cell_volumes.reshape(grid.shape_cells, order='F')
+    n_ex, n_ey = sfield._sizes[0], sfield._sizes[1]
+    ex = lambda i, j, k: i + nx * (j + (ny + 1) * k)                           # noqa: E731
+    ey = lambda i, j, k: n_ex + i + (nx + 1) * (j + ny * k)                    # noqa: E731
+    ez = lambda i, j, k: n_ex + n_ey + i + (nx + 1) * (j + (ny + 1) * k)       # noqa: E731
+    acc = {}
+
+    def add(index, value):
+        acc[index] = acc.get(index, 0.0) + value
+
+    for comp in range(3):
+        if abs(direction[comp]) <= 1e-10:
+            continue
+        pts = _component_points(grid, hshapes[comp])
+        corner = []
+        for d in range(3):                  # the linear receiver interpolation (get_receiver)
+            g = pts[d]
+            if not g[0] <= c[d] <= g[-1]:
+                corner = None
+                break
+            i = min(max(int(np.searchsorted(g, c[d])) - 1, 0), g.size - 2)
+            w = (c[d] - g[i]) / (g[i + 1] - g[i])
+            corner.append(((i, 1.0 - w), (i + 1, w)))
+        if corner is None:
+            continue
+        for k, wk in corner[2]:
+            for j, wj in corner[1]:
+                for i, wi in corner[0]:
+                    wf = wi * wj * wk * direction[comp]
+                    if wf == 0.0:
+                        continue
+                    # face (comp; i, j, k) as _edge_curl_factor forms it; faces it leaves at zero: skipped
+                    if comp == 0:
+                        if i == 0 or i >= nx:
+                            continue
+                        cf = wf * (vol[i - 1, j, k] + vol[i, j, k]) / ((hx[i - 1] + hx[i]) * hy[j] * hz[k])
+                        add(ez(i, j + 1, k), cf / hy[j]); add(ez(i, j, k), -cf / hy[j])
+                        add(ey(i, j, k + 1), -cf / hz[k]); add(ey(i, j, k), cf / hz[k])
+                    elif comp == 1:
+                        if j == 0 or j >= ny:
+                            continue
+                        cf = wf * (vol[i, j - 1, k] + vol[i, j, k]) / (hx[i] * (hy[j - 1] + hy[j]) * hz[k])
+                        add(ex(i, j, k + 1), cf / hz[k]); add(ex(i, j, k), -cf / hz[k])
+                        add(ez(i + 1, j, k), -cf / hx[i]); add(ez(i, j, k), cf / hx[i])
+                    else:
+                        if k == 0 or k >= nz:
+                            continue
+                        cf = wf * (vol[i, j, k - 1] + vol[i, j, k]) / (hx[i] * hy[j] * (hz[k - 1] + hz[k]))
+                        add(ey(i + 1, j, k), cf / hx[i]); add(ey(i, j, k), -cf / hx[i])
+                        add(ex(i, j + 1, k), -cf / hy[j]); add(ex(i, j, k), cf / hy[j])
+    index = np.array(sorted(acc), dtype=np.int64)
+    # H = curl E * zeta / (s mu0): the 1 / (s mu0) of the operator, then strength * (-s mu0) as for every source
+    values = np.array([acc[i] for i in index], dtype=complex) / sfield.smu0 * strength * -sfield.smu0
+    values = values.astype(sfield._field.dtype)
+    sfield._field[index] = values
+    sfield._sparse = (index, values)
+    return sfield
+
+
 def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs):
     """Source field ``-s mu_0 J_s`` of an electric dipole or wire.
 

@@ -24,7 +24,11 @@ by volume averaging (``Model.interpolate_to_grid``), the cell gradient comes bac
 adjoint of the linear averaging (``models._VolumeAverage.adjoint_add``; the reference takes that
 operator from discretize, ``maps._interp_volume_average_adj``, emg3d/maps.py:722-750).
 
-Limits as in the reference: no epsilon_r / mu_r; here, electric point receivers only.
+Magnetic point receivers (``magnetic=``): responses = ``get_magnetic_field`` interpolated linearly to the
+point, adjoint source = the transpose of exactly that map (``fields.get_magnetic_point_source_field``;
+the reference builds its ``_point_vector_magnetic`` from discretize's operators, emg3d/fields.py:749-789).
+
+Limits as in the reference: no epsilon_r / mu_r.
 """
 import numpy as np
 
@@ -43,19 +47,22 @@ _DCHAIN = {          # d sigma / d property, applied to the gradient w.r.t. cond
 }
 
 
-def residual_source_field(grid, frequency, receivers, residual, weight):
+def residual_source_field(grid, frequency, receivers, residual, weight, magnetic=None):
     """Source field of the back-propagation (``Simulation._get_rfield``, simulations.py:1235-1268):
     every receiver with data acts as a point dipole of strength ``conj(residual weight / (-s mu0))``
-    (``TxElectricPoint``: the adjoint of the tri-linear receiver interpolation).
+    -- an electric one (``TxElectricPoint``: the adjoint of the tri-linear receiver interpolation) or,
+    for the receivers flagged in ``magnetic``, a magnetic one (``TxMagneticPoint``).
     ``receivers``: sequence of (x, y, z, azimuth, elevation); ``residual`` / ``weight``: one value per
     receiver (NaN residual: no data)."""
     rfield = Field(grid, frequency=frequency)
     strength = np.conj(np.asarray(residual) * np.asarray(weight) / -rfield.smu0)
+    magnetic = np.zeros(len(strength), dtype=bool) if magnetic is None else np.asarray(magnetic, dtype=bool)
     index, value = [], []
-    for rec, res, st in zip(receivers, np.asarray(residual), strength):
+    for rec, res, st, mag in zip(receivers, np.asarray(residual), strength, magnetic):
         if np.isnan(res):
             continue
-        part = fields.get_point_source_field(grid, tuple(rec), frequency, strength=st)
+        make = fields.get_magnetic_point_source_field if mag else fields.get_point_source_field
+        part = make(grid, tuple(rec), frequency, strength=st)
         index.append(part._sparse[0])
         value.append(part._sparse[1])
     if index:
@@ -74,13 +81,14 @@ def _receiver_tuple(receivers):
 
 
 def misfit_and_gradient(model, sources, frequencies, receivers, observed, weights=None, solver_opts=None,
-                        tol_gradient=1e-5, costs=None, grids=None, interpolate_opts=None):
+                        tol_gradient=1e-5, costs=None, grids=None, interpolate_opts=None, magnetic=None):
     """Misfit ``sum w |synthetic - observed|^2 / 2`` and its adjoint-state gradient with respect to
     the model properties (shape (nx, ny, nz) for isotropic models, (2, ...) HTI / VTI, (3, ...)
     tri-axial, as ``Simulation.gradient``).
 
     sources: dict name -> source coordinates; frequencies: dict name -> Hz; receivers: sequence of
-    (x, y, z, azimuth, elevation) electric point receivers; observed / weights: dict
+    (x, y, z, azimuth, elevation) point receivers -- electric ones, or magnetic ones where the boolean
+    sequence ``magnetic`` says so (responses in A/m: ``get_magnetic_field`` at the point); observed / weights: dict
     (source name, frequency name) -> one value per receiver (NaN: no data; weights default 1).
     grids: the computational grid of the pairs, if it is not the model's: one TensorMesh for all, or
     a dict (source name, frequency name) -> TensorMesh (pairs that are missing use the model grid);
@@ -100,6 +108,7 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
     opts = dict(solver_opts or {})
     opts.setdefault('sslsolver', True)
     rec = _receiver_tuple(receivers)
+    mag = np.zeros(len(rec[0]), dtype=bool) if magnetic is None else np.asarray(magnetic, dtype=bool)
     pairs = parallel.srcfreq_pairs(sources, frequencies)
     rank, world = parallel.rank_and_world()
     mine = parallel.shard(len(pairs), rank, world, costs)
@@ -141,12 +150,26 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
                    'emg3d_dev_copy')
         meta = Field(grid, frequency=freq)
         synthetic = fields.get_receiver(meta, rec, 'linear', device_field=e_fwd)
+        if mag.any():                                  # H on the faces from the field in HBM, then the same interpolation
+            hmeta = Field(grid, frequency=freq, electric=False)
+            hdev = torch.empty(hmeta.field.size, dtype=e_fwd.dtype, device=dev)
+            hh = [torch.from_numpy(np.ascontiguousarray(h)).to(dev) for h in grid.h]
+            eo, mo = np.cumsum([0] + list(meta._sizes)), np.cumsum([0] + list(hmeta._sizes))
+            s0 = complex(meta.smu0)
+            _lib.check(_lib.lib().emg3d_dev_magnetic_field(
+                nx, ny, nz, int(e_fwd.is_complex()), _ptr(e_fwd, int(eo[0])), _ptr(e_fwd, int(eo[1])),
+                _ptr(e_fwd, int(eo[2])), _ptr(vol), _ptr(hh[0]), _ptr(hh[1]), _ptr(hh[2]), s0.real, s0.imag,
+                _ptr(hdev, int(mo[0])), _ptr(hdev, int(mo[1])), _ptr(hdev, int(mo[2])), _stream()),
+                'emg3d_dev_magnetic_field')
+            rmag = tuple(r[mag] for r in rec)
+            synthetic = np.array(synthetic)
+            synthetic[mag] = fields.get_receiver(hmeta, rmag, 'linear', device_field=hdev)
         obs = np.asarray(observed[(sname, fname)])
         w = np.ones(obs.shape) if weights is None else np.asarray(weights[(sname, fname)], dtype=float)
         residual = synthetic - obs
         have = ~np.isnan(residual)
         misfit += float(np.sum(w[have] * (residual[have].conj() * residual[have])).real) / 2
-        rfield = residual_source_field(grid, freq, receivers, residual, w)
+        rfield = residual_source_field(grid, freq, receivers, residual, w, mag)
         _, binfo = solver.solve(gmodel, rfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
                                 _sparse_source=True, **{**opts, 'tol': tol_gradient})
         smu0 = complex(sfield.smu0)

@@ -1498,6 +1498,90 @@ def test_adjoint_gradient_on_a_computational_grid_vs_finite_differences():
     assert m1 == m2 and np.array_equal(g1, g2)
 
 
+def test_magnetic_point_source_is_the_transpose_of_the_magnetic_receiver():
+    """`fields.get_magnetic_point_source_field` (adjoint source of a magnetic point receiver, reference
+    `_point_vector_magnetic`) is, entry by entry, the transpose of "H from E (`get_magnetic_field`, pinned to
+    the reference's vectors), interpolated linearly to the point": <vector, e> equals the response for
+    random fields, arbitrary orientations, points in stretched cells."""
+    rng = np.random.default_rng(21)
+    hx, hy, hz = widths(4, 3, 40., 1.3), widths(4, 2, 50., 1.25), widths(4, 3, 30., 1.4)
+    grid = emg3d.TensorMesh([hx, hy, hz], (-hx.sum() / 2, -hy.sum() / 2, -hz.sum() / 2))
+    model = emg3d.Model(grid, property_x=np.ones(grid.shape_cells))
+    e = emg3d.Field(grid, frequency=0.8)
+    e.field[:] = rng.standard_normal(e.field.size) + 1j * rng.standard_normal(e.field.size)
+    h = emg3d.get_magnetic_field(model, e)
+    recs = [(12.3, -7.1, 5.5, 0., 0.), (-40.2, 33.3, -20.1, 90., 0.), (3.3, 4.4, 18.8, 0., 90.),
+            (-61.7, -48.2, 44.1, 37., -21.), (55.5, 12.1, -39.9, -120., 63.)]
+    for rec in recs:
+        resp = emg3d.fields.get_receiver(h, tuple(np.array([c]) for c in rec), 'linear')[0]
+        src = emg3d.fields.get_magnetic_point_source_field(grid, rec, 0.8, strength=1.0)
+        idx, val = src._sparse
+        assert idx.size > 0 and np.array_equal(src.field[idx], val)
+        got = np.sum(val / -src.smu0 * e.field[idx])
+        assert abs(got - resp) < 1e-12 * abs(resp), (rec, got, resp)
+
+
+def test_adjoint_gradient_with_magnetic_receivers_vs_finite_differences():
+    """`misfit_and_gradient(magnetic=...)`: electric and magnetic point receivers in one data set;
+    central differences of the misfit on the cells with the largest gradient agree to 1.5 %."""
+    from emg3d_amd import gradient
+    rng = np.random.default_rng(9)
+    hx, hz = widths(4, 3, 50., 1.3), widths(4, 2, 40., 1.3)
+    grid = emg3d.TensorMesh([hx, hx, hz], (-hx.sum() / 2, -hx.sum() / 2, -hz[:4].sum()))
+    shape = grid.shape_cells
+    rho = 10 ** rng.uniform(-0.2, 0.5, shape)
+    srcs = {'a': (-60., 0., -30., 0., 0.), 'b': (40., 30., -30., 90., 0.)}
+    freqs = {'f': 1.0}
+    recs = np.array([[70., 10., -40., 0., 0.], [-30., -60., -40., 90., 0.], [10., 80., -25., 45., 0.],
+                     [-75., 20., -35., 30., 20.]])
+    mag = np.array([False, True, True, False])
+    opts = dict(tol=1e-10, sslsolver=True)
+    true = emg3d.Model(grid, property_x=rho * 1.4)
+    obs = {}
+    rt = tuple(recs[:, k] for k in range(5))
+    for s in srcs:
+        ef = emg3d.solve(true, emg3d.get_source_field(grid, srcs[s], 1.0), **opts)
+        d = np.array(emg3d.fields.get_receiver(ef, rt, 'linear'))
+        d[mag] = emg3d.fields.get_receiver(emg3d.get_magnetic_field(true, ef), tuple(r[mag] for r in rt), 'linear')
+        obs[(s, 'f')] = d
+    wts = {k: 1.0 / (0.05 * np.abs(v)) ** 2 for k, v in obs.items()}
+
+    def phi(r):
+        return gradient.misfit_and_gradient(emg3d.Model(grid, property_x=r), srcs, freqs, recs, obs, wts,
+                                            solver_opts=opts, tol_gradient=1e-10, magnetic=mag)
+    m0, g0, info = phi(rho)
+    assert g0.shape == shape and m0 > 0
+
+    def subset(sel, magnetic):
+        return gradient.misfit_and_gradient(emg3d.Model(grid, property_x=rho), srcs, freqs, recs[sel],
+                                            {k: v[sel] for k, v in obs.items()}, {k: v[sel] for k, v in wts.items()},
+                                            solver_opts=opts, tol_gradient=1e-10, magnetic=magnetic)
+    # misfit and gradient are sums over the data: electric subset + magnetic subset = the mixed set
+    me, ge, _ = subset(~mag, None)
+    mm, gm, _ = subset(mag, np.ones(mag.sum(), dtype=bool))
+    assert mm > 0 and me > 0 and abs(me + mm - m0) < 1e-9 * m0
+    assert relerr(ge + gm, g0) < 1e-6
+    # finite differences on the MAGNETIC part (the electric one has its own test)
+    phi = lambda r: gradient.misfit_and_gradient(                                   # noqa: E731
+        emg3d.Model(grid, property_x=r), srcs, freqs, recs[mag], {k: v[mag] for k, v in obs.items()},
+        {k: v[mag] for k, v in wts.items()}, solver_opts=opts, tol_gradient=1e-10, magnetic=np.ones(mag.sum(), dtype=bool))
+    g0 = gm
+    cand = np.abs(g0).copy()
+    cand[:2], cand[-2:], cand[:, :2], cand[:, -2:], cand[:, :, :2], cand[:, :, -2:] = 0, 0, 0, 0, 0, 0
+    for s in srcs.values():
+        i, j, k = (int(np.searchsorted(n, c)) - 1 for n, c in zip((grid.nodes_x, grid.nodes_y, grid.nodes_z), s[:3]))
+        cand[max(i - 1, 0):i + 2, max(j - 1, 0):j + 2, max(k - 1, 0):k + 2] = 0
+    order = np.argsort(cand.ravel())[::-1][:3]
+    for cell in (np.unravel_index(o, shape) for o in order):
+        d = 1e-4 * rho[cell]
+        rp, rm = rho.copy(), rho.copy()
+        rp[cell] += d
+        rm[cell] -= d
+        fd = (phi(rp)[0] - phi(rm)[0]) / (2 * d)
+        nrmsd = 200 * abs(g0[cell] - fd) / (abs(g0[cell]) + abs(fd))
+        assert nrmsd < 1.5, (cell, fd, g0[cell])
+
+
 @pytest.mark.parametrize('freq', [1.3, -2.0])
 def test_source_field_on_the_device_vs_host(freq):
     """the source vector of dipoles, finite dipoles and wires assembled by
