@@ -345,10 +345,11 @@ def get_magnetic_point_source_field(grid, coordinates, frequency, strength=1.0):
 
 
 def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs):
-    """Source field ``-s mu_0 J_s`` of an electric dipole or wire.
+    """Source field ``-s mu_0 J_s`` of an electric dipole or wire, or (``electric=False``) of a
+    magnetic dipole = an electric square loop around it.
 
     Same call as the reference's ``emg3d.get_source_field`` (emg3d/fields.py:386-519)
-    for the electric sources given as coordinates:
+    for sources given as coordinates:
 
     - ``(x, y, z, azimuth, elevation)``: dipole of ``length`` (default 1 m) centred at
       (x, y, z);
@@ -358,9 +359,8 @@ def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs
     ``frequency`` > 0: frequency domain (complex), < 0: Laplace domain (real), ``None``:
     the bare source vector.
     """
-    if kwargs.get('electric', True) is not True:
-        raise NotImplementedError("emg3d_amd: magnetic sources are out of scope.")
     src = np.asarray(source, dtype=float)
+    magnetic = kwargs.get('electric', True) is not True
     if src.size == 5:
         c = src[:3]
         half = 0.5 * length * _direction(src[3], src[4])
@@ -371,6 +371,23 @@ def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs
         pts = src
     else:
         raise ValueError(f"Source format not understood: {source!r}.")
+    if magnetic:
+        # ``electric=False``: a magnetic dipole, represented by an electric square loop perpendicular to
+        # it and centred on it, whose AREA equals the dipole's length (TxMagneticDipole,
+        # emg3d/electrodes.py:536-568, point_to_square_loop :795-822): five points, a closed wire
+        if pts.shape[0] != 2:
+            raise ValueError(f"A magnetic dipole is given by a point or two electrodes: {source!r}.")
+        if src.size == 5:
+            centre, azm, elv, area = src[:3], src[3], src[4], float(length)
+        else:
+            d = pts[1] - pts[0]
+            area = float(np.linalg.norm(d))
+            azm = np.angle(d[0] + 1j * d[1], deg=True)
+            elv = np.angle(np.sqrt(d[0] ** 2 + d[1] ** 2) + 1j * d[2], deg=True)
+            centre = pts.sum(0) / 2
+        half_diag = np.sqrt(area / 2)
+        hor, ver = _rotation(azm + 90.0, 0.0) * half_diag, _rotation(azm, elv + 90.0) * half_diag
+        pts = centre + np.stack([hor, ver, -hor, -ver, hor])
     pts = np.round(pts, 9)
     lo = np.array([grid.nodes_x[0], grid.nodes_y[0], grid.nodes_z[0]])
     hi = np.array([grid.nodes_x[-1], grid.nodes_y[-1], grid.nodes_z[-1]])

@@ -50,3 +50,9 @@ def golden_solves32():
 @pytest.fixture(scope='session')
 def golden_gradient():
     return np.load(os.path.join(GOLDEN, 'gradient.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_sources():
+    """Source vectors of the reference's get_source_field incl. magnetic dipoles (tools/make_golden.py sources)."""
+    return np.load(os.path.join(GOLDEN, 'sources.npz'), allow_pickle=False)

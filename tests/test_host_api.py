@@ -291,3 +291,25 @@ def test_smoother_omega_is_validated():
     for bad in (0, 2, -0.5, 2.5):
         with pytest.raises(ValueError, match="smoother_omega"):
             solver._check_omega(bad)
+
+
+def test_source_vectors_incl_magnetic_dipoles_vs_reference(golden_sources):
+    """get_source_field against the reference's own source vectors (tools/make_golden.py sources):
+    magnetic dipoles (``electric=False``: the square loop of TxMagneticDipole, point and two-electrode
+    format), an electric dipole and a wire -- bare vector, frequency and Laplace domain."""
+    g = golden_sources
+    grid = emg3d.TensorMesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    for name in g['names']:
+        src = g[f'{name}_source']
+        kw = dict(strength=float(g[f'{name}_strength']))
+        if src.size == 5:
+            kw['length'] = float(g[f'{name}_length'])
+        if not bool(g[f'{name}_electric']):
+            kw['electric'] = False
+        for tag, freq in (('vec', None), ('f', 0.9), ('s', -1.7)):
+            sf = emg3d.get_source_field(grid, src, freq, **kw)
+            want = np.zeros(sf.field.size, dtype=g[f'{name}_{tag}_value'].dtype)
+            want[g[f'{name}_{tag}_index']] = g[f'{name}_{tag}_value']
+            assert sf.field.dtype == want.dtype
+            scale = np.abs(want).max()
+            assert np.abs(sf.field - want).max() < 1e-12 * scale, (name, tag)

@@ -17,6 +17,7 @@ Fixtures written (each ≤ 1.5 MB):
     tests/golden/receivers.npz          magnetic field and receiver responses (cubic / linear)
                                         of the reference for random fields
     tests/golden/gridding.npz           models re-gridded by the reference (volume averaging)
+    tests/golden/sources.npz            (`sources`) source vectors incl. magnetic dipoles (square loops)
 Metadata (scipy version, mu_0, seeds) is stored in every file.
 """
 import os
@@ -495,6 +496,36 @@ def gridding():
     print('gridding.npz written')
 
 
+def sources():
+    """Source vectors of the reference's get_source_field: magnetic dipoles (electric=False: the
+    square loop of TxMagneticDipole) in the point and the two-electrode format, next to an electric
+    dipole and a wire -- sparse (index, value) of the bare vector (frequency=None) and of the
+    frequency- and Laplace-domain fields."""
+    hx, hy, hz = widths(6, 3, 40., 1.3), widths(4, 3, 50., 1.25), widths(4, 2, 30., 1.4)
+    grid = emg3d.TensorMesh([hx, hy, hz], (-hx.sum() / 2, -hy.sum() / 2, -hz[:5].sum()))
+    out = dict(META)
+    out['hx'], out['hy'], out['hz'], out['origin'] = hx, hy, hz, np.asarray(grid.origin, float)
+    cases = [
+        ('mag_point', (13., -7., 5., 37., -21.), dict(electric=False, length=1.0, strength=1.0)),
+        ('mag_point_big', (-20., 25., -3., 0., 90.), dict(electric=False, length=900.0, strength=2.5)),
+        ('mag_two', (-20., 25., -3., 17., 7., 31.), dict(electric=False, strength=1.0)),
+        ('el_point', (13., -7., 5., 37., -21.), dict(strength=3.0)),
+        ('el_wire', np.array([[-60., -40., -10.], [-10., -40., -10.], [-10., 30., 5.], [45., 30., 20.]]), dict(strength=1.5)),
+    ]
+    out['names'] = np.array([c[0] for c in cases])
+    for name, src, kw in cases:
+        out[f'{name}_source'] = np.asarray(src, dtype=float)
+        out[f'{name}_strength'] = kw.get('strength', 1.0)
+        out[f'{name}_length'] = kw.get('length', 1.0)
+        out[f'{name}_electric'] = kw.get('electric', True)
+        for tag, freq in (('vec', None), ('f', 0.9), ('s', -1.7)):
+            sf = emg3d.get_source_field(grid, src, freq, **kw)
+            nz = np.flatnonzero(sf.field)
+            out[f'{name}_{tag}_index'], out[f'{name}_{tag}_value'] = nz, sf.field[nz]
+    np.savez_compressed(os.path.join(OUT, 'sources.npz'), **out)
+    print('sources.npz written:', [c[0] for c in cases])
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['regression', 'kernels', 'solves', 'receivers', 'gridding']
@@ -512,3 +543,5 @@ if __name__ == '__main__':
         solves32()
     if 'gradient' in which:
         gradient()
+    if 'sources' in which:
+        sources()
