@@ -15,7 +15,7 @@ import numpy as np
 
 from emg3d_amd import meshes
 
-__all__ = ['Field', 'get_source_field', 'get_magnetic_field', 'get_receiver', 'MU_0', 'EPSILON_0']
+__all__ = ['Field', 'get_source_field', 'get_magnetic_field', 'get_receiver', 'get_responses', 'MU_0', 'EPSILON_0']
 
 # scipy 1.15.3 CODATA-2022 values (the reference takes them from scipy.constants;
 # SURVEY.md section 0 item 8). Hard-coded so that results do not move with scipy.
@@ -476,6 +476,49 @@ def get_magnetic_field(model, efield):
         _ptr(m, int(mo[0])), _ptr(m, int(mo[1])), _ptr(m, int(mo[2])), _stream()), 'emg3d_dev_magnetic_field')
     torch.from_numpy(hfield.field).copy_(m)
     return hfield
+
+
+def magnetic_field_device(grid, frequency, e_dev, mu_r=None):
+    """``get_magnetic_field`` for an electric field that is in HBM (device tensor ``[ex | ey | ez]``):
+    returns (a host ``Field`` describing the magnetic field -- grid, frequency, kind; its values are
+    NOT filled --, the device tensor ``[hx | hy | hz]``). For responses of magnetic receivers taken
+    from a solution that never leaves the device: ``get_receiver(meta, rec, method, device_field=h)``."""
+    torch, _lib, _ptr, _stream, dev = _device_tools()
+    nx, ny, nz = grid.shape_cells
+    emeta = Field(grid, frequency=frequency)
+    hmeta = Field(grid, frequency=frequency, electric=False)
+    vol = grid.cell_volumes
+    zeta = vol if mu_r is None else vol / np.asarray(mu_r, dtype=float).ravel('F')
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)   # noqa: E731
+    z, hx, hy, hz = up(zeta), up(grid.h[0]), up(grid.h[1]), up(grid.h[2])
+    hdev = torch.empty(hmeta.field.size, dtype=e_dev.dtype, device=dev)
+    eo, mo = np.cumsum([0] + list(emeta._sizes)), np.cumsum([0] + list(hmeta._sizes))
+    smu0 = complex(emeta.smu0)
+    _lib.check(_lib.lib().emg3d_dev_magnetic_field(
+        nx, ny, nz, int(e_dev.is_complex()), _ptr(e_dev, int(eo[0])), _ptr(e_dev, int(eo[1])), _ptr(e_dev, int(eo[2])),
+        _ptr(z), _ptr(hx), _ptr(hy), _ptr(hz), smu0.real, smu0.imag,
+        _ptr(hdev, int(mo[0])), _ptr(hdev, int(mo[1])), _ptr(hdev, int(mo[2])), _stream()), 'emg3d_dev_magnetic_field')
+    return hmeta, hdev
+
+
+def get_responses(meta, e_dev, receivers, method='cubic', magnetic=None, mu_r=None, efield=None):
+    """Responses at point receivers ``(x, y, z, azimuth, elevation)`` -- electric ones [V/m], magnetic
+    ones [A/m] where the boolean sequence ``magnetic`` says so (what ``Simulation._get_responses`` collects,
+    emg3d/simulations.py:759-792) -- from the solution in HBM (``e_dev``) or, without it, from the host
+    field ``efield``. ``meta``: a Field that describes grid and frequency."""
+    rec = tuple(np.atleast_1d(np.asarray(c, dtype=float)) for c in receivers)
+    src = meta if efield is None else efield
+    if magnetic is None or not np.any(magnetic):
+        return get_receiver(src, receivers, method, device_field=e_dev)
+    mag = np.broadcast_to(np.asarray(magnetic, dtype=bool), np.broadcast(*rec[:3]).shape).ravel()
+    rec = tuple(np.broadcast_to(c, mag.shape) for c in rec)
+    out = np.array(get_receiver(src, rec, method, device_field=e_dev))
+    if e_dev is None:
+        torch = _device_tools()[0]
+        e_dev = torch.from_numpy(np.ascontiguousarray(efield.field)).to(_device_tools()[4])
+    hmeta, hdev = magnetic_field_device(meta.grid, meta._frequency, e_dev, mu_r)
+    out[mag] = get_receiver(hmeta, tuple(c[mag] for c in rec), method, device_field=hdev)
+    return out
 
 
 def _rotation(azimuth, elevation):

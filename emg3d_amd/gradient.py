@@ -149,21 +149,7 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
         _lib.check(_lib.lib().emg3d_dev_copy(_ptr(e_fwd), _ptr(top.e), top.e.numel() * top.e.element_size(), _stream()),
                    'emg3d_dev_copy')
         meta = Field(grid, frequency=freq)
-        synthetic = fields.get_receiver(meta, rec, 'linear', device_field=e_fwd)
-        if mag.any():                                  # H on the faces from the field in HBM, then the same interpolation
-            hmeta = Field(grid, frequency=freq, electric=False)
-            hdev = torch.empty(hmeta.field.size, dtype=e_fwd.dtype, device=dev)
-            hh = [torch.from_numpy(np.ascontiguousarray(h)).to(dev) for h in grid.h]
-            eo, mo = np.cumsum([0] + list(meta._sizes)), np.cumsum([0] + list(hmeta._sizes))
-            s0 = complex(meta.smu0)
-            _lib.check(_lib.lib().emg3d_dev_magnetic_field(
-                nx, ny, nz, int(e_fwd.is_complex()), _ptr(e_fwd, int(eo[0])), _ptr(e_fwd, int(eo[1])),
-                _ptr(e_fwd, int(eo[2])), _ptr(vol), _ptr(hh[0]), _ptr(hh[1]), _ptr(hh[2]), s0.real, s0.imag,
-                _ptr(hdev, int(mo[0])), _ptr(hdev, int(mo[1])), _ptr(hdev, int(mo[2])), _stream()),
-                'emg3d_dev_magnetic_field')
-            rmag = tuple(r[mag] for r in rec)
-            synthetic = np.array(synthetic)
-            synthetic[mag] = fields.get_receiver(hmeta, rmag, 'linear', device_field=hdev)
+        synthetic = fields.get_responses(meta, e_fwd, rec, 'linear', magnetic=mag)
         obs = np.asarray(observed[(sname, fname)])
         w = np.ones(obs.shape) if weights is None else np.asarray(weights[(sname, fname)], dtype=float)
         residual = synthetic - obs

@@ -179,15 +179,15 @@ def solve(inp):
                             return_info=True, always_return=True, **opts)
     # responses at the receivers, from the field while it is still in HBM when the solver keeps
     # it there (multigrid, BiCGSTAB): without `keep_field` nothing but the responses comes back
-    on_device = (opts.get('hierarchy') is not None and inp.get('efield') is None and
-                 opts.get('sslsolver', True) in (True, False, None, 'bicgstab'))
+    on_device = opts.get('hierarchy') is not None and inp.get('efield') is None
     if on_device and not inp.get('keep_field', True):
         opts['_download'] = False
     efield, info = solver.solve(model=model, sfield=sfield, efield=inp.get('efield'),
                                 return_info=True, always_return=True, **opts)
     dev_e = opts['hierarchy'].top.e if on_device else None
-    info['responses'] = fields.get_receiver(efield, rec, inp.get('receiver_method', 'cubic'),
-                                            device_field=dev_e)
+    info['responses'] = fields.get_responses(sfield if efield is None else efield, dev_e, rec,
+                                             inp.get('receiver_method', 'cubic'), magnetic=inp.get('magnetic'),
+                                             mu_r=getattr(model, 'mu_r', None), efield=None if on_device else efield)
     if opts.get('_download') is False:
         efield = None
     return efield, info
@@ -205,7 +205,8 @@ def gather_objects(obj, dst=0):
 
 
 def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, solve_fn=None,
-            keep_fields=True, per_gpu=1, reuse=True, receivers=None, receiver_method='cubic', batch=1):
+            keep_fields=True, per_gpu=1, reuse=True, receivers=None, receiver_method='cubic', batch=1,
+            magnetic=None):
     """Solve all source-frequency pairs, sharded over the ranks of the process group.
 
     model: on rank 0 (None elsewhere is fine; it is broadcast). sources: dict name ->
@@ -216,7 +217,10 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
     receivers: ``(x, y, z, azimuth, elevation)`` (any form ``fields.get_receiver`` takes), or a
     dict source name -> such; every pair's ``info['responses']`` then holds the field at the
     receivers, interpolated on the device from the solution while it is still in HBM. With
-    ``keep_fields=False`` only the responses leave the GPU (no field download).
+    ``keep_fields=False`` only the responses leave the GPU (no field download). ``magnetic``: boolean
+    sequence (or dict source name -> such) marking the receivers that are magnetic point receivers:
+    their responses are the magnetic field (``get_magnetic_field``, formed on the device from the
+    solution) at the point [A/m]; pairs with magnetic receivers are not batched.
 
     batch > 1: up to that many of the rank's pairs that share a frequency are solved TOGETHER by
     ``solver.solve_batch`` (right-hand sides as one more grid dimension of every launch:
@@ -253,6 +257,8 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
             inp['receivers'] = receivers[s] if isinstance(receivers, dict) else receivers
             inp['receiver_method'] = receiver_method
             inp['keep_field'] = keep_fields
+            if magnetic is not None:
+                inp['magnetic'] = magnetic[s] if isinstance(magnetic, dict) else magnetic
         if stream is None:
             efield, info = solve_fn(inp)
         else:
@@ -264,7 +270,7 @@ def compute(model, grid, sources, frequencies, solver_opts=None, costs=None, sol
 
     # batched: multigrid, or BiCGSTAB + multigrid (the default of `solve`); cgs / gcrotmk run
     # pair by pair (on the device as well)
-    if (batch > 1 and solve_fn is solve and
+    if (batch > 1 and solve_fn is solve and magnetic is None and
             dict(solver_opts or {}).get('sslsolver', True) in (True, False, None, 'bicgstab') and
             dict(solver_opts or {}).get('cycle', 'F') is not None):
         from emg3d_amd import fields as _fields, solver as _solver

@@ -849,6 +849,34 @@ def test_parallel_compute_responses_from_device_field():
         assert set(full['_all_info'][('S0', 'f1')]) >= {'responses', 'it_mg'}
 
 
+def test_parallel_compute_magnetic_receivers_from_device_field():
+    """`parallel.compute(receivers=..., magnetic=...)`: electric and magnetic point receivers; the
+    magnetic responses are formed on the device (H from the solution in HBM, then the interpolation)
+    and equal `get_receiver(get_magnetic_field(model, efield), ...)` of the downloaded field."""
+    from emg3d_amd import parallel
+    hx = widths(8, 3, 50., 1.3)
+    grid = emg3d.TensorMesh([hx, hx, hx], (-hx.sum() / 2,) * 3)
+    model = emg3d.Model(grid, property_x=np.full(grid.shape_cells, 1.5))
+    rec = (np.array([120., -80., 40.]), np.array([30., 60., -90.]), np.array([-20., 10., 55.]),
+           np.array([0., 90., 30.]), np.array([0., 0., 45.]))
+    mag = np.array([False, True, True])
+    srcs, freqs = {'s': (0., 0., 0., 0., 0.)}, {'f': 1.0}
+    opts = dict(sslsolver=False, cycle='F', semicoarsening=True, linerelaxation=True, tol=1e-8)
+    for keep in (True, False):
+        out = parallel.compute(model, grid, srcs, freqs, solver_opts=opts, receivers=rec, magnetic=mag,
+                               keep_fields=keep, receiver_method='cubic')
+        ef, info = out[('s', 'f')]
+        resp = info['responses']
+        assert (ef is None) == (not keep)
+        if keep:
+            want = np.array(emg3d.fields.get_receiver(ef, rec, 'cubic'))
+            want[mag] = emg3d.fields.get_receiver(emg3d.get_magnetic_field(model, ef), tuple(c[mag] for c in rec), 'cubic')
+            first = resp
+            assert np.allclose(resp, want, rtol=1e-12, atol=0)
+        else:
+            assert np.allclose(resp, first, rtol=1e-12, atol=0)
+
+
 def test_model_regridding_vs_reference_vectors(golden_gridding):
     """Model.interpolate_to_grid (volume averaging on the device) against
     models re-gridded by the reference; the same grid returns the model itself; a solve on the
