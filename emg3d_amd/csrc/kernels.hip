@@ -88,6 +88,9 @@ int g_residual_zb = 8;
 // fused line kernel with the records in the global scratch (the largest levels): the instantiation
 // that is held to 256 registers, so that two workgroups share a CU and overlap their phases
 int g_line_occ2 = 0;
+// point smoother: levels with at most this many interior nodes run all passes of a call in one
+// single-workgroup launch (k_gs_point_small); 0: off
+int g_point_small = 512;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
 
@@ -148,6 +151,28 @@ __global__ __launch_bounds__(256) void k_gs_point(emg::Level<T> L, const T *pst,
     const int b = blockIdx.z / izn, z = blockIdx.z - b * izn;
     emg::gs_point_thread<T>(emg::source_level(L, b), pst, colour, iz0, blockIdx.x * blockDim.x + threadIdx.x,
                             blockIdx.y * blockDim.y + threadIdx.y, z);
+}
+
+// Point smoother on a level small enough for ONE workgroup: all colour passes of all `nu` sweeps in
+// one launch, workgroup barriers between the passes (the waves of a workgroup share their CU's L1:
+// what one wave stored, the others read after the barrier). `passes`: the colour classes in the
+// order of the plain schedule, two bits each (the launcher leaves out the repeated class of
+// skip_repeat). The coarsest levels of a W-cycle are visited 2^levels times per cycle; their four
+// to seven launches of a microsecond of work each become one.
+template <class T>
+__global__ __launch_bounds__(256) void k_gs_point_small(emg::Level<T> L, const T *pst, unsigned long long passes, int npass)
+{
+    const int hx = (L.nx + 1) / 2, hy = (L.ny + 1) / 2, nzp = L.nz - 1;      // (gx, gy) cover both parities
+    const int n = hx * hy * nzp;
+    for (int p = 0; p < npass; ++p) {
+        const int colour = (int)((passes >> (2 * p)) & 3ULL);
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int gx = i % hx, r = i / hx, gy = r % hy, gz = r / hy;
+            emg::gs_point_thread<T>(L, pst, colour, 1, gx, gy, gz);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // eta edge sums of a level (stencil.h: point_setup_cell), one thread per extended cell
@@ -1184,6 +1209,23 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             }
             continue;
         }
+        if (lr == 0 && g_point_small > 0 && L.batch == 1 && 4 * nu <= 28 &&
+            (long long)(nx - 1) * (ny - 1) * (nz - 1) <= g_point_small) {
+            // a level for one workgroup: every pass of every sweep in ONE launch (k_gs_point_small)
+            if (it > 0) continue;                      // (launched with the first sweep)
+            unsigned long long passes = 0;
+            int npass = 0, ib = 0;
+            for (int s2 = 0; s2 < nu; ++s2) {
+                ib = 1 - ib;
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (g_skip_repeat && s2 > 0 && cc == 0) continue;
+                    passes |= (unsigned long long)emg::sweep_colour(ib, cc) << (2 * npass);
+                    ++npass;
+                }
+            }
+            hipLaunchKernelGGL(k_gs_point_small<T>, dim3(1), dim3(256), 0, st, L, pst, passes, npass);
+            continue;
+        }
         if (lr == 0) {
             // (same redundancy for the node classes; only the unslabbed schedule is a plain
             // sequence of whole colour passes)
@@ -1385,6 +1427,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "point_prefetch")) { g_point_prefetch = value; return 0; }
     if (!std::strcmp(name, "residual_zb")) { g_residual_zb = value > 0 ? value : 1; return 0; }
     if (!std::strcmp(name, "line_occ2")) { g_line_occ2 = value; return 0; }
+    if (!std::strcmp(name, "point_small")) { g_point_small = value; return 0; }
     if (!std::strcmp(name, "line_lpw")) {
         if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32)
             return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8, 16 or 32");
@@ -1406,6 +1449,7 @@ int emg3d_get_option(const char *name)
     if (name && !std::strcmp(name, "point_prefetch")) return g_point_prefetch;
     if (name && !std::strcmp(name, "residual_zb")) return g_residual_zb;
     if (name && !std::strcmp(name, "line_occ2")) return g_line_occ2;
+    if (name && !std::strcmp(name, "point_small")) return g_point_small;
     if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
     return -1;
 }
