@@ -14,11 +14,17 @@ B="python $R/bench.py --workload $WL --no-256 --no-survey --no-cpu-baseline"
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- $B > $O/trace.log 2>&1
 python $R/tools/rocpd_summary.py $O/trace/run_results.db > $R/gpurun_out/${TAG}_${WL}_kernel_stats.txt
 python $R/tools/trace_by_grid.py $O/trace/run_results.db k_line_colour > $R/gpurun_out/${TAG}_${WL}_line_launches_by_level.txt
-# (counter collection crashes inside HIP graph replays on this stack: the same kernels, launched eagerly)
+# (counter collection crashes inside HIP graph replays on this stack: the same kernels, launched eagerly.
+#  Even so rocprofv3 segfaults -- once it hung -- in about every second counter pass over this
+#  134 000-dispatch run, whatever the library options: bounded time, up to three attempts per pass)
 export EMG3D_AMD_GRAPHS=0
 BP="$B --steps 3 --warmup 0"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o run -- $BP > $O/f.log 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o run -- $BP > $O/w.log 2>&1
+for try in 1 2 3; do
+  rm -rf $O/f; timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o run -- $BP > $O/f.log 2>&1 && break
+done
+for try in 1 2 3; do
+  rm -rf $O/w; timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o run -- $BP > $O/w.log 2>&1 && break
+done
 unset EMG3D_AMD_GRAPHS
 F=$(ls $O/f/*counter_collection.csv | head -1); W=$(ls $O/w/*counter_collection.csv | head -1); tail -3 $O/f.log
 cd $R && python tools/pmc_traffic.py $WL $F $W > $R/gpurun_out/${TAG}_pmc_traffic_$WL.log 2>&1
