@@ -286,7 +286,16 @@ def run_cycles(top, var):
     loud = var.verb > 4
     if var.first_cycle and var.verb > 3:
         var.level_all.append(0)
-    l2_last = top.residual(store=False, norm=True)
+    # Residual form (solve(..., residual_form=); not for preconditioner calls, which are in that form
+    # already, nor for batches): every cycle solves A d = r = s - A e from d = 0 and adds d to e.
+    # For this linear, stationary iteration that is the same cycle in exact arithmetic; in floating
+    # point the errors of the smoothers -- the line solves multiply by stored block inverses: eps x
+    # cond of a block, relative to the right-hand side they are given -- then scale with the
+    # residual, not with the field, and the iteration converges to round-off.
+    resform = bool(getattr(var, 'residual_form', False)) and not var.sslsolver and top.batch == 1
+    if resform:
+        top._b_valid = False
+    l2_last = top.residual(store=resform, norm=True)
     ring = np.full(var.maxcycle, l2_last)           # errors one round of the schedule ago
     var.cprint("     it cycmax               error", 4)
     var.cprint("      level [  dimension  ]            info\n", 4)
@@ -297,11 +306,15 @@ def run_cycles(top, var):
         smooth_level(top, var.nu_init, var.lr_dir, var)
         if loud:
             _log_smoothing(var, 0, top, "initial smoothing", 0, _level0_visits(var))
+        if resform:
+            top.residual(store=True, norm=False)
     fixed = getattr(var, 'fixed_cycles', None)
     it = 0
     while True:
         l2_prev = l2_last
         ring[(it - 1) % var.maxcycle] = l2_last
+        if resform:
+            top.to_residual_equation()
         if var.clevel[var.sc_dir] == 0:            # a single level: nothing to recurse into
             smooth_level(top, var.nu_coarse, var.lr_dir, var)
             if loud:
@@ -323,7 +336,9 @@ def run_cycles(top, var):
                     _log_smoothing(var, 0, top, "post-smoothing", it)
         it += 1
         var.it += 1
-        l2_last = top.residual(store=False, norm=True)
+        if resform:
+            top.from_residual_equation()
+        l2_last = top.residual(store=resform, norm=True)
         record_cycle(var, l2_last, l2_prev)
         if var.sc_cycle:
             var.sc_dir = next(var.sc_cycle)

@@ -254,6 +254,35 @@ class DeviceLevel:
             self.e.numel(), int(self.is_complex), _ptr(self.e), 2, xs, slots, scales, 0, none_p, none_p, none_i, 0, none_i,
             _ptr(w.ws), _ptr(w.ws), w.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
 
+    # ---- finest level in residual form (_cycle.run_cycles): the cycle works on A d = r from d = 0
+    def to_residual_equation(self):
+        """Before a cycle: r = s - A e is in ``self.r`` (residual(store=True)). Keeps e and s aside,
+        then s <- r, e <- 0."""
+        nbytes = self.e.numel() * self.e.element_size()
+        if self.__dict__.get('_x_kept') is None:
+            self._x_kept, self._b_kept = torch.empty_like(self.e), torch.empty_like(self.s)
+            self._b_valid = False
+        cp = _lib.lib().emg3d_dev_copy
+        _lib.check(cp(_ptr(self._x_kept), _ptr(self.e), nbytes, _stream()), 'emg3d_dev_copy')
+        if not self._b_valid:                     # the source of a solve does not change between its cycles
+            _lib.check(cp(_ptr(self._b_kept), _ptr(self.s), nbytes, _stream()), 'emg3d_dev_copy')
+            self._b_valid = True
+        _lib.check(cp(_ptr(self.s), _ptr(self.r), nbytes, _stream()), 'emg3d_dev_copy')
+        self.zero_field()
+
+    def from_residual_equation(self):
+        """After the cycle: e <- e_kept + d (one fused update), s <- the solve's source."""
+        xs = (ctypes.c_void_p * 2)(self._x_kept.data_ptr(), self.e.data_ptr())
+        slots = (ctypes.c_int * 2)(-1, -1)
+        scales = (ctypes.c_double * 2)(1.0, 1.0)
+        none_p, none_i = (ctypes.c_void_p * 1)(), (ctypes.c_int * 1)()
+        w = self.work
+        _lib.check(_lib.lib().emg3d_dev_krylov_step(
+            self.e.numel(), int(self.is_complex), _ptr(self.e), 2, xs, slots, scales, 0, none_p, none_p, none_i, 0, none_i,
+            _ptr(w.ws), _ptr(w.ws), w.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
+        _lib.check(_lib.lib().emg3d_dev_copy(_ptr(self.s), _ptr(self._b_kept), self.s.numel() * self.s.element_size(),
+                                             _stream()), 'emg3d_dev_copy')
+
     def residual(self, store=True, norm=False):
         """r = s - A e into self.r (store) and/or its l2-norm (norm; synchronises)."""
         lib = _lib.lib()

@@ -41,7 +41,33 @@ def __dir__():
 _SOLVE_EXTRAS = {'always_return': False, 'plain': False, 'efield': None, 'hierarchy': None,
                  '_download': True,           # False: the result stays in hierarchy.top.e only
                  '_sparse_source': False,     # the source goes up as its few non-zeros
-                 'smoother_omega': 1.0}       # != 1: extrapolated smoothing calls (_cycle.smooth_level)
+                 'smoother_omega': 1.0,       # != 1: extrapolated smoothing calls (_cycle.smooth_level)
+                 'residual_form': 'auto'}     # finest level in residual form (_cycle.run_cycles)
+
+
+def _residual_form(choice, var, model, sfield):
+    """Does multigrid as a SOLVER run its finest level in residual form (``_cycle.run_cycles``)?
+    True / False, or 'auto': yes where the accuracy the line smoothers' stored block inverses can
+    reach on the model -- eps times the largest 1 / (|s| mu0 sigma h^2) of a cell, a bound the
+    measured residual floors stay one to two orders under -- is not well below the tolerance asked
+    for. (As a Krylov preconditioner multigrid is in residual form anyway.)"""
+    if choice in (True, False):
+        return bool(choice)
+    if choice != 'auto':
+        raise ValueError(f"`residual_form` must be True, False or 'auto'. Provided: {choice!r}.")
+    if var.sslsolver or not var.cycle or sfield.sval is None:
+        return False
+    hx, hy, hz = (np.asarray(h, dtype=float) for h in model.grid.h)
+    hmin = np.minimum(np.minimum(hx[:, None, None], hy[None, :, None]), hz[None, None, :])
+    with np.errstate(divide='ignore', over='ignore', invalid='ignore'):
+        sig = None
+        for name in ('property_x', 'property_y', 'property_z'):
+            c = model.conductivity(name)
+            if c is not None:
+                c = np.asarray(c, dtype=float).reshape(hmin.shape, order='F')
+                sig = c if sig is None else np.minimum(sig, c)
+        cond = 1.0 / np.min(abs(complex(sfield.sval)) * fields.MU_0 * sig * hmin ** 2)
+    return bool(np.isfinite(cond) and np.finfo(float).eps * cond > 0.01 * var.tol)
 
 
 def _check_omega(omega):
@@ -71,7 +97,12 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     value != 1 extrapolates every smoothing call, e <- e_before + omega (e_after - e_before) --
     same solution, and on models where the four-colour ordering costs cycles against the
     reference's sequential sweeps, fewer of them (1.2-1.3: 0-17 % in DESIGN.md 4.1; too large a
-    value diverges).
+    value diverges); ``residual_form='auto'`` (True / False): multigrid as a solver runs every cycle
+    on the residual equation A d = s - A e from d = 0 and adds d to the field -- the same iteration
+    in exact arithmetic, but the rounding errors of the smoothers then scale with the residual
+    instead of the field, so that the iteration converges to round-off where the stored block
+    inverses of the line smoothers would otherwise stall it (air layers, very low frequencies:
+    DESIGN.md 4.3); 'auto' switches it on where model and tolerance call for it.
 
     Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``).
     """
@@ -89,6 +120,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
             "it with `emg3d.fields.get_source_field`, or initiate it "
             "with `emg3d.fields.Field`, providing frequency information.")
     var.smoother_omega = _check_omega(extra['smoother_omega'])
+    var.residual_form = _residual_form(extra['residual_form'], var, model, sfield)
     var.sparse_source = bool(extra['_sparse_source']) and getattr(sfield, '_sparse', None) is not None
     var.download = bool(extra['_download'])
     var.l2_refe = _host_norm(sfield._sparse[1] if var.sparse_source else sfield.field)

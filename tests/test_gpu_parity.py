@@ -1451,6 +1451,45 @@ def test_adjoint_gradient_vs_finite_differences():
         assert nrmsd < 1.5, (cell, fd, g0[cell])
 
 
+def test_residual_form_converges_to_roundoff_with_an_air_layer():
+    """Multigrid as a solver on a marine model with an AIR layer of 1e8 Ohm m (the standard CSEM setting):
+    the line smoothers multiply by stored block inverses, whose rounding errors (eps x cond of a block:
+    1 / (omega mu sigma h^2) ~ 5e9 in the air) are relative to the right-hand side they are given. With
+    the finest level in direct form that is the FIELD's scale and the residual stalls near 1e-8 of the
+    source -- the reference reaches 1e-14 --; in residual form (`residual_form='auto'` switches it on
+    for this model) it is the residual's scale: the iteration follows the oracle's (same ordering)
+    history and converges to round-off like it. On a benign model both forms are the same iteration."""
+    from bench import workload
+    wl = workload('marine32')
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    zc = np.broadcast_to(grid.cell_centers_z[None, None, :], grid.shape_cells)
+    rh = np.where(zc > 0, 1e8, np.where(zc > -1000, 0.3, 1.0))
+    rv = np.where(zc > 0, 1e8, np.where(zc > -1000, 0.3, 2.0))
+    model = emg3d.Model(grid, property_x=rh, property_z=rv)
+    sfield = emg3d.get_source_field(grid, wl['source'], 1.0)
+    opts = dict(wl['opts'], sslsolver=False, tol=1e-12, maxit=40)
+    e, info = emg3d.solve(model, sfield, return_info=True, **opts)                       # 'auto'
+    assert info['exit'] == 0, info['exit_message']
+    ed, infod = emg3d.solve(model, sfield, return_info=True, residual_form=False, **opts)
+    assert infod['exit'] == 1 and infod['rel_error'] > 1e-10                             # the floor of the direct form
+    og = mg_ref.Grid(grid.h, grid.origin)
+    vm = mg_ref.volume_model(og, 1.0, 1 / rh, None, 1 / rv)
+    oo = {k: v for k, v in opts.items() if k != 'sslsolver'}
+    eo, io = mg_ref.solve(vm, mg_ref.Field(og, sfield.field.copy()), order=1, **oo)
+    assert io['exit'] == 0 and abs(info['it_mg'] - io['it_mg']) <= 1
+    n = min(len(info['error_at_cycle']), len(io['error_at_cycle'])) - 2
+    assert np.allclose(info['error_at_cycle'][:n], io['error_at_cycle'][:n], rtol=2e-2)
+    # (two fields with residuals of 1e-12 differ by 1e-7 here: the air makes the SYSTEM that ill-conditioned)
+    assert relerr(e.field, eo.field) < 1e-6
+    # benign model: the same iteration in both forms
+    model2 = emg3d.Model(grid, property_x=np.where(zc > -1000, 0.3, 1.0), property_z=np.where(zc > -1000, 0.3, 2.0))
+    o2 = dict(opts, tol=1e-9)
+    _, ia = emg3d.solve(model2, sfield, return_info=True, residual_form=True, **o2)
+    _, ib = emg3d.solve(model2, sfield, return_info=True, residual_form=False, **o2)
+    assert ia['exit'] == ib['exit'] == 0 and ia['it_mg'] == ib['it_mg']
+    assert np.allclose(ia['error_at_cycle'], ib['error_at_cycle'], rtol=1e-5)
+
+
 def test_volume_average_adjoint_is_the_transpose():
     """`_VolumeAverage.adjoint_add` (the gradient's way back from a computational grid, reference
     maps._interp_volume_average_adj) is the exact transpose of the linear averaging the same plan

@@ -313,3 +313,26 @@ def test_source_vectors_incl_magnetic_dipoles_vs_reference(golden_sources):
             assert sf.field.dtype == want.dtype
             scale = np.abs(want).max()
             assert np.abs(sf.field - want).max() < 1e-12 * scale, (name, tag)
+
+
+def test_residual_form_auto_rule():
+    """`solve(residual_form='auto')`: the finest level goes into residual form where eps / (|s| mu0 sigma h^2)
+    of the worst cell is not well below the tolerance (air layers, very low frequencies, tight tolerances)."""
+    from emg3d_amd import solver
+    h = np.full(8, 50.)
+    grid = emg3d.TensorMesh([h, h, h], (0., 0., 0.))
+    sf = emg3d.get_source_field(grid, (200., 200., 200., 0., 0.), 1.0)
+    benign = emg3d.Model(grid, property_x=np.full(grid.shape_cells, 1.0))
+    rho = np.full(grid.shape_cells, 1.0)
+    rho[:, :, 6:] = 1e8
+    air = emg3d.Model(grid, property_x=rho)
+
+    def rule(model, choice='auto', **kw):
+        var = solver.MGParameters(0, kw.pop('sslsolver', False), True, True, model.shape, **kw)
+        return solver._residual_form(choice, var, model, sf)
+    assert rule(benign, tol=1e-6) is False and rule(air, tol=1e-6) is True
+    assert rule(benign, tol=1e-12) is True
+    assert rule(air, tol=1e-6, sslsolver=True) is False          # a preconditioner is in residual form anyway
+    assert rule(benign, True, tol=1e-6) is True and rule(air, False, tol=1e-6) is False
+    with pytest.raises(ValueError):
+        rule(benign, 'yes', tol=1e-6)
