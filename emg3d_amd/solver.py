@@ -261,6 +261,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     keep_fields = kwargs.pop('keep_fields', True)
     hierarchy = kwargs.pop('hierarchy', None)            # a Hierarchy(vmodel, batch=len(sfields)) to reuse
     omega = _check_omega(kwargs.pop('smoother_omega', 1.0))     # extrapolated smoothing calls, as in solve()
+    resform = kwargs.pop('residual_form', 'auto')               # finest level in residual form, as in solve()
     sfields = list(sfields)
     nb = len(sfields)
     if nb == 0:
@@ -279,6 +280,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         return v
     vars_ = [new_var() for _ in sfields]
     var = svar = new_var()             # carries the structure of the cycle, shared by all sources
+    svar.residual_form = _residual_form(resform, svar, model, first)
     if var.sslsolver not in (None, False, 'bicgstab') or (var.sslsolver and not var.cycle):
         raise ValueError("solve_batch: multigrid, or BiCGSTAB with multigrid as preconditioner.")
     def rec_of(b):
@@ -291,7 +293,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         for b, sf in enumerate(sfields):
             ef, info = solve(model, sf, sslsolver=sslsolver, semicoarsening=semicoarsening,
                              linerelaxation=linerelaxation, verb=verb, return_info=True, always_return=True,
-                             smoother_omega=omega, **kwargs)
+                             smoother_omega=omega, residual_form=resform, **kwargs)
             if rec_of(b) is not None:
                 info['responses'] = fields.get_receiver(ef, rec_of(b), receiver_method)
             out.append((ef if keep_fields else None, info))
@@ -343,7 +345,11 @@ def _multigrid_batch(lv, svar, vars_, active=None):
     n = lv.grid.n_edges
     cycmax = svar.cycmax
     it = 0
-    l2_last = lv.residual(store=False, norm=True)
+    # (finest level in residual form, as _cycle.run_cycles does it for one source)
+    resform = bool(getattr(svar, 'residual_form', False)) and not svar.sslsolver
+    if resform:
+        lv._b_valid = False
+    l2_last = lv.residual(store=resform, norm=True)
     l2_stag = np.ones((nb, svar.maxcycle)) * l2_last[:, None]
     active = [True] * nb if active is None else list(active)
     done = [None] * nb
@@ -352,9 +358,13 @@ def _multigrid_batch(lv, svar, vars_, active=None):
     s0 = svar.smoother_cell_sweeps
     if svar.nu_init > 0:
         _smooth(lv, svar.nu_init, svar.lr_dir, svar)
+        if resform:
+            lv.residual(store=True, norm=False)
     while any(active):
         l2_prev = l2_last.copy()
         l2_stag[:, (it - 1) % svar.maxcycle] = l2_last
+        if resform:
+            lv.to_residual_equation()
         if svar.nu_pre > 0:
             _smooth(lv, svar.nu_pre, svar.lr_dir, svar)
         sc_dir = _current_sc_dir(svar.sc_dir, lv.grid)
@@ -365,7 +375,9 @@ def _multigrid_batch(lv, svar, vars_, active=None):
         if svar.nu_post > 0:
             _smooth(lv, svar.nu_post, svar.lr_dir, svar)
         it += 1
-        l2_last = lv.residual(store=False, norm=True)
+        if resform:
+            lv.from_residual_equation()
+        l2_last = lv.residual(store=resform, norm=True)
         sc_now, lr_now = svar.sc_dir, svar.lr_dir
         if svar.sc_cycle:
             svar.sc_dir = next(svar.sc_cycle)

@@ -908,7 +908,7 @@ def test_model_regridding_vs_reference_vectors(golden_gridding):
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(cycle='W', linerelaxation=False), dict(plain=True, cycle='V'),
-                                dict(semicoarsening=False, linerelaxation=2)])
+                                dict(semicoarsening=False, linerelaxation=2), dict(residual_form=True)])
 def test_solve_batch_equals_separate_solves(kw):
     """solve_batch: several sources of one frequency through the same launches (emg3d_level::batch)
     give, source by source, the field, cycle count and error history of separate solves -- also
