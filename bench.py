@@ -261,7 +261,14 @@ def smoothers_256(device, n=256, nu=2, reps=5):
         full = BYTES_PER_CELL_SWEEP['triaxial'] * grid.n_cells * nu          # nu whole sweeps
         gbs_exec = full * executed / (ms_call * 1e-3) / 1e9
         gbs_deliv = full / (ms_call * 1e-3) / 1e9
+        # secondary check: fp64 rate of the work executed. Operations per cell and sweep
+        # counted from the kernels' instruction mix (tools/isa_mix.py): point 546 fp64 instructions per
+        # node, lines 4 lanes x (51 forward + 51 backward) + ~130 right-hand side per block; ~85 % of
+        # them fused multiply-adds -> ~1.0 kflop per cell-sweep either way (the reference: ~1.1 kflop)
+        kflop = 1.01 if lr == 0 else 1.0
+        tflops = kflop * 1e3 * grid.n_cells * nu * executed / (ms_call * 1e-3) / 1e12
         out[names[lr]] = {'ms_per_call': ms_call, 'launches_per_call': launches,
+                          'approx_fp64_tflops': tflops, 'approx_fp64_frac_of_78.6_vector_peak': tflops / 78.6,
                           'ms_per_launch': ms_call / launches, 'ms_per_delivered_sweep': ms_call / nu,
                           'achieved': gbs_exec, 'unit': 'GB/s', 'frac': gbs_exec / HBM_PEAK_GBS,
                           'achieved_delivered': gbs_deliv, 'frac_delivered': gbs_deliv / HBM_PEAK_GBS,
