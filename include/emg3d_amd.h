@@ -143,12 +143,16 @@ int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex);
  * on eta, zeta and h only, so it is computed once per level and direction
  * (emg3d_dev_line_setup) and reused by every sweep -- the work core.solve
  * (emg3d/core.py:1481-1616) repeats on every call of the reference's line smoothers.
- * Accuracy: a line solve multiplies by the stored inverses of its 5 x 5 Schur complements, so its
- * rounding errors are eps x cond of a block (~ 1 / (omega mu sigma h^2)) relative to the right-hand
- * side -- 2e-12 against the reference per call on the models of the tests, but 1e-7 where cells of
- * 1e8 Ohm m (air) are in the line. An iteration that needs more runs the smoother on the residual
- * equation (what emg3d_amd.solve(residual_form=...) does on the finest level; coarse levels and
- * preconditioner calls are in that form anyway): the errors then scale with the residual.
+ * Accuracy: the local systems are as ill-conditioned as 1 / (omega mu sigma h^2) (1e5 in sediments
+ * at 1 Hz, 5e9 in air of 1e8 Ohm m), so any two fp64 evaluations of a sweep differ by eps x cond:
+ * 1e-14 (marine model) ... 3e-6 (the same model under an air layer, random fields) between these
+ * kernels -- point and line smoothers alike -- and the reference's arithmetic. What sets the line
+ * smoothers apart is the RESIDUAL a solve leaves: multiplying by the stored inverses of the 5 x 5
+ * Schur complements it is eps x cond x |right-hand side|, where a substitution (the point
+ * smoother's, the reference's) leaves eps x |right-hand side|. An iteration whose tolerance is below
+ * that runs the smoother on the residual equation (emg3d_amd.solve(residual_form=...) on the finest
+ * level; coarse levels and preconditioner calls are in that form anyway): the errors then scale
+ * with the residual and the iteration converges to round-off.
  * Sizes of the two factor buffers (complex/real part `fac`, real coupling part `lfac`)
  * and of the per-call scratch (right-hand sides / solutions of one colour class): */
 size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex);
