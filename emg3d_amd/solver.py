@@ -48,7 +48,7 @@ _SOLVE_EXTRAS = {'always_return': False, 'plain': False, 'efield': None, 'hierar
 def _residual_form(choice, var, model, sfield):
     """Does multigrid as a SOLVER run its finest level in residual form (``_cycle.run_cycles``)?
     True / False, or 'auto': yes where the accuracy the line smoothers' stored block inverses can
-    reach on the model -- eps times the largest 1 / (|s| mu0 sigma h^2) of a cell, a bound the
+    reach on the model -- eps / (|s| mu0 sigma_min h_min^2), a bound the
     measured residual floors stay one to two orders under -- is not well below the tolerance asked
     for. (As a Krylov preconditioner multigrid is in residual form anyway.)"""
     if choice in (True, False):
@@ -57,16 +57,22 @@ def _residual_form(choice, var, model, sfield):
         raise ValueError(f"`residual_form` must be True, False or 'auto'. Provided: {choice!r}.")
     if var.sslsolver or not var.cycle or sfield.sval is None:
         return False
-    hx, hy, hz = (np.asarray(h, dtype=float) for h in model.grid.h)
-    hmin = np.minimum(np.minimum(hx[:, None, None], hy[None, :, None]), hz[None, None, :])
+    # (cheap on purpose: two reductions per property array -- the smallest conductivity of the model
+    # with the smallest cell width, whether or not they meet in one cell)
+    hmin = min(float(np.min(h)) for h in model.grid.h)
+    names = ('property_x', 'property_y', 'property_z')
+    key = (model.mapping,) + tuple(id(getattr(model, n)) for n in names)
+    cached = model.__dict__.get('_sigma_min')            # (the arrays of a model are replaced, not edited)
     with np.errstate(divide='ignore', over='ignore', invalid='ignore'):
-        sig = None
-        for name in ('property_x', 'property_y', 'property_z'):
-            c = model.conductivity(name)
-            if c is not None:
-                c = np.asarray(c, dtype=float).reshape(hmin.shape, order='F')
-                sig = c if sig is None else np.minimum(sig, c)
-        cond = 1.0 / np.min(abs(complex(sfield.sval)) * fields.MU_0 * sig * hmin ** 2)
+        if cached is None or cached[0] != key:
+            sig = np.inf
+            for name in names:
+                prop = getattr(model, name)
+                if prop is not None:
+                    ends = models._MAPS[model.mapping](np.array([np.min(prop), np.max(prop)], dtype=float))
+                    sig = min(sig, float(np.min(ends)))
+            cached = model.__dict__['_sigma_min'] = (key, sig)
+        cond = np.float64(1.0) / np.float64(abs(complex(sfield.sval)) * fields.MU_0 * cached[1] * hmin ** 2)
     return bool(np.isfinite(cond) and np.finfo(float).eps * cond > 0.01 * var.tol)
 
 
