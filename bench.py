@@ -57,9 +57,11 @@ def widths(ncore, npad, width, factor):
 
 
 # ------------------------------------------------------------------------- workloads ---
-def workload(name, source_index=0):
+def workload(name, source_index=0, with_model=True):
     """Grid widths, origin, resistivities (host arrays), source and solver settings of the
-    BASELINE.json configurations."""
+    BASELINE.json configurations. with_model=False: everything but the
+    resistivity arrays (`res` is None) -- ranks > 0 of a multi-GPU run receive the model by
+    broadcast and never build it."""
     if name in ('marine128', 'marine64', 'marine32'):
         # config 2 (and reduced copies of it for quick checks): stretched marine halfspace,
         # VTI sediments, deep water; F-cycle + semicoarsening + line relaxation
@@ -74,7 +76,7 @@ def workload(name, source_index=0):
         rv = np.where(zc > -1000 * n / 128, 0.3, 2.0)
         shape = (n, n, n)
         res = {'property_x': np.broadcast_to(rh[None, None, :], shape),
-               'property_z': np.broadcast_to(rv[None, None, :], shape)}
+               'property_z': np.broadcast_to(rv[None, None, :], shape)} if with_model else None
         # config 4: 8 x-dipoles at x = -1400 ... +1400 step 400
         sx = (-1400. + 400. * (source_index % 8)) * n / 128 if source_index else 0.
         src = (sx, 0., -950. * n / 128, 0., 0.)
@@ -87,10 +89,12 @@ def workload(name, source_index=0):
         n = int(name[8:])
         h = widths(n // 2, n // 4, 25., 1.03 if n == 256 else 1.06)
         origin = (-h.sum() / 2,) * 3
-        rng = np.random.default_rng(20260928)
-        lat = 10 ** rng.uniform(-0.5, 1.5, (16, 16, 16))
-        px = np.kron(lat, np.ones((n // 16,) * 3))
-        res = {'property_x': px, 'property_y': 1.5 * px, 'property_z': 2.5 * px}
+        res = None
+        if with_model:
+            rng = np.random.default_rng(20260928)
+            lat = 10 ** rng.uniform(-0.5, 1.5, (16, 16, 16))
+            px = np.kron(lat, np.ones((n // 16,) * 3))
+            res = {'property_x': px, 'property_y': 1.5 * px, 'property_z': 2.5 * px}
         opts = dict(cycle='W', semicoarsening=True, linerelaxation=True)
         # rank r of a multi-GPU run solves its own source: x-dipoles 100 m apart
         return dict(h=[h, h, h], origin=origin, res=res, source=(100. * source_index, 0., 0., 0., 0.),
@@ -102,7 +106,7 @@ def workload(name, source_index=0):
         # uniform fullspace, plain F-cycle: exercises the POINT smoother
         n = int(name[7:])
         h = np.full(n, 50.)
-        res = {'property_x': np.ones((n, n, n))}
+        res = {'property_x': np.ones((n, n, n))} if with_model else None
         opts = dict(cycle='F', semicoarsening=False, linerelaxation=False)
         return dict(h=[h, h, h], origin=(-25. * n,) * 3, res=res, source=(0., 0., 0., 0., 0.),
                     frequency=1.0, opts=opts, case='isotropic',
@@ -117,18 +121,20 @@ def workload(name, source_index=0):
         hx = widths(256 // q, 64 // q, 50. * q, 1.04 ** q)
         hy = widths(128 // q, 64 // q, 50. * q, 1.04 ** q)
         origin = (-hx.sum() / 2, -hy.sum() / 2, -hy[:64 // q].sum() - 5400.)
-        xc, yc, zc = (o + np.cumsum(h) - h / 2 for o, h in zip(origin, (hx, hy, hy)))
-        X, Y, Z = np.meshgrid(xc, yc, zc, indexing='ij')
-        rho = np.where(Z > -1000., 0.3, 1.0 + 2.0 * np.clip((-1000. - Z) / 5000., 0., 1.))
-        for cx, cy, cz, ax, ay, az in ((-800., 0., -3000., 2200., 1500., 900.),
-                                       (1500., 600., -3600., 1400., 1800., 700.),
-                                       (200., -900., -2400., 900., 700., 500.)):
-            inside = ((X - cx) / ax) ** 2 + ((Y - cy) / ay) ** 2 + ((Z - cz) / az) ** 2 < 1.
-            rho = np.where(inside & (Z <= -1000.), 100., rho)
+        rho = None
+        if with_model:
+            xc, yc, zc = (o + np.cumsum(h) - h / 2 for o, h in zip(origin, (hx, hy, hy)))
+            X, Y, Z = np.meshgrid(xc, yc, zc, indexing='ij')
+            rho = np.where(Z > -1000., 0.3, 1.0 + 2.0 * np.clip((-1000. - Z) / 5000., 0., 1.))
+            for cx, cy, cz, ax, ay, az in ((-800., 0., -3000., 2200., 1500., 900.),
+                                           (1500., 600., -3600., 1400., 1800., 700.),
+                                           (200., -900., -2400., 900., 700., 500.)):
+                inside = ((X - cx) / ax) ** 2 + ((Y - cy) / ay) ** 2 + ((Z - cz) / az) ** 2 < 1.
+                rho = np.where(inside & (Z <= -1000.), 100., rho)
         freq = (0.25, 0.5, 1.0, 2.0)[(source_index // 2) % 4]
         src = (-2000. if source_index % 2 == 0 else 2000., 0., -950., 0., 0.)
         opts = dict(cycle='F', semicoarsening=True, linerelaxation=True)
-        return dict(h=[hx, hy, hy], origin=origin, res={'property_x': rho}, source=src,
+        return dict(h=[hx, hy, hy], origin=origin, res={'property_x': rho} if with_model else None, source=src,
                     frequency=freq, opts=opts, case='isotropic',
                     label=f"{hx.size} x {hy.size} x {hy.size} salt-like isotropic model, x-dipole at "
                     f"x = {src[0]:+.0f} m, {freq} Hz, F-cycle + semicoarsening + line relaxation")
@@ -137,13 +143,13 @@ def workload(name, source_index=0):
 
 # -------------------------------------------------------------------------- GPU side ---
 class Bench:
-    def __init__(self, wl, device):
+    def __init__(self, wl, model, device):
         import torch
         import emg3d_amd as emg3d
         from emg3d_amd import solver
         self.torch, self.solver = torch, solver
-        grid = emg3d.TensorMesh(wl['h'], wl['origin'])
-        model = emg3d.Model(grid, **wl['res'])
+        grid = model.grid
+        self.model = model
         self.sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
         vmodel = emg3d.models.VolumeModel(model, self.sfield)
         self.grid, self.case = grid, model.case
@@ -312,49 +318,118 @@ def survey_8(device):
     return out
 
 
+REDUCED_COPY = {'triaxial256': 'triaxial64', 'marine128': 'marine64', 'salt384': 'salt96'}
+
+
+def time_to_tol(name, wl, b, tol=1e-6):
+    """Time to solution next to the cell-sweep rate. The GPU sweeps lines in four colours, the
+    reference sequentially (emg3d/core.py:602-624): same converged field, but on models like config
+    3's the coloured order needs more cycles -- invisible in a metric that counts cell-sweeps. This
+    block reports the whole solve of the bench workload to `tol` on the GPU (cycles, seconds on the
+    warm hierarchy) and, on the reduced copy of the workload the oracle can solve in seconds, the
+    cycle counts of both orders; ``cycle_ratio`` = lexicographic / four-colour (<= 1) converts the
+    headline value into lexicographic-equivalent cell-sweeps (filled in by the CPU leg)."""
+    import torch
+    import emg3d_amd as emg3d
+    out = {'tol': tol, 'workload': name}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, info = emg3d.solve(b.model, b.sfield, sslsolver=False, tol=tol, return_info=True, hierarchy=b.hier,
+                          _download=False, **wl['opts'])
+    torch.cuda.synchronize()
+    out['gpu'] = {'cycles': int(info['it_mg']), 'seconds': time.perf_counter() - t0, 'exit': int(info['exit']),
+                  'rel_error': float(info['rel_error']), 'ordering': 'four-colour lines (0,2,3,1)'}
+    small = REDUCED_COPY.get(name)
+    if small:
+        ws = workload(small)
+        grid = emg3d.TensorMesh(ws['h'], ws['origin'])
+        sf = emg3d.get_source_field(grid, ws['source'], ws['frequency'])
+        _, i2 = emg3d.solve(emg3d.Model(grid, **ws['res']), sf, sslsolver=False, tol=tol, return_info=True, **ws['opts'])
+        out['reduced_copy'] = {'workload': small, 'gpu_cycles': int(i2['it_mg'])}
+    return out
+
+
+def time_to_tol_cpu(ttt, value, seconds=40.0):
+    """The oracle's cycle count in the reference's lexicographic order on the reduced copy (CPU)."""
+    from oracle import mg_ref
+    rc = ttt.get('reduced_copy')
+    if not rc:
+        return
+    ws = workload(rc['workload'])
+    import emg3d_amd as emg3d
+    grid = emg3d.TensorMesh(ws['h'], ws['origin'])
+    sf = emg3d.get_source_field(grid, ws['source'], ws['frequency'])
+    og = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in ws['res'].items()}
+    vm = mg_ref.volume_model(og, ws['frequency'], cond['property_x'], cond.get('property_y'), cond.get('property_z'))
+    t0 = time.perf_counter()
+    _, io = mg_ref.solve(vm, mg_ref.Field(og, sf.field.copy()), tol=ttt['tol'], **ws['opts'])
+    rc['oracle_lexicographic_cycles'] = int(io['it_mg'])
+    rc['oracle_seconds'] = time.perf_counter() - t0
+    ratio = min(1.0, io['it_mg'] / max(rc['gpu_cycles'], 1))
+    ttt['cycle_ratio_lexicographic_over_four_colour'] = ratio
+    ttt['value_lexicographic_equivalent'] = value * ratio
+    ttt['note'] = ('value x cycle_ratio: cell-sweeps per second weighted by what a sweep in the GPU ordering is '
+                   'worth in cycles of the reference ordering, measured on the reduced copy')
+
+
 def pmc_traffic(workload_name, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary
-    (profiles/r02_pmc_traffic.json, else r01: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    passes of this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
-    None if there is no entry for this workload and kernel."""
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from): read from the
+    committed PMC summary of the newest round (profiles/rNN_pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes of this very command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured in this run, counters cannot be read
+    from inside the process; (None, None) if there is no entry for this workload and kernel."""
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
-                return json.load(f)[workload_name][kernel]['bytes_per_launch']
+                doc = json.load(f)
+            entry = doc[workload_name][kernel]
+            src = {'file': 'profiles/' + name, 'measured_in_this_run': False,
+                   'how': 'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command '
+                          '(tools/profile_bench.sh), FETCH_SIZE x 2'}
+            for k in ('library_commit', 'date', 'passes'):
+                if k in doc.get('_meta', {}):
+                    src[k] = doc['_meta'][k]
+            return entry['bytes_per_launch'], src
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
 
 
-def run_gpu(args, rank, world):
+def run_gpu(args):
     import torch
     import torch.distributed as dist
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    import emg3d_amd as emg3d
+    from emg3d_amd import parallel
+    gpu_t0 = time.perf_counter()
     # EMG3D_BENCH_BACKEND=gloo: dry run of the multi-rank code path on a box with fewer GPUs
     # than ranks (all ranks share the visible devices, collectives go through host tensors)
     backend = os.environ.get('EMG3D_BENCH_BACKEND', 'nccl')
-    if backend != 'nccl':
-        local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
-    cdev = device if backend == 'nccl' else torch.device('cpu')     # where collectives run
-    if world > 1:
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
-        else:
-            dist.init_process_group(backend)
+    rank, world, cdev = parallel.init(backend)               # the product's process-group setup
+    if cdev.type == 'cuda':
+        device = cdev
+    else:
+        local = int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
 
-    wl = workload(args.workload, source_index=rank if world > 1 else 0)
+    # rank 0 builds the model; the others receive it through the product's broadcast (one RCCL
+    # broadcast per property array over xGMI, the received arrays stay in HBM and eta / zeta are
+    # formed from them on the device: parallel.broadcast_model, SURVEY.md section 8e)
+    wl = workload(args.workload, source_index=rank if world > 1 else 0, with_model=(rank == 0))
+    model = None
+    if rank == 0:
+        model = emg3d.Model(emg3d.TensorMesh(wl['h'], wl['origin']), **wl['res'])
+    broadcast_ms = None
     if world > 1:
-        # the model is built on rank 0 and broadcast over RCCL/xGMI; every rank builds its
-        # own eta(f), zeta and source locally (SURVEY.md section 8e)
-        for k in sorted(wl['res']):
-            t = torch.from_numpy(np.ascontiguousarray(wl['res'][k], dtype=np.float64)).to(cdev)
-            if rank != 0:
-                t.zero_()
-            dist.broadcast(t, 0)
-            wl['res'][k] = t.cpu().numpy()
-    b = Bench(wl, device)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.perf_counter()
+        model = parallel.broadcast_model(model, 0, cdev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        broadcast_ms = (time.perf_counter() - tb) * 1e3
+    b = Bench(wl, model, device)
 
     def sync():
         torch.cuda.synchronize()
@@ -406,6 +481,7 @@ def run_gpu(args, rank, world):
         bytes_per_launch = BYTES_PER_CELL_SWEEP[b.case] * n0 / 4.0
         ms_launch = stats[dom]['ms'] / stats[dom]['launches']
         achieved = bytes_per_launch / (ms_launch * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(args.workload, names[dom])
         out = {
             'metric': 'Mcells*smoother-iters/s (fp64) per multigrid cycle',
             'value': work_all / dt_max / 1e6,
@@ -419,11 +495,14 @@ def run_gpu(args, rank, world):
                        'cells': n0, 'cycle': wl['opts']['cycle'],
                        'cell_sweeps_per_step': work / args.steps,
                        'rel_error_after_run': l2,
-                       'parallelism': f'{world} independent sources, 1 per GPU'},
+                       'parallelism': f'{world} independent sources, 1 per GPU',
+                       'model_distribution': None if world == 1 else
+                       'parallel.broadcast_model from rank 0 (one broadcast per property array, received '
+                       f'arrays stay in HBM), backend {backend}', 'broadcast_ms': broadcast_ms},
             'roofline': {
                 'bound': 'hbm', 'kernel': names[dom], 'hip_kernel': hip_names[dom],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload, names[dom]),
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                 'bytes_per_launch': bytes_per_launch, 'ms_per_launch': ms_launch,
                 'launches_timed': stats[dom]['launches'],
                 'gcell_sweeps_per_s': n0 / 4.0 / (ms_launch * 1e-3) / 1e9,
@@ -432,6 +511,11 @@ def run_gpu(args, rank, world):
                     'GB/s': bytes_per_launch / (v['ms'] / v['launches'] * 1e-3) / 1e9}
                     for k, v in stats.items()}},
         }
+    if rank == 0 and world == 1 and not args.no_ttt:
+        try:
+            out['time_to_tol'] = time_to_tol(args.workload, wl, b)
+        except Exception as exc:        # informational block: never takes the bench line down
+            out['time_to_tol'] = {'error': repr(exc)}
     if rank == 0 and world == 1 and not args.no_256:
         del b
         torch.cuda.empty_cache()
@@ -442,7 +526,8 @@ def run_gpu(args, rank, world):
             'kernel': 'k_gs_point_tile (core.gauss_seidel, 256^3 tri-axial)', 'bound': 'hbm',
             'achieved': pt['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': pt['frac'],
             'frac_delivered': pt['frac_delivered'], 'ms_per_launch': pt['ms_per_launch'],
-            'traffic': pmc_traffic('smoothers_256', 'k_gs_point_tile')}
+            'traffic': pmc_traffic('smoothers_256', 'k_gs_point_tile')[0],
+            'traffic_source': pmc_traffic('smoothers_256', 'k_gs_point_tile')[1]}
     if rank == 0 and world == 1 and not args.no_survey:
         torch.cuda.empty_cache()
         try:
@@ -450,9 +535,14 @@ def run_gpu(args, rank, world):
         except Exception as exc:        # informational block: never takes the bench line down
             out['survey_8_sources'] = {'error': repr(exc)}
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    return out, wl
+        parallel.finalize()
+    if out is not None:
+        # wall time of everything this process did on the GPU (setup, warm-up, timed region, the
+        # informational blocks), for reconciliation with an outside sampler of GPU activity: the
+        # timed region is `steps` x `ms_per_step` of it
+        torch.cuda.synchronize()
+        out['gpu_seconds_total'] = time.perf_counter() - gpu_t0
+    return out, wl, rank, world
 
 
 # -------------------------------------------------------------------------- CPU side ---
@@ -634,11 +724,10 @@ def main():
     ap.add_argument('--opt', action='append', default=[],
                     help='library tuning option name=value (emg3d_set_option), for experiments')
     ap.add_argument('--no-survey', action='store_true', help='skip the 8-source survey block')
+    ap.add_argument('--no-ttt', action='store_true', help="skip the time-to-tolerance block")
     ap.add_argument('--no-256', action='store_true',
                     help="skip the separate 256^3 smoother measurement ('smoothers_256')")
     args = ap.parse_args()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
     if 'RANK' not in os.environ and args.gpus > 1:
         raise SystemExit(_spawn_ranks(args))
     if args.opt:
@@ -647,10 +736,12 @@ def main():
             k, v = o.split('=')
             if _lib.lib().emg3d_set_option(k.encode(), int(v)) != 0:
                 raise SystemExit(f"unknown option {o}")
-    out, wl = run_gpu(args, rank, world)
+    out, wl, rank, world = run_gpu(args)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = run_cpu_baseline(workload(args.workload))
+            out['cpu_baseline'] = run_cpu_baseline(wl)
+            if 'reduced_copy' in out.get('time_to_tol', {}):
+                time_to_tol_cpu(out['time_to_tol'], out['value'])
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

@@ -20,6 +20,8 @@ import os
 import numpy as np
 import torch
 
+from emg3d_amd import _lib
+
 __all__ = ['run_cycles', 'coarse_correction', 'coarse_schedule', 'smooth_level', 'stop_reason',
            'ConvergenceError', 'current_sc_dir', 'current_lr_dir']
 
@@ -187,8 +189,10 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None):
         runner.run(steps)
         return
     cache = clv.__dict__.setdefault('_graphs', {})
+    # (the library's options select kernels and factor buffers: a graph captured under other
+    # options would replay launches into buffers that may have been freed since)
     key = (int(var.sc_dir), int(var.lr_dir), budget, var.cycle, var.nu_pre, var.nu_post, var.nu_coarse, depth,
-           float(getattr(var, 'smoother_omega', 1.0)))
+           float(getattr(var, 'smoother_omega', 1.0)), _lib.options_fingerprint())
     entry = cache.get(key)
     if entry is None or entry['graph'] is None:
         if entry is None:
@@ -315,25 +319,12 @@ def run_cycles(top, var):
         ring[(it - 1) % var.maxcycle] = l2_last
         if resform:
             top.to_residual_equation()
-        if var.clevel[var.sc_dir] == 0:            # a single level: nothing to recurse into
-            smooth_level(top, var.nu_coarse, var.lr_dir, var)
-            if loud:
-                _log_smoothing(var, 0, top, "coarsest level", it, 1)
-        else:
-            if var.nu_pre > 0:
-                smooth_level(top, var.nu_pre, var.lr_dir, var)
-                if loud:
-                    _log_smoothing(var, 0, top, "pre-smoothing", it)
-            sc = current_sc_dir(var.sc_dir, top.grid)
-            top.residual(store=True, norm=False)
-            coarse_correction(top.restrict_to(sc), var, var.cycmax)
-            top.prolong_from(sc)
-            if var.first_cycle and var.verb > 3:
-                var.level_all.append(0)
-            if var.nu_post > 0:
-                smooth_level(top, var.nu_post, var.lr_dir, var)
-                if loud:
-                    _log_smoothing(var, 0, top, "post-smoothing", it)
+        try:
+            _one_cycle(top, var, it, loud)
+        except BaseException:
+            if resform:        # (e, s) hold (d, r): give the caller's field and source back before unwinding
+                top.abandon_residual_equation()
+            raise
         it += 1
         var.it += 1
         if resform:
@@ -350,6 +341,29 @@ def run_cycles(top, var):
         elif terminate(var, l2_last, ring[(it - 1) % var.maxcycle], it):
             break
     var.l2 = l2_last
+
+
+def _one_cycle(top, var, it, loud):
+    """Smoothing, coarse-grid correction, smoothing on the finest level (emg3d/solver.py:512-637)."""
+    if var.clevel[var.sc_dir] == 0:            # a single level: nothing to recurse into
+        smooth_level(top, var.nu_coarse, var.lr_dir, var)
+        if loud:
+            _log_smoothing(var, 0, top, "coarsest level", it, 1)
+        return
+    if var.nu_pre > 0:
+        smooth_level(top, var.nu_pre, var.lr_dir, var)
+        if loud:
+            _log_smoothing(var, 0, top, "pre-smoothing", it)
+    sc = current_sc_dir(var.sc_dir, top.grid)
+    top.residual(store=True, norm=False)
+    coarse_correction(top.restrict_to(sc), var, var.cycmax)
+    top.prolong_from(sc)
+    if var.first_cycle and var.verb > 3:
+        var.level_all.append(0)
+    if var.nu_post > 0:
+        smooth_level(top, var.nu_post, var.lr_dir, var)
+        if loud:
+            _log_smoothing(var, 0, top, "post-smoothing", it)
 
 
 def _level0_visits(var):

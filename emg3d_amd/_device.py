@@ -205,13 +205,12 @@ class DeviceLevel:
 
     def point_factors(self):
         """Eta edge sums of the point smoother (emg3d_dev_point_setup), built on first use. Their
-        layout follows the sweep schedule of the level (option point_tile_min): kept per value of
-        that option."""
+        layout follows the sweep schedule of the level (option point_tile_min): one buffer per value
+        of that option, all kept -- graphs captured under an earlier value (``_cycle.coarse_correction``
+        keys them on the option set) still hold its buffer's address."""
         lib = _lib.lib()
         key = ('point', lib.emg3d_get_option(b'point_tile_min'))
         if key not in self._factors:
-            for k in [k for k in self._factors if isinstance(k, tuple) and k[0] == 'point']:
-                del self._factors[k]
             fac = torch.empty(lib.emg3d_point_fac_bytes_lv(self._cref), dtype=torch.uint8, device=self.device)
             _lib.check(lib.emg3d_dev_point_setup(self._cref, _ptr(fac), _stream()),
                        'emg3d_dev_point_setup')
@@ -282,6 +281,13 @@ class DeviceLevel:
             _ptr(w.ws), _ptr(w.ws), w.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
         _lib.check(_lib.lib().emg3d_dev_copy(_ptr(self.s), _ptr(self._b_kept), self.s.numel() * self.s.element_size(),
                                              _stream()), 'emg3d_dev_copy')
+
+    def abandon_residual_equation(self):
+        """A cycle in residual form was interrupted: e <- e_kept, s <- the solve's source."""
+        nbytes = self.e.numel() * self.e.element_size()
+        cp = _lib.lib().emg3d_dev_copy
+        _lib.check(cp(_ptr(self.e), _ptr(self._x_kept), nbytes, _stream()), 'emg3d_dev_copy')
+        _lib.check(cp(_ptr(self.s), _ptr(self._b_kept), nbytes, _stream()), 'emg3d_dev_copy')
 
     def residual(self, store=True, norm=False):
         """r = s - A e into self.r (store) and/or its l2-norm (norm; synchronises)."""

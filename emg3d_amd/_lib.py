@@ -56,6 +56,8 @@ SIGNATURES = {
     'emg3d_device_count': (_ci, []),
     'emg3d_set_option': (_ci, [ctypes.c_char_p, _ci]),
     'emg3d_get_option': (_ci, [ctypes.c_char_p]),
+    'emg3d_option_count': (_ci, []),
+    'emg3d_option_name': (ctypes.c_char_p, [_ci]),
     'emg3d_core_amat_x': (_ci, [_vp] * 13 + [_ci] * 4),
     'emg3d_core_gauss_seidel': (_ci, [_ci] + [_vp] * 13 + [_ci] * 5),
     'emg3d_core_restrict': (_ci, [_vp] * 15 + [_ci] * 5),
@@ -124,6 +126,13 @@ def check(status, what=''):
         msg = lib().emg3d_last_error()
         raise Emg3dAmdError(f"{what} failed with status {status}: "
                             f"{msg.decode() if msg else ''}")
+
+
+def options_fingerprint():
+    """Current values of all run-time options of the library, in its own order (part of the key of
+    everything that is built under them: captured graphs, option-dependent factor buffers)."""
+    L = lib()
+    return tuple(L.emg3d_get_option(L.emg3d_option_name(i)) for i in range(L.emg3d_option_count()))
 
 
 def require_gpu():

@@ -1414,43 +1414,35 @@ extern "C" {
 int emg3d_version(void) { return EMG3D_AMD_VERSION; }
 const char *emg3d_last_error(void) { return g_err.c_str(); }
 
+// run-time options: name -> variable (documented where the variables are declared)
+struct OptionEntry { const char *name; int *value; };
+static const OptionEntry g_options[] = {
+    {"point_slab", &g_point_slab},       {"point_tile_min", &g_point_tile_min}, {"line_fuse", &g_line_fuse},
+    {"line_fuse_max", &g_line_fuse_max}, {"skip_repeat", &g_skip_repeat},       {"tile_fuse", &g_tile_fuse},
+    {"line_lds", &g_line_lds},           {"point_prefetch", &g_point_prefetch}, {"residual_zb", &g_residual_zb},
+    {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
+};
+constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
+
+int emg3d_option_count(void) { return N_OPTIONS; }
+const char *emg3d_option_name(int i) { return (i >= 0 && i < N_OPTIONS) ? g_options[i].name : nullptr; }
+
 int emg3d_set_option(const char *name, int value)
 {
     if (!name) return fail(EMG3D_ERR_BADARG, "set_option: null name");
-    if (!std::strcmp(name, "point_slab")) { g_point_slab = value; return 0; }
-    if (!std::strcmp(name, "point_tile_min")) { g_point_tile_min = value; return 0; }
-    if (!std::strcmp(name, "line_fuse")) { g_line_fuse = value; return 0; }
-    if (!std::strcmp(name, "line_fuse_max")) { g_line_fuse_max = value; return 0; }
-    if (!std::strcmp(name, "skip_repeat")) { g_skip_repeat = value; return 0; }
-    if (!std::strcmp(name, "tile_fuse")) { g_tile_fuse = value; return 0; }
-    if (!std::strcmp(name, "line_lds")) { g_line_lds = value; return 0; }
-    if (!std::strcmp(name, "point_prefetch")) { g_point_prefetch = value; return 0; }
-    if (!std::strcmp(name, "residual_zb")) { g_residual_zb = value > 0 ? value : 1; return 0; }
-    if (!std::strcmp(name, "line_occ2")) { g_line_occ2 = value; return 0; }
-    if (!std::strcmp(name, "point_small")) { g_point_small = value; return 0; }
-    if (!std::strcmp(name, "line_lpw")) {
-        if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32)
-            return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8, 16 or 32");
-        g_line_lpw = value;
-        return 0;
-    }
+    if (!std::strcmp(name, "residual_zb") && value < 1) value = 1;
+    if (!std::strcmp(name, "line_lpw") && value != 0 && value != 4 && value != 8 && value != 16 && value != 32)
+        return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8, 16 or 32");
+    for (const OptionEntry &o : g_options)
+        if (!std::strcmp(name, o.name)) { *o.value = value; return 0; }
     return fail(EMG3D_ERR_BADARG, "set_option: unknown option");
 }
 
 int emg3d_get_option(const char *name)
 {
-    if (name && !std::strcmp(name, "point_slab")) return g_point_slab;
-    if (name && !std::strcmp(name, "point_tile_min")) return g_point_tile_min;
-    if (name && !std::strcmp(name, "line_fuse")) return g_line_fuse;
-    if (name && !std::strcmp(name, "line_fuse_max")) return g_line_fuse_max;
-    if (name && !std::strcmp(name, "skip_repeat")) return g_skip_repeat;
-    if (name && !std::strcmp(name, "tile_fuse")) return g_tile_fuse;
-    if (name && !std::strcmp(name, "line_lds")) return g_line_lds;
-    if (name && !std::strcmp(name, "point_prefetch")) return g_point_prefetch;
-    if (name && !std::strcmp(name, "residual_zb")) return g_residual_zb;
-    if (name && !std::strcmp(name, "line_occ2")) return g_line_occ2;
-    if (name && !std::strcmp(name, "point_small")) return g_point_small;
-    if (name && !std::strcmp(name, "line_lpw")) return g_line_lpw;
+    if (name)
+        for (const OptionEntry &o : g_options)
+            if (!std::strcmp(name, o.name)) return *o.value;
     return -1;
 }
 

@@ -155,6 +155,11 @@ def misfit_and_gradient(model, sources, frequencies, receivers, observed, weight
         residual = synthetic - obs
         have = ~np.isnan(residual)
         misfit += float(np.sum(w[have] * (residual[have].conj() * residual[have])).real) / 2
+        if not np.any(have & (residual != 0)):
+            # no data (or a perfect fit) for this pair: no residual source, nothing back-propagated,
+            # no contribution (the reference drops such pairs, emg3d/simulations.py:1120-1190)
+            info[(sname, fname)] = {'forward': finfo, 'backward': None, 'synthetic': synthetic}
+            continue
         rfield = residual_source_field(grid, freq, receivers, residual, w, mag)
         _, binfo = solver.solve(gmodel, rfield, return_info=True, always_return=True, hierarchy=hier, _download=False,
                                 _sparse_source=True, **{**opts, 'tol': tol_gradient})

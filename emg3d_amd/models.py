@@ -51,6 +51,12 @@ class Model:
                      (True, True): 'triaxial'}[(self.property_y is not None,
                                                 self.property_z is not None)]
 
+    def __setattr__(self, name, value):
+        # a replaced property array invalidates its HBM snapshot (parallel.broadcast_model)
+        if name in ('property_x', 'property_y', 'property_z', 'mu_r', 'epsilon_r'):
+            self.__dict__.get('_device_props', {}).pop(name, None)
+        object.__setattr__(self, name, value)
+
     def _init(self, value, name):
         if value is None:
             return None

@@ -106,7 +106,11 @@ def broadcast_model(model, src=0, device=None):
 
     Metadata (grid widths, origin, mapping, which properties exist) goes as one small
     pickled object; each property array (float64, nx*ny*nz) is ONE broadcast of the raw
-    buffer. `model` may be None on ranks != src."""
+    buffer. `model` may be None on ranks != src. With a CUDA `device` the received arrays also
+    stay in HBM (``_device_props`` of the RETURNED model, which ``VolumeModel.device_arrays``
+    starts from): a snapshot of the properties at the time of the call -- the returned object is
+    meant for the solves of that call (``compute``); replacing one of its property arrays drops
+    the array's device copy, edits in place are not seen."""
     import torch
     from emg3d_amd import meshes, models
     dist = _dist()
@@ -139,7 +143,14 @@ def broadcast_model(model, src=0, device=None):
             kw[n] = t.cpu().numpy().reshape(grid.shape_cells, order='F')
     if rank != src:
         model = models.Model(grid, mapping=meta['mapping'], **kw)
-    model._device_props = dev
+    else:
+        # the caller's model is not touched: the HBM copies are a snapshot of its arrays NOW, and
+        # an update of the model (an inversion step, an air layer written in place) followed by a
+        # direct solve must see the host arrays. The snapshot travels on a shallow copy that
+        # shares the arrays and lives as long as the caller keeps it (``compute``: one call).
+        import copy
+        model = copy.copy(model)
+    model.__dict__['_device_props'] = dev
     return model
 
 

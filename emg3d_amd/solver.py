@@ -60,19 +60,16 @@ def _residual_form(choice, var, model, sfield):
     # (cheap on purpose: two reductions per property array -- the smallest conductivity of the model
     # with the smallest cell width, whether or not they meet in one cell)
     hmin = min(float(np.min(h)) for h in model.grid.h)
-    names = ('property_x', 'property_y', 'property_z')
-    key = (model.mapping,) + tuple(id(getattr(model, n)) for n in names)
-    cached = model.__dict__.get('_sigma_min')            # (the arrays of a model are replaced, not edited)
+    # (not cached: models are edited in place -- `model.property_x[:, :, -1] = 1e8` adds the air
+    # layer this rule exists for -- and two reductions per array cost 5 ms at 128^3)
+    sig = np.inf
     with np.errstate(divide='ignore', over='ignore', invalid='ignore'):
-        if cached is None or cached[0] != key:
-            sig = np.inf
-            for name in names:
-                prop = getattr(model, name)
-                if prop is not None:
-                    ends = models._MAPS[model.mapping](np.array([np.min(prop), np.max(prop)], dtype=float))
-                    sig = min(sig, float(np.min(ends)))
-            cached = model.__dict__['_sigma_min'] = (key, sig)
-        cond = np.float64(1.0) / np.float64(abs(complex(sfield.sval)) * fields.MU_0 * cached[1] * hmin ** 2)
+        for name in ('property_x', 'property_y', 'property_z'):
+            prop = getattr(model, name)
+            if prop is not None:
+                ends = models._MAPS[model.mapping](np.array([np.min(prop), np.max(prop)], dtype=float))
+                sig = min(sig, float(np.min(ends)))
+        cond = np.float64(1.0) / np.float64(abs(complex(sfield.sval)) * fields.MU_0 * sig * hmin ** 2)
     return bool(np.isfinite(cond) and np.finfo(float).eps * cond > 0.01 * var.tol)
 
 
@@ -142,6 +139,11 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     _log_table_head(var)
     if extra['hierarchy'] is not None:
         extra['hierarchy'].check(vmodel)
+        if not var.sslsolver and not var.cycle:
+            # nothing to iterate (zero source / start field already good enough): the hierarchy's
+            # field must still be THIS solve's result -- receivers and the gradient read it from
+            # HBM, where the previous pair's field would otherwise linger
+            extra['hierarchy'].upload_field(efield)
     if var.sslsolver:
         krylov(vmodel, sfield, efield, var, hierarchy=extra['hierarchy'])
     elif var.cycle:
@@ -512,6 +514,9 @@ class Hierarchy:
 
     def upload(self, sfield, efield, sparse=False):
         self.put_source(sfield, self.top.s, sparse)
+        self.upload_field(efield)
+
+    def upload_field(self, efield):
         if getattr(efield, '_is_zero', False):
             self.top.zero_field()        # the start field solve() made itself: nothing to send
         else:
@@ -577,9 +582,15 @@ def krylov(model, sfield, efield, var, hierarchy=None):
         status = _krylov_on_device(device_solver, hier, sfield, efield, var)
     except _ConvergenceError:            # the preconditioner diverged or stagnated
         status = -1
-        efield.field[:] = 0
-        hier.top.zero_field()            # responses taken from the device field are those of the zero field too
-        var.exit_message += " (returned field is zero)"
+        var.exit_message += " (returned field is zero)"      # (the reference's message, emg3d/solver.py:767-770)
+        if getattr(efield, '_is_zero', False):
+            # the zero field solve() made itself is what comes back
+            efield.field[:] = 0
+            hier.top.zero_field()        # responses taken from the device field are those of the zero field too
+        else:
+            # a start field the caller provided stays what it was (SciPy iterates on a copy in the
+            # reference, the assignment never happens); the device field follows it
+            hier.upload_field(efield)
 
     outcome = {True: "CONVERGED", False: "MAX. ITERATION REACHED, NOT CONVERGED"}
     if status >= 0:

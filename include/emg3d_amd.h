@@ -103,6 +103,10 @@ int emg3d_device_count(void);
  * sweeps meet run both sweeps on one LDS copy (same operations, one load / store less). */
 int emg3d_set_option(const char *name, int value);
 int emg3d_get_option(const char *name);
+/* enumeration of the options (for callers that key cached state -- captured graphs, option-
+ * dependent buffers -- on the whole option set): names 0 .. emg3d_option_count()-1 */
+int emg3d_option_count(void);
+const char *emg3d_option_name(int i);
 
 /* ---------------------------------------------------------------- host flavour ---- */
 

@@ -15,6 +15,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: more than a minute of oracle (CPU) time; part of -m gpu")
 
 
 @pytest.fixture(scope='session')

@@ -1169,6 +1169,7 @@ def test_full_size_per_sweep_parity_vs_oracle(shape, case):
     ((128, 96, 96), 1), ((96, 128, 96), 2), ((96, 96, 130), 3),        # 16 lines / workgroup, partial-LDS records
     ((256, 96, 96), 1), ((96, 258, 96), 2), ((96, 96, 256), 3),        # records in the global scratch
     ((130, 6, 10), 1), ((6, 256, 10), 2), ((10, 6, 129), 3),           # long lines, few of them (4 lines / workgroup)
+    ((384, 6, 10), 1), ((384, 96, 96), 1),                             # the x-lines of config 5 (384 x 256 x 256)
 ])
 @pytest.mark.parametrize('dtype', [complex, float])
 def test_long_line_record_modes_vs_oracle(shape, lr, dtype):
@@ -1245,6 +1246,144 @@ def test_bench_workloads_converged_vs_oracle(name):
     assert info['it_mg'] <= int(np.ceil(1.6 * io['it_mg']))
 
 
+def _one_cycle_vs_oracle(name, source_index=0):
+    """ONE multigrid cycle of a bench workload, exactly as bench.py builds it, on the GPU and with the
+    oracle's driver in the same smoother ordering: every level, transfer and smoother call (through
+    the captured-graph path's eager first occurrence) of the cycle the bench times."""
+    from bench import workload
+    wl = workload(name, source_index=source_index)
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-30, maxit=1, return_info=True, **wl['opts'])
+    assert info['it_mg'] == 1
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in wl['res'].items()}
+    vm = mg_ref.volume_model(ogrid, wl['frequency'], cond['property_x'], cond.get('property_y'), cond.get('property_z'))
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-30, maxit=1, order=1, **wl['opts'])
+    assert io['it_mg'] == 1
+    assert relerr(e.field, eo.field) < 1e-10
+    assert info['abs_error'] == pytest.approx(io['abs_error'], rel=1e-9)
+    assert info['smoother_cell_sweeps'] == io['smooth_work']
+
+
+@pytest.mark.slow
+def test_triaxial256_one_cycle_vs_oracle_same_order():
+    """BASELINE.json config 3 at full size -- the workload `bench.py` times by default: one W-cycle
+    with semicoarsening and line relaxation (every semicoarsened level down to 256 x 2 x 2) against the
+    oracle in the same ordering; ~1.5 min of oracle time."""
+    _one_cycle_vs_oracle('triaxial256')
+
+
+@pytest.mark.slow
+def test_salt384_one_cycle_vs_oracle_same_order():
+    """BASELINE.json config 5 at its real shape (384 x 256 x 256: 384-block x-lines), pair 7 (2 Hz,
+    the source at x = +2000 m): one F-cycle against the oracle in the same ordering."""
+    _one_cycle_vs_oracle('salt384', source_index=7)
+
+
+@pytest.mark.parametrize('pair', [3, 5, 6])
+def test_salt96_other_pairs_converged_vs_oracle(pair):
+    """Config 5's other (source, frequency) pairs on the quarter-size copy (pair 0 is in
+    test_bench_workloads_converged_vs_oracle): 0.5 Hz / x = +2000 m, 1 Hz / +2000 m, 2 Hz / -2000 m
+    -- with pair 0, all four frequencies and both sources; converged against the lexicographic
+    oracle at 1e-8."""
+    from bench import workload
+    wl = workload('salt96', source_index=pair)
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **wl['opts'])
+    assert info['exit'] == 0, info['exit_message']
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    vm = mg_ref.volume_model(ogrid, wl['frequency'], 1.0 / wl['res']['property_x'])
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **wl['opts'])
+    assert io['exit'] == 0
+    assert relerr(e.field, eo.field) < 1e-8
+    assert info['it_mg'] <= int(np.ceil(1.6 * io['it_mg']))
+
+
+@pytest.mark.slow
+def test_config4_eight_sources_batch_equals_separate_and_oracle():
+    """BASELINE.json config 4 on one GPU: the 8 sources of the 128^3 marine model solved together
+    (solve_batch) give bit for bit the fields, cycle counts and error histories of 8 separate
+    solves; source 7 (x = +1400 m, the one farthest from the single-source bench workload) agrees
+    with the oracle's converged field (lexicographic order, both at tol 1e-9) to 1e-8."""
+    from bench import workload
+    wls = [workload('marine128', source_index=i) for i in range(8)]
+    grid = emg3d.TensorMesh(wls[0]['h'], wls[0]['origin'])
+    model = emg3d.Model(grid, **wls[0]['res'])
+    opts = dict(wls[0]['opts'], tol=1e-9)
+    sfields = [emg3d.get_source_field(grid, w['source'], w['frequency']) for w in wls]
+    assert len({w['source'] for w in wls}) == 8
+    hier = solver.Hierarchy(emg3d.models.VolumeModel(model, sfields[0]))
+    sep = [emg3d.solve(model, sf, sslsolver=False, return_info=True, hierarchy=hier, **opts) for sf in sfields]
+    del hier
+    torch.cuda.empty_cache()
+    bat = emg3d.solve_batch(model, sfields, **opts)
+    for (e1, i1), (e2, i2) in zip(sep, bat):
+        assert i1['exit'] == i2['exit'] == 0 and i1['it_mg'] == i2['it_mg']
+        assert np.array_equal(i1['error_at_cycle'], i2['error_at_cycle'])
+        assert np.array_equal(e1.field, e2.field)
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in wls[7]['res'].items()}
+    vm = mg_ref.volume_model(ogrid, 1.0, cond['property_x'], None, cond['property_z'])
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfields[7].field.copy()), **opts)
+    assert io['exit'] == 0
+    assert relerr(sep[7][0].field, eo.field) < 1e-8
+
+
+def test_hierarchy_field_follows_a_solve_that_has_nothing_to_do():
+    """A solve that takes the zero-source / already-converged shortcut on a reused hierarchy must
+    leave THIS solve's field in HBM (receivers and the gradient read it there), not the previous
+    pair's; and a pair without data contributes nothing to the gradient."""
+    from emg3d_amd import gradient
+    hx = widths(8, 2, 50., 1.3)
+    grid = emg3d.TensorMesh([hx, hx, hx], (-hx.sum() / 2,) * 3)
+    model = emg3d.Model(grid, 1.0)
+    sfield = emg3d.get_source_field(grid, (0., 0., 0., 0., 0.), 1.0)
+    hier = solver.Hierarchy(emg3d.models.VolumeModel(model, sfield))
+    emg3d.solve(model, sfield, sslsolver=False, hierarchy=hier)
+    assert float(hier.top.e.abs().max()) > 0
+    zero = emg3d.Field(grid, frequency=1.0)
+    e0, info = emg3d.solve(model, zero, sslsolver=False, hierarchy=hier, return_info=True)
+    assert info['exit'] == 0 and not np.any(e0.field)
+    assert float(hier.top.e.abs().max()) == 0.0
+    # gradient: one pair with data, one all-NaN pair
+    rec = [(100., 50., 20., 0., 0.), (-120., 30., -40., 90., 0.)]
+    sources = {'A': (0., 0., 0., 0., 0.), 'B': (60., -30., 10., 20., 0.)}
+    freqs = {'f': 1.0}
+    obs = {('A', 'f'): np.array([1e-11 + 2e-11j, -3e-11j]), ('B', 'f'): np.array([np.nan, np.nan])}
+    m2, g2, i2 = gradient.misfit_and_gradient(model, sources, freqs, rec, obs, solver_opts={'tol': 1e-8})
+    m1, g1, _ = gradient.misfit_and_gradient(model, {'A': sources['A']}, freqs, rec, {('A', 'f'): obs[('A', 'f')]},
+                                            solver_opts={'tol': 1e-8})
+    assert i2[('B', 'f')]['backward'] is None
+    assert m2 == pytest.approx(m1, rel=1e-12) and np.array_equal(g1, g2)
+
+
+def test_failed_krylov_leaves_a_provided_start_field_alone():
+    """A diverging / stagnating preconditioner aborts the Krylov solver: the zero field solve() made
+    itself comes back as zeros, a start field the caller provided is not overwritten
+    (emg3d/solver.py:764-770: SciPy works on a copy, the assignment never happens)."""
+    hx = widths(8, 2, 50., 1.3)
+    grid = emg3d.TensorMesh([hx, hx, hx], (-hx.sum() / 2,) * 3)
+    model = emg3d.Model(grid, 1.0)
+    sfield = emg3d.get_source_field(grid, (0., 0., 0., 0., 0.), 1.0)
+    rng = np.random.default_rng(3)
+    start = emg3d.Field(grid, frequency=1.0)
+    start.field[:] = 1e-9 * (rng.standard_normal(start.field.size) + 1j * rng.standard_normal(start.field.size))
+    # gcrotmk preconditions unit-norm vectors: the multigrid's divergence rule aborts the first call
+    # (the first call also zeroes the PEC faces of the start field, emg3d/solver.py:349-355)
+    for attempt in range(2):
+        before = start.field.copy()
+        info = emg3d.solve(model, sfield, efield=start, sslsolver='gcrotmk', return_info=True)
+        assert info['exit'] == 1 and 'returned field is zero' in info['exit_message']
+        assert np.any(start.field)
+    assert np.array_equal(start.field, before)
+    e, info = emg3d.solve(model, sfield, sslsolver='gcrotmk', return_info=True)
+    assert info['exit'] == 1 and not np.any(e.field)
+
+
 @pytest.mark.parametrize('method', ['bicgstab', 'cgs', 'gcrotmk', 'gcrotmk(1,1)'])
 @pytest.mark.parametrize('dtype', [complex, float])
 def test_device_krylov_matches_scipy_iteration(method, dtype, monkeypatch):
@@ -1319,15 +1458,20 @@ def test_device_krylov_matches_scipy_iteration(method, dtype, monkeypatch):
     assert relerr(e.field, x) < 1e-9
 
 
-def test_bench_two_ranks_through_its_own_launcher():
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_bench_two_ranks_through_its_own_launcher(backend):
     """`python bench.py --gpus 2` as a driver would call it: bench.py spawns its two ranks itself
-    (torch.distributed.run on 127.0.0.1), the ranks share this box's one GPU and run their
-    collectives over gloo (EMG3D_BENCH_BACKEND) -- rank-dependent source, model broadcast, barrier,
-    MAX / SUM reductions and the rank-0 JSON line of the multi-GPU path."""
+    (torch.distributed.run on 127.0.0.1). 'gloo': the ranks share this box's one GPU and run their
+    collectives over gloo (EMG3D_BENCH_BACKEND); 'nccl' (needs two GPUs, skipped otherwise): one rank
+    per GPU over RCCL, the property arrays broadcast device to device. Either way the product's
+    multi-GPU path: parallel.init, parallel.broadcast_model (rank 1 never builds the model), rank-
+    dependent source, barrier, MAX / SUM reductions and the rank-0 JSON line."""
     import json
     import subprocess
     import sys
-    env = dict(os.environ, EMG3D_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL leg needs two GPUs on the box")
+    env = dict(os.environ, EMG3D_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'marine64',
@@ -1339,6 +1483,7 @@ def test_bench_two_ranks_through_its_own_launcher():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
     assert out['config']['workload'] == 'marine64' and out['value'] > 0
+    assert out['config']['broadcast_ms'] > 0 and backend in out['config']['model_distribution']
     # two independent sources: twice the cell-sweeps of one rank per step
     assert out['config']['cell_sweeps_per_step'] > 0
     assert out['value'] == pytest.approx(2 * out['config']['cell_sweeps_per_step'] * 3 / (out['ms_per_step'] * 3e-3) / 1e6, rel=0.02)
