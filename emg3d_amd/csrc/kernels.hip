@@ -93,6 +93,10 @@ int g_line_occ2 = 0;
 int g_point_small = 512;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
+// TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
+// the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
+// never left the chip
+int g_line_debug = 0;
 
 // eta edge sums of the tiled point smoother: 8-byte storage (launch.h: tile_pst_*) for real
 // fields and for complex fields whose eta are purely imaginary (emg3d_level::flags)
@@ -895,7 +899,8 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
         dum = lvec + (size_t)lpw * (sp.khi - sp.klo) * 4;
         dum4 = dummy;
     } else {
-        V = VecRef<T>::global(vec, nlines);
+        // (vstride == ~0 in a single-source launch: the debug aliasing of option line_debug)
+        V = VecRef<T>::global(vec, (!BATCH && vstride == ~(size_t)0) ? 0 : nlines);
         dum = dum4 = dummy;
     }
     // (1) right-hand sides of the workgroup's lines; x-lines run the lanes along the line
@@ -1101,7 +1106,8 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                c, lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                  \
         else                                                                                                             \
             hipLaunchKernelGGL((k_line_colour<T, DIR, VM, false, QDV>), dim3(nwg), dim3(LC_THREADS), SMEM, st, L, c,      \
-                               lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                     \
+                               lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off,                               \
+                               (VM == 0 && (g_line_debug & 1)) ? ~(size_t)0 : vstride);                                  \
     } while (0)
         if (shortl) {              // (records of <= 6 blocks: a few KB, they fit whenever LDS records are on)
             if (fits(smem1))
@@ -1286,8 +1292,10 @@ int launch_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double 
     emg::Level<T> L = to_level<T>(lv);
     const dim3 block = d3(emg::cell_block());
     dim3 grid = d3(emg::cell_grid(L.nx + 1, L.ny + 1, L.nz + 1));
-    // planes per workgroup: 8 where that still leaves every CU several workgroups, else 1
-    const int zb = (size_t)grid.x * grid.y * (grid.z / g_residual_zb) * L.batch >= 8u * (unsigned)compute_units() ? g_residual_zb : 1;
+    // planes per workgroup: 8 where that still leaves every CU several workgroups, else 1. Decided
+    // per right-hand side: the blocking fixes the summation order of the norm, and a source must get
+    // the same bits whether it is solved alone or in a batch
+    const int zb = (size_t)grid.x * grid.y * (grid.z / g_residual_zb) >= 8u * (unsigned)compute_units() ? g_residual_zb : 1;
     grid.z = cdiv((int)grid.z, zb);
     const size_t nblk = (size_t)grid.x * grid.y * grid.z;       // per right-hand side
     if (sumsq && (ws == nullptr || ws_len < nblk * L.batch)) return fail(EMG3D_ERR_SCRATCH, "residual: workspace too small");
@@ -1421,6 +1429,7 @@ static const OptionEntry g_options[] = {
     {"line_fuse_max", &g_line_fuse_max}, {"skip_repeat", &g_skip_repeat},       {"tile_fuse", &g_tile_fuse},
     {"line_lds", &g_line_lds},           {"point_prefetch", &g_point_prefetch}, {"residual_zb", &g_residual_zb},
     {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
+    {"line_debug", &g_line_debug},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 

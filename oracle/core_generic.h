@@ -28,6 +28,10 @@
 #define EX(a, i, j, k) (a)[(size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)(ny + 1) * (size_t)(k))]
 #define EY(a, i, j, k) (a)[(size_t)(i) + (size_t)(nx + 1) * ((size_t)(j) + (size_t)ny * (size_t)(k))]
 #define EZ(a, i, j, k) (a)[(size_t)(i) + (size_t)(nx + 1) * ((size_t)(j) + (size_t)(ny + 1) * (size_t)(k))]
+/* in-pass over-relaxation (experiments only; oracle_omega = 1: plain assignment, the reference) */
+#ifndef RELAX
+#define RELAX(dst, val) do { if (oracle_omega == 1.0) (dst) = (val); else (dst) = (dst) + oracle_omega * ((val) - (dst)); } while (0)
+#endif
 #define CC(a, i, j, k) (a)[(size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)ny * (size_t)(k))]
 
 /* ------------------------------------------------------------------------- */
@@ -314,12 +318,12 @@ static void FN(gs_node)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
     FN(solve)(amat, rhs, 6);
 
     /* core.py:498-503 */
-    EX(ex, ixm, iy, iz) = rhs[0];
-    EX(ex, ix, iy, iz) = rhs[1];
-    EY(ey, ix, iym, iz) = rhs[2];
-    EY(ey, ix, iy, iz) = rhs[3];
-    EZ(ez, ix, iy, izm) = rhs[4];
-    EZ(ez, ix, iy, izm + 1) = rhs[5];
+    RELAX(EX(ex, ixm, iy, iz), rhs[0]);
+    RELAX(EX(ex, ix, iy, iz), rhs[1]);
+    RELAX(EY(ey, ix, iym, iz), rhs[2]);
+    RELAX(EY(ey, ix, iy, iz), rhs[3]);
+    RELAX(EZ(ez, ix, iy, izm), rhs[4]);
+    RELAX(EZ(ez, ix, iy, izm + 1), rhs[5]);
 }
 
 /* core.gauss_seidel -- reference emg3d/core.py:210-503 */
@@ -479,12 +483,12 @@ static void FN(gs_line_x)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T
 
     for (ixh = 1; ixh < nx + 1; ixh++) {
         int ixm = ixh - 1;
-        EX(ex, ixm, iy, iz) = bvec[5 * ixm];
+        RELAX(EX(ex, ixm, iy, iz), bvec[5 * ixm]);
         if (ixm < nx - 1) {
-            EY(ey, ixh, iym, iz) = bvec[1 + 5 * ixm];
-            EY(ey, ixh, iy, iz) = bvec[2 + 5 * ixm];
-            EZ(ez, ixh, iy, izm) = bvec[3 + 5 * ixm];
-            EZ(ez, ixh, iy, iz) = bvec[4 + 5 * ixm];
+            RELAX(EY(ey, ixh, iym, iz), bvec[1 + 5 * ixm]);
+            RELAX(EY(ey, ixh, iy, iz), bvec[2 + 5 * ixm]);
+            RELAX(EZ(ez, ixh, iy, izm), bvec[3 + 5 * ixm]);
+            RELAX(EZ(ez, ixh, iy, iz), bvec[4 + 5 * ixm]);
         }
     }
 }
@@ -624,12 +628,12 @@ static void FN(gs_line_y)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T
 
     for (iyh = 1; iyh < ny + 1; iyh++) {
         int iym = iyh - 1;
-        EY(ey, ix, iym, iz) = bvec[5 * iym];
+        RELAX(EY(ey, ix, iym, iz), bvec[5 * iym]);
         if (iym < ny - 1) {
-            EX(ex, ixm, iyh, iz) = bvec[1 + 5 * iym];
-            EX(ex, ix, iyh, iz) = bvec[2 + 5 * iym];
-            EZ(ez, ix, iyh, izm) = bvec[3 + 5 * iym];
-            EZ(ez, ix, iyh, iz) = bvec[4 + 5 * iym];
+            RELAX(EX(ex, ixm, iyh, iz), bvec[1 + 5 * iym]);
+            RELAX(EX(ex, ix, iyh, iz), bvec[2 + 5 * iym]);
+            RELAX(EZ(ez, ix, iyh, izm), bvec[3 + 5 * iym]);
+            RELAX(EZ(ez, ix, iyh, iz), bvec[4 + 5 * iym]);
         }
     }
 }
@@ -768,12 +772,12 @@ static void FN(gs_line_z)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T
 
     for (izh = 1; izh < nz + 1; izh++) {
         int izm = izh - 1;
-        EZ(ez, ix, iy, izm) = bvec[5 * izm];
+        RELAX(EZ(ez, ix, iy, izm), bvec[5 * izm]);
         if (izm < nz - 1) {
-            EX(ex, ixm, iy, izh) = bvec[1 + 5 * izm];
-            EX(ex, ix, iy, izh) = bvec[2 + 5 * izm];
-            EY(ey, ix, iym, izh) = bvec[3 + 5 * izm];
-            EY(ey, ix, iy, izh) = bvec[4 + 5 * izm];
+            RELAX(EX(ex, ixm, iy, izh), bvec[1 + 5 * izm]);
+            RELAX(EX(ex, ix, iy, izh), bvec[2 + 5 * izm]);
+            RELAX(EY(ey, ix, iym, izh), bvec[3 + 5 * izm]);
+            RELAX(EY(ey, ix, iy, izh), bvec[4 + 5 * izm]);
         }
     }
 }

@@ -34,6 +34,12 @@ int oracle_tile_order[8] = {0, 7, 1, 6, 2, 5, 3, 4};   /* complementary colours 
 void oracle_set_tile(int bx, int by, int bz) { oracle_tile[0] = bx; oracle_tile[1] = by; oracle_tile[2] = bz; }
 void oracle_set_tile_order(const int *o) { int i; for (i = 0; i < 8; i++) oracle_tile_order[i] = o[i]; }
 
+/* Over-relaxation INSIDE the colour passes / sweeps (an experiment of the oracle, not in the
+ * reference, which notes the possibility at emg3d/core.py:774): every solved edge value is written as
+ * old + omega (new - old). 1.0 = the reference's plain Gauss-Seidel update. */
+double oracle_omega = 1.0;
+void oracle_set_omega(double w) { oracle_omega = w; }
+
 #define PASTE_(a, b) a##b
 #define PASTE(a, b) PASTE_(a, b)
 
