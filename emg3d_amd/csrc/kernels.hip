@@ -93,6 +93,11 @@ int g_line_occ2 = 0;
 int g_point_small = 512;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
+// the largest levels (records not, or not completely, in LDS): k_line_stream -- right-hand sides
+// produced into an LDS ring by the helper waves while the chain waves substitute (1, default); 0:
+// k_line_colour everywhere
+int g_line_stream = 1;
+int g_line_stream_r = 0;           // rows per chunk of the ring (0: 16)
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
@@ -451,13 +456,15 @@ template <class T> struct QuadRow {
         b04 = lf[3];
         d4 = lf[7];
     }
-    template <class A> __device__ __forceinline__ void load(const A &a, int k)
+    // RECS = false: factors and coupling only (the streamed kernel takes its right-hand sides from LDS)
+    template <class A, bool RECS = true> __device__ __forceinline__ void load(const A &a, int k)
     {
         const char *f = a.fac + (size_t)k * a.frow, *lf = a.lfac + (size_t)k * a.lrow;
 #pragma unroll
         for (int r = 0; r < 5; ++r) t[r] = *reinterpret_cast<const T *>(f + a.ft[r]);
         t44 = *reinterpret_cast<const T *>(f + a.ft[5]);
-        if constexpr (A::split) {
+        if constexpr (!RECS) {
+        } else if constexpr (A::split) {
             // split records: the slot is in LDS or in the global scratch, depending on the row --
             // both are read (the one that does not apply at a fixed valid address), no branch
             const bool in = a.in_lds(k);
@@ -468,7 +475,7 @@ template <class T> struct QuadRow {
         } else {
             v = *a.pvj(k);
         }
-        v4 = *a.pv4(k);
+        if constexpr (RECS) v4 = *a.pv4(k);
         bA = *reinterpret_cast<const double *>(lf + a.la);
         bD = *reinterpret_cast<const double *>(lf + a.ld);
         b04 = *reinterpret_cast<const double *>(lf + a.l04);
@@ -608,6 +615,25 @@ template <class T, int HALF, bool SPLIT = false> struct LaneAddr {
 // branches around memory operations the compiler's s_waitcnt insertion falls back to
 // vmcnt(0) at the loop head and drains the prefetch ring every iteration. Quads beyond the
 // last line walk the last line again but store into a dummy area behind the records.
+// One block step of a forward half-chain: (v, v4) = this lane's right-hand-side entries j and 4 of
+// the block, q its factor record; updates the carried (wsel, w4p), returns w_j and w_4.
+template <class T>
+__device__ __forceinline__ void quad_forward_step(const QuadRow<T> &q, const T v, const T v4, const double nz,
+                                                  const double is0, T &wsel, T &w4p, T &wn, T &w4)
+{
+    // c_j = rhs_j - (B w_prev)_j ; row 0: the row sum ; row j: B(j,j) w_j
+    const T rowsum = quad_sum(q.bA * wsel);
+    const T cj = emg::nmad(q.bD * nz, wsel, emg::nmad(is0, rowsum, v));
+    const T c4 = v4 - q.d4 * w4p;
+    const T c1 = quad_rot<1>(cj), c2 = quad_rot<2>(cj), c3 = quad_rot<3>(cj);
+    // w_j = sum_m T(j,m) c_m ; w_4 from the partial products T(j,4) c_j
+    // two accumulators, four fused multiply-adds per complex product (cplx.h: mad)
+    wn = emg::mad(q.t[4], c4, emg::mad(q.t[1], c1, q.t[0] * cj)) + emg::mad(q.t[3], c3, q.t[2] * c2);
+    w4 = emg::mad(q.t44, c4, quad_sum(q.t[4] * cj));
+    wsel = nz * wn + is0 * w4;
+    w4p = w4;
+}
+
 template <class T, int HALF, int QD, bool SPLIT = false>
 __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int qend, int j, const T *fac,
                                              const double *lfac, const VecRef<T> V, T *dummy, T *dummy4)
@@ -636,17 +662,8 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
         for (int d = 0; d < QD; ++d) {
             const int k = W.fwd(i0 + d);
             const QuadRow<T> &q = ring[d];
-            // c_j = rhs_j - (B w_prev)_j ; row 0: the row sum ; row j: B(j,j) w_j
-            const T rowsum = quad_sum(q.bA * wsel);
-            const T cj = emg::nmad(q.bD * nz, wsel, emg::nmad(is0, rowsum, q.v));
-            const T c4 = q.v4 - q.d4 * w4p;
-            const T c1 = quad_rot<1>(cj), c2 = quad_rot<2>(cj), c3 = quad_rot<3>(cj);
-            // w_j = sum_m T(j,m) c_m ; w_4 from the partial products T(j,4) c_j
-            // two accumulators, four fused multiply-adds per complex product (cplx.h: mad)
-            const T wn = emg::mad(q.t[4], c4, emg::mad(q.t[1], c1, q.t[0] * cj)) + emg::mad(q.t[3], c3, q.t[2] * c2);
-            const T w4 = emg::mad(q.t44, c4, quad_sum(q.t[4] * cj));
-            wsel = nz * wn + is0 * w4;
-            w4p = w4;
+            T wn, w4;
+            quad_forward_step(q, q.v, q.v4, nz, is0, wsel, w4p, wn, w4);
             T *const o4 = active ? LA.pv4(k) : dslot4 + 4;
             if constexpr (SPLIT) {
                 // (dummy: LDS, dummy4: global -- one store into either space, the idle one to its dummy slot)
@@ -941,6 +958,153 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
     else quad_backward<T, DIR, 1, QD, BATCH, SPLIT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
+// ---- fused colour pass with STREAMED right-hand sides (the largest levels) ---------------------
+// k_line_colour runs right-hand sides, forward and backward substitution one after the other, and
+// on the levels whose records do not fit the LDS of a CU the right-hand sides make a round trip
+// through the global scratch (written by the first phase, read by the second: 160 B per block of
+// the pass's ~1450). Here the two helper waves PRODUCE the right-hand sides of the
+// next R block rows into an LDS ring while the two chain waves CONSUME the current R rows in their
+// forward half-chains: the right-hand sides never leave the CU, and their assembly (a bandwidth
+// phase) overlaps the forward substitution (a latency chain). Same arithmetic, entry by entry, as
+// k_line_colour (stencil.h: line_rhs_e0 / line_rhs_t, quad_forward_step): bit-identical results.
+//
+// LDS: ring [2 buffers][2 halves][R rows][lpw lines][5 entries] -- item (half, step i) holds the five
+// right-hand-side entries of the block that half's chain works on at step i, already in the
+// chain's grouping (bottom half = mirrored blocks: entry 0 of record row k, entries 1..4 of row
+// k - 1). The w / solution records stay in the global scratch (with them in LDS only 8 lines of 256
+// blocks fit a workgroup, and half-filled chain waves cost more than the bytes save: measured).
+// Four producer waves: with two the producers, one memory round trip per item, are what the
+// chains wait for. One workgroup barrier (LDS-only: the chains' factor prefetch stays in flight)
+// per R = 16 steps. The producers also put the raw right-hand sides of the rows the middle block
+// reads (row m, and entry 0 of row m + 1) into the records.
+template <class T, int DIR>
+__device__ __forceinline__ void stream_produce(const emg::Axes<T, DIR> &A, int colour, int cntp, int cntq, int n0p,
+                                               int line0, int nl, int lpw, T *buf, int R, int chunk, int pt, int np)
+{
+    const int n0 = A.n0();
+    const int items = 2 * R * lpw;
+    for (int it = pt; it < items; it += np) {
+        // x-lines: the lanes run along the line (the field is contiguous there); else across the lines
+        int ll, row, half;
+        if (DIR == 0) { row = it % R; ll = (it / R) % lpw; half = it / (R * lpw); }
+        else { ll = it % lpw; row = (it / lpw) % R; half = it / (R * lpw); }
+        const int i = chunk * R + row;                       // forward step of the half
+        const int k = half ? n0p - 1 - i : i;                // its block
+        const int k0 = k, kt = half ? k - 1 : k;             // record rows of entry 0 / entries 1..4
+        const int lid = line0 + min(ll, nl - 1);
+        int i1, i2, l2;
+        emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+        T rhs[5];
+        emg::line_rhs_t<T, DIR>(A, min(max(kt, 0), n0 - 1), i1, i2, rhs);
+        rhs[0] = emg::line_rhs_e0<T, DIR>(A, min(max(k0, 0), n0 - 1), i1, i2);
+        const double keep0 = (k0 >= 0 && k0 < n0) ? 1.0 : 0.0;          // identity padding blocks: rhs = 0
+        const double keept = (kt >= 0 && kt < n0) ? 1.0 : 0.0;
+        T *o = buf + ((size_t)(half * R + row) * lpw + ll) * 5;
+        o[0] = keep0 * rhs[0];
+#pragma unroll
+        for (int r = 1; r < 5; ++r) o[r] = keept * rhs[r];
+    }
+}
+
+// forward half-chain that takes its right-hand sides from the LDS ring (see k_line_stream)
+template <class T, int HALF, int QD>
+__device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
+                                                    const T *fac, const double *lfac, const VecRef<T> V, T *dummy,
+                                                    T *dummy4, const T *ringbase, int lpw, int R, int nchunks)
+{
+    const HalfWalk<HALF> W(n0, n0p);
+    const bool active = qline < qend;
+    const int line = min(qline, qend - 1);
+    const int ll = line - line0;
+    T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
+    T *const dslot4 = dummy4 + ((threadIdx.x & 63) >> 2) * 5;
+    QuadRow<T> ring[QD];
+    const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T> &q, int i) { q.template load<LaneAddr<T, HALF, false>, false>(LA, W.fwd(W.clampi(i))); };
+#pragma unroll
+    for (int d = 0; d < QD; ++d) fetch(ring[d], d);
+    __syncthreads();                                          // chunk 0 of the ring and the middle rows are there
+    T wsel = emg::zero<T>(), w4p = emg::zero<T>();
+    const double nz = j != 0 ? 1.0 : 0.0, is0 = 1.0 - nz;
+    const size_t bufelems = (size_t)2 * R * lpw * 5;
+    for (int c = 0; c < nchunks; ++c) {
+        const T *const items = ringbase + (size_t)(c & 1) * bufelems + ((size_t)(HALF * R) * lpw + ll) * 5;
+        const int iend = min((c + 1) * R, W.steps);
+        for (int i0 = c * R; i0 < iend; i0 += QD) {
+#pragma unroll
+            for (int d = 0; d < QD; ++d) {
+                const int k = W.fwd(i0 + d);
+                const QuadRow<T> &q = ring[d];
+                const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
+                const T v = it[j], v4 = it[4];
+                T wn, w4;
+                quad_forward_step(q, v, v4, nz, is0, wsel, w4p, wn, w4);
+                T *const o4 = active ? LA.pv4(k) : dslot4 + 4;
+                T *const oj = active ? LA.pvj(k) : dslot + j;
+                *oj = wn;
+                *o4 = w4;
+                fetch(ring[d], i0 + d + QD);
+            }
+        }
+        lds_barrier();                                        // this chunk is consumed, the next one produced
+    }
+}
+
+constexpr int LS_PROD = 256;                 // producer threads of k_line_stream (4 waves; + 2 chain waves)
+template <class T, int DIR, int QD = emg::LINE_PAD>
+__global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                                  int lpw, int R, const T *fac, const double *lfac,
+                                                                  T *vec, T *dummy)
+{
+    extern __shared__ double2 ls_smem[];
+    const emg::Axes<T, DIR> A(L);
+    const int n0 = A.n0();
+    const int nlines = cntp * cntq;
+    const int line0 = blockIdx.x * lpw;
+    const int nl = min(lpw, nlines - line0);
+    T *const ringbase = reinterpret_cast<T *>(ls_smem);
+    const size_t bufelems = (size_t)2 * R * lpw * 5;
+    const VecRef<T> V = VecRef<T>::global(vec, nlines);
+    const int mk = emg::line_mid(n0);
+    const int smax = max(mk, n0p - 2 - mk);
+    const int nchunks = (smax + R - 1) / R;
+    const int wave = threadIdx.x >> 6;
+    if (wave >= 2) {
+        // ---- producers
+        const int pt = threadIdx.x - 128;
+        for (int ll = pt; ll < nl; ll += LS_PROD) {
+            const int lid = line0 + ll;
+            int i1, i2, l2;
+            emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+            T rhs[5];
+            emg::line_rhs<T, DIR>(A, mk, i1, i2, rhs);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *V.p(mk, lid, r) = rhs[r];
+            *V.p4(mk, lid) = rhs[4];
+            *V.p(mk + 1, lid, 0) = emg::line_rhs_e0<T, DIR>(A, min(mk + 1, n0 - 1), i1, i2);
+        }
+        stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase, R, 0, pt, LS_PROD);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks)
+                stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + (size_t)((c + 1) & 1) * bufelems, R,
+                                       c + 1, pt, LS_PROD);
+            lds_barrier();
+        }
+        return;
+    }
+    const int half = wave & 1;
+    const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
+    const int qend = line0 + nl;
+    if (half == 0) quad_forward_stream<T, 0, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dummy, dummy, ringbase, lpw, R, nchunks);
+    else quad_forward_stream<T, 1, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dummy, dummy, ringbase, lpw, R, nchunks);
+    __syncthreads();
+    // (six waves share four SIMDs: 256 registers per lane -- the middle block is solved before the
+    // backward pass's register ring is filled, as in the batched k_line_colour)
+    if (half == 0) quad_backward<T, DIR, 0, QD, true, false>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, 0);
+    else quad_backward<T, DIR, 1, QD, true, false>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, 0);
+}
+
 // Residual + per-block partial sums of |r|^2. A workgroup walks `zb` consecutive planes: the plane
 // above the current one, fetched for the curl, is the next iteration's own plane and is still in
 // the CU's cache then -- with one plane per workgroup the three workgroups that need a plane run on
@@ -1109,6 +1273,18 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off,                               \
                                (VM == 0 && (g_line_debug & 1)) ? ~(size_t)0 : vstride);                                  \
     } while (0)
+        // the largest levels of a single-source solve: right-hand sides streamed through LDS
+        if (g_line_stream && !shortl && L.batch == 1 && !g_line_occ2 && !(g_line_debug & 1) && !fits(smem1) && lc.n0 >= 16) {
+            const int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
+            const size_t smem = (size_t)2 * 2 * R * lpw * 5 * sizeof(T);
+            const void *kern = (const void *)&k_line_stream<T, DIR, P4>;
+            (void)allow_lds(kern, lds_cu);
+            T *dummyp = vec + dummy_off;
+            void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
+                            (void *)&f, (void *)&lf, (void *)&vec, (void *)&dummyp};
+            (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + LS_PROD), args, smem, st);
+            return;
+        }
         if (shortl) {              // (records of <= 6 blocks: a few KB, they fit whenever LDS records are on)
             if (fits(smem1))
                 LC_LAUNCH(1, smem1, P2);
@@ -1429,7 +1605,7 @@ static const OptionEntry g_options[] = {
     {"line_fuse_max", &g_line_fuse_max}, {"skip_repeat", &g_skip_repeat},       {"tile_fuse", &g_tile_fuse},
     {"line_lds", &g_line_lds},           {"point_prefetch", &g_point_prefetch}, {"residual_zb", &g_residual_zb},
     {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
-    {"line_debug", &g_line_debug},
+    {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 

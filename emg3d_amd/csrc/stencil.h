@@ -674,9 +674,33 @@ EMG_HD void line_matrix(const Axes<T, DIR> &A, int k, int i1, int i2, T (&dg)[5]
 }
 
 // Right-hand side of block k (core.py:727-766): source + terms of the edges that are NOT
-// on the line, with the current field values. nrows = 5, or 1 for the last block.
+// on the line, with the current field values. Two parts, so that callers can take them from
+// different record rows (the mirrored blocks of the two-sided solve, below: E0(k) with t(k)):
+//   line_rhs_e0: entry 0, the along-line edge E0(k)                              (core.py:727, 735-738)
+//   line_rhs_t : entries 1..4, the transverse edges t(k+1) at node k+1           (core.py:729-732, 740-766);
+//                zero for the last block k = n0 - 1, which has only the along-line edge
+// Every entry is evaluated by the same expression, in the same order, wherever it is called from.
 template <class T, int DIR>
-EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
+EMG_HD T line_rhs_e0(const Axes<T, DIR> &A, int k, int i1, int i2)
+{
+    const int i0m = k;
+    const int i1m = i1 - 1, i1p = i1 + 1, i2m = i2 - 1, i2p = i2 + 1;
+    const double h10 = A.ih1()[i1m], h11 = A.ih1()[i1];
+    const double h20 = A.ih2()[i2m], h21 = A.ih2()[i2];
+    const double k10 = 0.5 * h10, k11 = 0.5 * h11, k20 = 0.5 * h20, k21 = 0.5 * h21;
+    const double z000 = A.zeta(i0m, i1m, i2m), z010 = A.zeta(i0m, i1, i2m);
+    const double z001 = A.zeta(i0m, i1m, i2), z011 = A.zeta(i0m, i1, i2);
+    const double mzyLxm = k10 * (z001 + z000), mzyRxm = k11 * (z011 + z010);
+    const double myzLxm = k20 * (z010 + z000), myzRxm = k21 * (z011 + z001);
+    T r0 = A.s(0, i0m, i1, i2);
+    r0 += (mzyRxm * h11) * A.e(0, i0m, i1p, i2);
+    r0 += (mzyLxm * h10) * A.e(0, i0m, i1m, i2);
+    r0 += (myzRxm * h21) * A.e(0, i0m, i1, i2p);
+    r0 += (myzLxm * h20) * A.e(0, i0m, i1, i2m);
+    return r0;
+}
+template <class T, int DIR>
+EMG_HD void line_rhs_t(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
 {
     const int n0 = A.n0();
     const int i0m = k;
@@ -690,14 +714,6 @@ EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
 
     const double z000 = A.zeta(i0m, i1m, i2m), z010 = A.zeta(i0m, i1, i2m);
     const double z001 = A.zeta(i0m, i1m, i2), z011 = A.zeta(i0m, i1, i2);
-    const double mzyLxm = k10 * (z001 + z000), mzyRxm = k11 * (z011 + z010);
-    const double myzLxm = k20 * (z010 + z000), myzRxm = k21 * (z011 + z001);
-
-    rhs[0] = A.s(0, i0m, i1, i2);
-    rhs[0] += (mzyRxm * h11) * A.e(0, i0m, i1p, i2);
-    rhs[0] += (mzyLxm * h10) * A.e(0, i0m, i1m, i2);
-    rhs[0] += (myzRxm * h21) * A.e(0, i0m, i1, i2p);
-    rhs[0] += (myzLxm * h20) * A.e(0, i0m, i1, i2m);
     // (the last block has only the along-line edge: its entries 1..4 are zeroed at the end --
     // no early return, so that callers can batch several blocks with all loads in flight)
     const double z100 = A.zeta(i0, i1m, i2m), z110 = A.zeta(i0, i1, i2m);
@@ -736,6 +752,12 @@ EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
     rhs[4] += (mxyRzp * h11) * A.e(2, i0, i1p, i2);
     rhs[4] += (mxyLzp * h10) * A.e(2, i0, i1m, i2);
     if (k == n0 - 1) rhs[1] = rhs[2] = rhs[3] = rhs[4] = zero<T>();
+}
+template <class T, int DIR>
+EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
+{
+    line_rhs_t<T, DIR>(A, k, i1, i2, rhs);
+    rhs[0] = line_rhs_e0<T, DIR>(A, k, i1, i2);
 }
 
 
