@@ -1051,6 +1051,10 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
 }
 
 constexpr int LS_PROD = 256;                 // producer threads of k_line_stream (4 waves; + 2 chain waves)
+// (Measured, not adopted: the same kernel with the records in LDS behind the ring on the levels whose
+// records fit -- 64-block lines: 0.350 -> 0.376 ms per call, the cycle 0.5 % slower: there the right-
+// hand sides are a 4 us phase, and six waves with 256 registers walk the chains slower than four
+// with 276.)
 template <class T, int DIR, int QD = emg::LINE_PAD>
 __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                                   int lpw, int R, const T *fac, const double *lfac,
@@ -1065,6 +1069,7 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream(emg::Level<T> 
     T *const ringbase = reinterpret_cast<T *>(ls_smem);
     const size_t bufelems = (size_t)2 * R * lpw * 5;
     const VecRef<T> V = VecRef<T>::global(vec, nlines);
+    T *const dum = dummy;
     const int mk = emg::line_mid(n0);
     const int smax = max(mk, n0p - 2 - mk);
     const int nchunks = (smax + R - 1) / R;
@@ -1096,8 +1101,8 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream(emg::Level<T> 
     const int half = wave & 1;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
-    if (half == 0) quad_forward_stream<T, 0, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dummy, dummy, ringbase, lpw, R, nchunks);
-    else quad_forward_stream<T, 1, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dummy, dummy, ringbase, lpw, R, nchunks);
+    if (half == 0) quad_forward_stream<T, 0, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dum, dum, ringbase, lpw, R, nchunks);
+    else quad_forward_stream<T, 1, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dum, dum, ringbase, lpw, R, nchunks);
     __syncthreads();
     // (six waves share four SIMDs: 256 registers per lane -- the middle block is solved before the
     // backward pass's register ring is filled, as in the batched k_line_colour)
@@ -1274,7 +1279,7 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                (VM == 0 && (g_line_debug & 1)) ? ~(size_t)0 : vstride);                                  \
     } while (0)
         // the largest levels of a single-source solve: right-hand sides streamed through LDS
-        if (g_line_stream && !shortl && L.batch == 1 && !g_line_occ2 && !(g_line_debug & 1) && !fits(smem1) && lc.n0 >= 16) {
+        if (g_line_stream && !shortl && L.batch == 1 && !g_line_occ2 && !(g_line_debug & 1) && lc.n0 >= 16 && !fits(smem1)) {
             const int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
             const size_t smem = (size_t)2 * 2 * R * lpw * 5 * sizeof(T);
             const void *kern = (const void *)&k_line_stream<T, DIR, P4>;

@@ -479,6 +479,43 @@ def test_tuning_options_do_not_change_results(golden_kernels):
         lib.emg3d_set_option(b'line_lds', 1)
 
 
+@pytest.mark.parametrize('shape,lr', [((64, 96, 96), 1), ((96, 64, 96), 2), ((96, 96, 130), 3), ((258, 96, 96), 1)])
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_streamed_line_kernel_is_bit_identical(shape, lr, dtype):
+    """k_line_stream (right-hand sides produced into an LDS ring while the forward chains run) against
+    k_line_colour (line_stream = 0): the same arithmetic entry by entry, so the fields after nu = 3 sweeps
+    must agree bit for bit. Shapes: 64-block lines whose records fit in LDS (k_line_colour either way),
+    130-block lines (records partly in LDS before), 258-block lines (global scratch), each with enough
+    lines per colour class for 16-line workgroups."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(sum(shape) + lr)
+    h = [rng.uniform(5., 15., n) * 1.02 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, 0.7 if dtype is complex else -0.7, *sig)
+    s, e0 = mg_ref.Field(grid, dtype=dtype), mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    args = (s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
+    out = {}
+    old = lib.emg3d_get_option(b'line_stream')
+    try:
+        for mode in (0, 1):
+            lib.emg3d_set_option(b'line_stream', mode)
+            b = e0.copy()
+            getattr(core, SMOOTHERS[lr])(b.fx, b.fy, b.fz, *args)
+            out[mode] = b.field.copy()
+    finally:
+        lib.emg3d_set_option(b'line_stream', old)
+    assert np.any(out[0] != e0.field)
+    assert np.array_equal(out[1], out[0])
+
+
 @pytest.mark.parametrize('shape,kw', [
     ((48, 32, 24), dict(cycle='W', semicoarsening=True, linerelaxation=True)),
     ((24, 40, 16), dict(cycle='V', semicoarsening=2, linerelaxation=2)),
