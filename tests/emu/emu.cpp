@@ -269,6 +269,42 @@ void emu_restrict_param(void *out, const void *in, int nx, int ny, int nz, int s
             }
 }
 
+// The blocks of ONE line system as stencil.h assembles them (complex fields): per block k the
+// diagonal dg[5], the strictly lower real part mid[5][5], the coupling to the previous block
+// (left0[5], leftd[5]) and the right-hand side rhs[5] -- for numerical experiments with other
+// elimination orders (tools/line_reduced_prototype.py) against the kernels' own inputs.
+void emu_line_blocks(const LevelArgs *lv, int dir, int i1, int i2, void *dg_, double *mid_, double *left0_,
+                     double *leftd_, void *rhs_)
+{
+    const emg::Level<cplx> L = to_level<cplx>(lv);
+    cplx *dgo = (cplx *)dg_, *rhso = (cplx *)rhs_;
+    auto run = [&](auto A) {
+        const int n0 = A.n0();
+        for (int k = 0; k < n0; ++k) {
+            cplx dg[5], rhs[5];
+            double mid[5][5] = {}, l0[5], ld[5];
+            if (dir == 0) {
+                emg::line_matrix<cplx, 0>(emg::Axes<cplx, 0>(L), k, i1, i2, dg, mid, l0, ld);
+                emg::line_rhs<cplx, 0>(emg::Axes<cplx, 0>(L), k, i1, i2, rhs);
+            } else if (dir == 1) {
+                emg::line_matrix<cplx, 1>(emg::Axes<cplx, 1>(L), k, i1, i2, dg, mid, l0, ld);
+                emg::line_rhs<cplx, 1>(emg::Axes<cplx, 1>(L), k, i1, i2, rhs);
+            } else {
+                emg::line_matrix<cplx, 2>(emg::Axes<cplx, 2>(L), k, i1, i2, dg, mid, l0, ld);
+                emg::line_rhs<cplx, 2>(emg::Axes<cplx, 2>(L), k, i1, i2, rhs);
+            }
+            for (int r = 0; r < 5; ++r) {
+                dgo[k * 5 + r] = dg[r];
+                rhso[k * 5 + r] = rhs[r];
+                left0_[k * 5 + r] = l0[r];
+                leftd_[k * 5 + r] = ld[r];
+                for (int m = 0; m < 5; ++m) mid_[(k * 5 + r) * 5 + m] = m < r ? mid[r][m] : 0.0;
+            }
+        }
+    };
+    if (dir == 0) run(emg::Axes<cplx, 0>(L)); else if (dir == 1) run(emg::Axes<cplx, 1>(L)); else run(emg::Axes<cplx, 2>(L));
+}
+
 void emu_solve(void *amat, void *bvec, int n, int is_complex)
 {
     if (is_complex) emg::band_solve<cplx>((cplx *)amat, (cplx *)bvec, n);

@@ -78,6 +78,19 @@ def residual(e, s, vm, r=None):
     return lib().emu_residual(ctypes.byref(lv), _ptr(r.fx), _ptr(r.fy), _ptr(r.fz))
 
 
+def line_blocks(e, s, vm, direction, i1, i2):
+    """Blocks of the line system of line (i1, i2) (abstract transverse node indices) in direction
+    0/1/2 as the kernels assemble them: (dg (n0,5) complex, mid (n0,5,5), left0 (n0,5), leftd (n0,5),
+    rhs (n0,5) complex)."""
+    keep = []
+    lv = make_level(e, s, vm, keep)
+    n0 = vm.grid.shape_cells[direction]
+    dg, rhs = np.zeros((n0, 5), complex), np.zeros((n0, 5), complex)
+    mid, l0, ld = np.zeros((n0, 5, 5)), np.zeros((n0, 5)), np.zeros((n0, 5))
+    lib().emu_line_blocks(ctypes.byref(lv), int(direction), int(i1), int(i2), _ptr(dg), _ptr(mid), _ptr(l0), _ptr(ld), _ptr(rhs))
+    return dg, mid, l0, ld, rhs
+
+
 def restrict(c, r, w9, shape, sc_dir):
     arr = (ctypes.c_void_p * 9)(*[_ptr(a) if a is not None else None for a in w9])
     nx, ny, nz = shape

@@ -1,4 +1,4 @@
-"""Turn the two PMC passes of a bench run into profiles/r02_pmc_traffic.json.
+"""Turn the two PMC passes of a bench run into profiles/<round>_pmc_traffic.json (round: env PMC_ROUND, default r03).
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/f -o run -- python bench.py ...
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/w -o run -- python bench.py ...
@@ -41,7 +41,7 @@ def main():
     for d, name in ((0, 'k_gs_line<x>'), (1, 'k_gs_line<y>'), (2, 'k_gs_line<z>')):
         parts = {}
         for k in fetch:
-            for tag in (f'k_line_colour<emg::cplx, {d},', f'k_line_backward<emg::cplx, {d}>',
+            for tag in (f'k_line_colour<emg::cplx, {d},', f'k_line_stream<emg::cplx, {d},', f'k_line_backward<emg::cplx, {d}>',
                         f'k_line_rhs<emg::cplx, {d}>', 'k_line_rhs_xt<emg::cplx>' if d == 0 else None):
                 if tag and tag in k:
                     cand = {'read': 2 * fetch[k][1] * 1024, 'write': write[k][1] * 1024,
@@ -53,9 +53,11 @@ def main():
             continue
         gmax = max(p['grid'] for p in parts.values())
         # fused and unfused kernels never serve the same level: keep the finest level's set
-        fused = {k: p for k, p in parts.items() if 'colour' in k}
+        # the finest level is served either by k_line_stream (384-thread workgroups) or by k_line_colour
+        stream = {k: p for k, p in parts.items() if 'stream' in k}
+        fused = stream or {k: p for k, p in parts.items() if 'colour' in k}
         use = fused if fused and max(p['grid'] for p in fused.values()) * 2 >= gmax else \
-            {k: p for k, p in parts.items() if 'colour' not in k}
+            {k: p for k, p in parts.items() if 'colour' not in k and 'stream' not in k}
         total = sum(p['read'] + p['write'] for p in use.values())
         res[name] = {'bytes_per_launch': total, 'kernels': use}
     pt = [k for k in fetch if 'k_gs_point_tile' in k]
@@ -64,13 +66,20 @@ def main():
         res['k_gs_point_tile'] = {'bytes_per_launch': 2 * fetch[k][1] * 1024 + write.get(k, (0, 0, 0))[1] * 1024,
                                   'kernels': {'k_gs_point_tile': {'read': 2 * fetch[k][1] * 1024, 'write': write.get(k, (0, 0, 0))[1] * 1024,
                                                                   'grid': fetch[k][0], 'launches': fetch[k][2]}}}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r02_pmc_traffic.json')
+    rnd = os.environ.get('PMC_ROUND', 'r03')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', f'{rnd}_pmc_traffic.json')
     try:
         with open(path) as f:
             allres = json.load(f)
     except OSError:
         allres = {}
     allres[wl] = res
+    import datetime
+    meta = allres.setdefault('_meta', {})
+    meta['date'] = datetime.date.today().isoformat()
+    meta['passes'] = 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, tools/profile_bench.sh'
+    if os.environ.get('PMC_COMMIT'):
+        meta['library_commit'] = os.environ['PMC_COMMIT']
     with open(path, 'w') as f:
         json.dump(allres, f, indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
