@@ -1,7 +1,10 @@
 """Soak test (through gpurun): random small solves -- grids, stretching, anisotropy, air layers, frequency and
 Laplace domain, multigrid / BiCGSTAB / CGS, cycle types -- against the oracle's converged fields. (This
 kind of run found the accuracy floor of the direct-form finest level)
-    python tools/soak_solves.py"""
+    python tools/soak_solves.py           (SEEDS=23,26 python ... : only these)
+Known non-failures of the library: seeds 23 and 26 -- CGS on a model with an air layer does not reach
+tol 1e-10 within 80 iterations (identical with the round-2 library; the device CGS follows SciPy's
+iteration step by step, tests/test_gpu_parity.py::test_device_krylov_matches_scipy_iteration)."""
 import sys, os, time
 root = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
@@ -11,7 +14,7 @@ from oracle import mg_ref
 from helpers import widths
 bad = 0
 t0 = time.time()
-for seed in range(40):
+for seed in [int(x) for x in os.environ.get("SEEDS","").split(",")] if os.environ.get("SEEDS") else range(40):
     rng = np.random.default_rng(11000 + seed)
     shape = tuple(int(rng.choice([8, 10, 12, 16, 20, 24])) for _ in range(3))
     h = [widths(max(n // 2, 2), (n - max(n // 2, 2)) // 2, 20., float(rng.choice([1.05, 1.15, 1.3]))) for n in shape]
