@@ -1279,7 +1279,10 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                (VM == 0 && (g_line_debug & 1)) ? ~(size_t)0 : vstride);                                  \
     } while (0)
         // the largest levels of a single-source solve: right-hand sides streamed through LDS
-        if (g_line_stream && !shortl && L.batch == 1 && !g_line_occ2 && !(g_line_debug & 1) && lc.n0 >= 16 && !fits(smem1)) {
+        // (where slots 0..3 of the records fit in LDS -- 128-block lines -- k_line_colour's mode 2 is as fast:
+        // 11.34 against 11.40 ms per config-2 cycle, 1.80-1.91 against 1.82-1.88 ms per call at 256 x 128 x 128)
+        if (g_line_stream && !shortl && L.batch == 1 && !g_line_occ2 && !(g_line_debug & 1) && lc.n0 >= 16 && !fits(smem1) &&
+            (!fits(smem2) || g_line_stream >= 2)) {
             const int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
             const size_t smem = (size_t)2 * 2 * R * lpw * 5 * sizeof(T);
             const void *kern = (const void *)&k_line_stream<T, DIR, P4>;
