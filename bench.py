@@ -200,6 +200,16 @@ class Bench:
         return stats
 
 
+def line_kernel_name(n0):
+    """The HIP kernel that runs a colour pass of lines of n0 blocks on a large level (what rocprofv3
+    lists): k_line_stream where the records of 16 lines do not fit in LDS even without their fifth slot
+    (csrc/kernels.hip: launch_line_colour), else k_line_colour."""
+    from emg3d_amd import _lib
+    padded = n0 + 6                        # upper bound of the padded record rows (stencil.h: line_padded)
+    too_long = (16 * padded * 4 + 80) * 16 > 160 * 1024
+    return 'k_line_stream' if (_lib.lib().emg3d_get_option(b'line_stream') > 0 and too_long) else 'k_line_colour'
+
+
 def smoothers_256(device, n=256, nu=2, reps=5):
     """BASELINE.json's north-star kernel figure: each smoother on a 256^3 tri-axial level
     (random model and fields, complex fp64), nu sweeps per call, HIP events on the launch
@@ -243,8 +253,9 @@ def smoothers_256(device, n=256, nu=2, reps=5):
     skip = bool(lib.emg3d_get_option(b'skip_repeat'))
     fuse = bool(lib.emg3d_get_option(b'tile_fuse'))
     out = {}
-    names = {0: 'gauss_seidel (k_gs_point_tile)', 1: 'gauss_seidel_x (k_line_colour<0>)',
-             2: 'gauss_seidel_y (k_line_colour<1>)', 3: 'gauss_seidel_z (k_line_colour<2>)'}
+    lk = line_kernel_name(n)
+    names = {0: 'gauss_seidel (k_gs_point_tile)', 1: f'gauss_seidel_x ({lk}<0>)',
+             2: f'gauss_seidel_y ({lk}<1>)', 3: f'gauss_seidel_z ({lk}<2>)'}
     for lr in (0, 1, 2, 3):
         lv.smooth(lr, nu)                       # builds factors, warms up
         lv.smooth(lr, nu)
@@ -475,8 +486,9 @@ def run_gpu(args):
         nx_, ny_, nz_ = b.grid.shape_cells
         tmin = _lib.lib().emg3d_get_option(b'point_tile_min')
         tiled = tmin > 0 and (nx_ - 1) * (ny_ - 1) * (nz_ - 1) >= tmin and (nx_ + 1) * (ny_ + 1) * (nz_ + 1) < 2 ** 31
-        hip_names = {0: 'k_gs_point_tile' if tiled else 'k_gs_point', 1: 'k_line_colour<T, DIR=0, ...>',
-                     2: 'k_line_colour<T, DIR=1, ...>', 3: 'k_line_colour<T, DIR=2, ...>'}
+        hip_names = {0: 'k_gs_point_tile' if tiled else 'k_gs_point'}
+        for d_, n_ in ((1, nx_), (2, ny_), (3, nz_)):
+            hip_names[d_] = f'{line_kernel_name(n_)}<T, DIR={d_ - 1}, ...>'
         dom = max(stats, key=lambda k: stats[k]['ms'])
         bytes_per_launch = BYTES_PER_CELL_SWEEP[b.case] * n0 / 4.0
         ms_launch = stats[dom]['ms'] / stats[dom]['launches']

@@ -100,7 +100,14 @@ int emg3d_device_count(void);
  * (default) does not launch the colour pass that repeats the last colour class of the previous
  * sweep of the same call (it reproduces the same values bit by bit); 0 launches every pass.
  * "tile_fuse": 1 (default) lets the tiles of the tiled point smoother where two consecutive
- * sweeps meet run both sweeps on one LDS copy (same operations, one load / store less). */
+ * sweeps meet run both sweeps on one LDS copy (same operations, one load / store less).
+ * "line_stream": 1 (default) runs the colour passes of lines too long for LDS records (more than
+ * ~128 blocks with 16 lines per workgroup) with the right-hand sides produced into an LDS ring
+ * while the forward substitution consumes them (k_line_stream: no round trip of the right-hand
+ * sides through the scratch, bit-identical results); 0 the three-phase kernel everywhere; 2 also
+ * where part of the records fit in LDS. "line_stream_r": rows per half of that ring (0 = 16).
+ * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
+ * results); leave it 0. */
 int emg3d_set_option(const char *name, int value);
 int emg3d_get_option(const char *name);
 /* enumeration of the options (for callers that key cached state -- captured graphs, option-
