@@ -336,3 +336,55 @@ def test_residual_form_auto_rule():
     assert rule(benign, True, tol=1e-6) is True and rule(air, False, tol=1e-6) is False
     with pytest.raises(ValueError):
         rule(benign, 'yes', tol=1e-6)
+
+
+def test_option_table_and_fingerprint():
+    """The run-time options of the library: enumerable, settable by name, unknown names refused; the
+    fingerprint that keys captured graphs follows a change."""
+    lib = _lib.lib()
+    names = [lib.emg3d_option_name(i).decode() for i in range(lib.emg3d_option_count())]
+    assert lib.emg3d_option_name(len(names)) is None and lib.emg3d_option_name(-1) is None
+    for want in ('point_tile_min', 'skip_repeat', 'line_stream', 'line_lds', 'residual_zb'):
+        assert want in names
+    assert len(set(names)) == len(names)
+    before = _lib.options_fingerprint()
+    assert len(before) == len(names)
+    old = lib.emg3d_get_option(b'line_stream')
+    try:
+        assert lib.emg3d_set_option(b'line_stream', 1 - old) == 0
+        assert lib.emg3d_get_option(b'line_stream') == 1 - old
+        assert _lib.options_fingerprint() != before
+    finally:
+        lib.emg3d_set_option(b'line_stream', old)
+    assert _lib.options_fingerprint() == before
+    assert lib.emg3d_set_option(b'no_such_option', 1) != 0 and lib.emg3d_get_option(b'no_such_option') == -1
+    assert lib.emg3d_set_option(b'line_lpw', 5) != 0                      # only 0, 4, 8, 16, 32
+    assert lib.emg3d_set_option(b'residual_zb', 0) == 0 and lib.emg3d_get_option(b'residual_zb') == 1
+    lib.emg3d_set_option(b'residual_zb', 8)
+
+
+def test_bench_helpers_without_a_gpu():
+    """bench.py: ranks > 0 of a multi-GPU run never build the model (`with_model=False`), the level-0
+    kernel label follows the line length, and the PMC figure names where it comes from."""
+    import bench
+    for name in ('marine64', 'triaxial64', 'salt96', 'uniform32'):
+        lean, full = bench.workload(name, with_model=False), bench.workload(name)
+        assert lean['res'] is None and full['res'] is not None
+        assert all(np.array_equal(a, b) for a, b in zip(lean['h'], full['h'])) and lean['source'] == full['source']
+    assert bench.line_kernel_name(256) == 'k_line_stream' and bench.line_kernel_name(384) == 'k_line_stream'
+    assert bench.line_kernel_name(128) == 'k_line_colour' and bench.line_kernel_name(64) == 'k_line_colour'
+    traffic, src = bench.pmc_traffic('triaxial256', 'k_gs_line<y>')
+    assert traffic > 3e9 and src['file'].startswith('profiles/r03') and src['measured_in_this_run'] is False
+    assert bench.pmc_traffic('no_such_workload', 'k') == (None, None)
+
+
+def test_model_drops_a_device_snapshot_when_a_property_is_replaced():
+    """parallel.broadcast_model leaves HBM copies of the property arrays on the model it RETURNS
+    (`_device_props`); replacing a property array must drop that array's copy."""
+    grid = emg3d.TensorMesh([np.ones(4), np.ones(4), np.ones(4)], (0, 0, 0))
+    model = emg3d.Model(grid, 2.0, property_z=3.0)
+    model.__dict__['_device_props'] = {'property_x': 'X', 'property_z': 'Z'}
+    model.property_x = np.full(grid.shape_cells, 5.0)
+    assert model._device_props == {'property_z': 'Z'}
+    model.mapping = model.mapping                      # other attributes do not touch it
+    assert model._device_props == {'property_z': 'Z'}
