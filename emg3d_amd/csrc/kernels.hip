@@ -93,9 +93,10 @@ int g_line_occ2 = 0;
 int g_point_small = 512;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
-// the largest levels (records not, or not completely, in LDS): k_line_stream -- right-hand sides
-// produced into an LDS ring by the helper waves while the chain waves substitute (1, default); 0:
-// k_line_colour everywhere
+// the largest levels (records of 16 lines do not fit in LDS even without their fifth slot: lines of
+// ~160 blocks and more): k_line_stream -- right-hand sides produced into an LDS ring by the helper
+// waves while the chain waves substitute (1, default); 0: k_line_colour everywhere; 2: k_line_stream
+// also where slots 0..3 would fit (~128-block lines: measured equal)
 int g_line_stream = 1;
 int g_line_stream_r = 0;           // rows per chunk of the ring (0: 16)
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
 // k_line_colour runs right-hand sides, forward and backward substitution one after the other, and
 // on the levels whose records do not fit the LDS of a CU the right-hand sides make a round trip
 // through the global scratch (written by the first phase, read by the second: 160 B per block of
-// the pass's ~1450). Here the two helper waves PRODUCE the right-hand sides of the
+// the pass's ~1450). Here four producer waves PRODUCE the right-hand sides of the
 // next R block rows into an LDS ring while the two chain waves CONSUME the current R rows in their
 // forward half-chains: the right-hand sides never leave the CU, and their assembly (a bandwidth
 // phase) overlaps the forward substitution (a latency chain). Same arithmetic, entry by entry, as
