@@ -479,14 +479,16 @@ def test_tuning_options_do_not_change_results(golden_kernels):
         lib.emg3d_set_option(b'line_lds', 1)
 
 
-@pytest.mark.parametrize('shape,lr', [((64, 96, 96), 1), ((96, 64, 96), 2), ((96, 96, 130), 3), ((258, 96, 96), 1)])
+@pytest.mark.parametrize('shape,lr', [((64, 96, 96), 1), ((96, 64, 96), 2), ((96, 96, 130), 3), ((258, 96, 96), 1),
+                                      ((60, 384, 60), 2)])
 @pytest.mark.parametrize('dtype', [complex, float])
 def test_streamed_line_kernel_is_bit_identical(shape, lr, dtype):
     """k_line_stream (right-hand sides produced into an LDS ring while the forward chains run) against
     k_line_colour (line_stream = 0): the same arithmetic entry by entry, so the fields after nu = 3 sweeps
     must agree bit for bit. Shapes: 64-block lines whose records fit in LDS (k_line_colour either way),
     130-block lines (records partly in LDS before), 258-block lines (global scratch), each with enough
-    lines per colour class for 16-line workgroups."""
+    lines per colour class for 16-line workgroups; and 384-block lines with 8 lines per workgroup (half-
+    filled chain waves, surplus quads)."""
     lib = _lib.lib()
     rng = np.random.default_rng(sum(shape) + lr)
     h = [rng.uniform(5., 15., n) * 1.02 ** np.abs(np.arange(n) - n // 2) for n in shape]
@@ -1207,6 +1209,7 @@ def test_full_size_per_sweep_parity_vs_oracle(shape, case):
     ((256, 96, 96), 1), ((96, 258, 96), 2), ((96, 96, 256), 3),        # records in the global scratch
     ((130, 6, 10), 1), ((6, 256, 10), 2), ((10, 6, 129), 3),           # long lines, few of them (4 lines / workgroup)
     ((384, 6, 10), 1), ((384, 96, 96), 1),                             # the x-lines of config 5 (384 x 256 x 256)
+    ((60, 60, 384), 3),                                                # streamed kernel with 8 lines per workgroup
 ])
 @pytest.mark.parametrize('dtype', [complex, float])
 def test_long_line_record_modes_vs_oracle(shape, lr, dtype):
