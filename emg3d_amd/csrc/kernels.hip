@@ -326,11 +326,16 @@ __global__ __launch_bounds__(256) void k_any_real_part(const cplx *a, size_t n, 
 // Two waves per 64 lines: wave 0 factorises the top chains, wave 1 the bottom chains (they are
 // independent and the setup is one long dependent recurrence per line); the LDL^T factors of
 // the bottom chain's last block go through LDS to wave 0, which finishes with the middle block.
+// All four colour classes in one launch (grid.z = colour): the recurrence of a line is one long
+// dependent chain, and a class alone puts one wave pair on every CU -- four of them interleave.
+struct SetupClasses { int cntp[4], cntq[4]; size_t fac_off[4], lfac_off[4]; };
 template <class T, int DIR>
-__global__ __launch_bounds__(128) void k_line_setup(emg::Level<T> L, int colour, int cntp, int cntq, T *fac,
-                                                    double *lfac)
+__global__ __launch_bounds__(128) void k_line_setup(emg::Level<T> L, SetupClasses S, T *fac0, double *lfac0)
 {
     __shared__ T xch[15][64];
+    const int colour = blockIdx.z, cntp = S.cntp[colour], cntq = S.cntq[colour];
+    T *const fac = fac0 + S.fac_off[colour];
+    double *const lfac = lfac0 + S.lfac_off[colour];
     const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int i1, i2, lid;
     const bool valid = emg::line_of_thread<DIR>(colour, cntp, cntq, blockIdx.x * 64 + lane, blockIdx.y, i1, i2, lid);
@@ -1450,12 +1455,18 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
 template <class T, int DIR>
 void launch_line_setup_dir(const emg::Level<T> &L, T *fac, double *lfac, hipStream_t st)
 {
+    SetupClasses S;
+    int gx = 0, gy = 0;
     for (int c = 0; c < 4; ++c) {
         const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
-        if (lc.lines <= 0) continue;
-        hipLaunchKernelGGL((k_line_setup<T, DIR>), d3(emg::line_grid(lc)), dim3(128), 0, st, L, c, lc.cntp, lc.cntq,
-                           fac + lc.fac_off, lfac + lc.lfac_off);
+        S.cntp[c] = lc.lines > 0 ? lc.cntp : 0; S.cntq[c] = lc.lines > 0 ? lc.cntq : 0;
+        S.fac_off[c] = lc.fac_off; S.lfac_off[c] = lc.lfac_off;
+        if (lc.lines > 0) {
+            const emg::Dim3 g = emg::line_grid(lc);
+            gx = g.x > gx ? g.x : gx; gy = g.y > gy ? g.y : gy;
+        }
     }
+    if (gx > 0 && gy > 0) hipLaunchKernelGGL((k_line_setup<T, DIR>), dim3(gx, gy, 4), dim3(128), 0, st, L, S, fac, lfac);
 }
 
 template <class T>
