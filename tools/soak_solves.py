@@ -4,7 +4,10 @@ kind of run found the accuracy floor of the direct-form finest level, DESIGN.md 
     python tools/soak_solves.py           (SEEDS=23,26 python ... : only these)
 Known non-failures of the library: seeds 23 and 26 -- CGS on a model with an air layer does not reach
 tol 1e-10 within 80 iterations (identical with the round-2 library; the device CGS follows SciPy's
-iteration step by step, tests/test_gpu_parity.py::test_device_krylov_matches_scipy_iteration)."""
+iteration step by step, tests/test_gpu_parity.py::test_device_krylov_matches_scipy_iteration). With
+SEED_BASE=31000 seed 28 (plain V-cycle with semicoarsening on an air-layer model): 80 cycles are not enough in
+the four-colour order (the oracle needs 83 in that order, 55 in the reference's: the ordering's price, DESIGN.md
+4.1), likewise CGS seeds 31033 / 47026."""
 import sys, os, time
 root = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
@@ -15,7 +18,7 @@ from helpers import widths
 bad = 0
 t0 = time.time()
 for seed in [int(x) for x in os.environ.get("SEEDS","").split(",")] if os.environ.get("SEEDS") else range(40):
-    rng = np.random.default_rng(11000 + seed)
+    rng = np.random.default_rng(int(os.environ.get("SEED_BASE", 11000)) + seed)
     shape = tuple(int(rng.choice([8, 10, 12, 16, 20, 24])) for _ in range(3))
     h = [widths(max(n // 2, 2), (n - max(n // 2, 2)) // 2, 20., float(rng.choice([1.05, 1.15, 1.3]))) for n in shape]
     shape = tuple(len(x) for x in h)
