@@ -98,6 +98,11 @@ int g_line_lpw = 0;
 // waves while the chain waves substitute (1, default); 0: k_line_colour everywhere; 2: k_line_stream
 // also where slots 0..3 would fit (~128-block lines: measured equal)
 int g_line_stream = 1;
+// sequence of the colour passes of the LINE smoothers (launch.h: line_sweep_colour): 1 (default) cyclic
+// 1,2,3,0,1,...; 0 mirrored sweeps (0,2,3,1 forward / its reverse backward: rounds 1-2). Like
+// point_tile_min this selects the ORDER of the Gauss-Seidel sweep, i.e. it is part of the algorithm
+// definition (converged fields are the same; per-sweep values and cycle counts are not).
+int g_line_order = 1;
 int g_line_stream_r = 0;           // rows per chunk of the ring (0: 16)
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
@@ -1437,11 +1442,11 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             continue;
         }
         for (int cc = 0; cc < 4; ++cc) {
-            const int c = emg::sweep_colour(iback, cc);
-            // A sweep ends with the colour class the next one (opposite direction) starts with.
-            // A line solve depends on the edges NOT on the line only, and lines of one class do not
-            // see each other: solving the class again right away reproduces the same values bit by
-            // bit. (The reference's sequential sweeps have the same redundant first line.)
+            const int c = emg::line_sweep_colour(g_line_order, it, cc);
+            // A sweep ends with the colour class the next one starts with (both rules of launch.h:
+            // line_sweep_colour). A line solve depends on the edges NOT on the line only, and lines of
+            // one class do not see each other: solving the class again right away reproduces the same
+            // values bit by bit. (The reference's sequential sweeps have the same redundant first line.)
             if (g_skip_repeat && it > 0 && cc == 0) continue;
             if (lr == 1) launch_line_colour<T, 0>(L, c, (const T *)fac, lfac, (T *)scratch, st);
             else if (lr == 2) launch_line_colour<T, 1>(L, c, (const T *)fac, lfac, (T *)scratch, st);
@@ -1626,6 +1631,7 @@ static const OptionEntry g_options[] = {
     {"line_lds", &g_line_lds},           {"point_prefetch", &g_point_prefetch}, {"residual_zb", &g_residual_zb},
     {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
+    {"line_order", &g_line_order},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 

@@ -26,6 +26,21 @@ inline int sweep_colour(int iback, int cc)
     const int seq[4] = {0, 2, 3, 1};
     return seq[iback ? 3 - cc : cc];
 }
+// LINE smoothers (round 3): the colour passes of a call CYCLE through the classes 1,2,3,0,1,2,3,0,...
+// -- sweep `it` (0, 1, ...) of the call takes positions 3 it .. 3 it + 3, so that it begins with the
+// class the previous sweep ended with (that pass reproduces the same values and is not launched:
+// 4 nu - (nu - 1) passes per call, as with the mirrored order). Measured with the oracle on reduced
+// copies of BASELINE.json's configurations: every mirrored pair of sequences (a
+// backward sweep followed by its reverse, the sweep_colour() rule above) is among the slowest of
+// all 576 pairs -- 24 / 11 / 10 cycles to 1e-10 on configs 3 / 2 / 5 --, every cyclic one among the
+// fastest with seven passes per two sweeps -- 21 / 9 / 9 (the reference's sequential order: 17 / 7 / 8).
+// order 0: the mirrored rule (the definition of rounds 1-2, kept for comparison).
+inline int line_sweep_colour(int order, int it, int cc)
+{
+    if (order == 0) return sweep_colour((it + 1) & 1, cc);        // first sweep backward
+    const int seq[4] = {1, 2, 3, 0};
+    return seq[(3 * it + cc) & 3];
+}
 
 // ---- point smoother: colour = ((ix+iz)&1) | (((iy+iz)&1)<<1); global thread (gx,gy,gz);
 //      one launch covers the node planes iz0 .. iz0+izn-1.

@@ -20,9 +20,11 @@
  *      point:  colour = ((ix+iz)&1) | (((iy+iz)&1)<<1)
  *      lines:  colour = (a&1) | ((b&1)<<1), (a,b) the two transverse node indices
  *              x-line: (iy,iz); y-line: (ix,iz); z-line: (ix,iy)
- *      forward sweep visits colours 0,2,3,1 (oracle_colour_order), backward sweep the
- *      reverse; inside a colour the nodes/lines are independent, so any order gives
- *      the same result.
+ *      point smoother: a forward sweep visits colours 0,2,3,1 (oracle_colour_order), a
+ *      backward sweep the reverse; line smoothers: the passes of a call cycle through
+ *      1,2,3,0,1,... (oracle_line_cycle; sweep `it` takes positions 3 it .. 3 it + 3), or follow
+ *      the point smoother's mirrored rule (oracle_set_line_order(0, ...)). Inside a colour the
+ *      nodes/lines are independent, so any order gives the same result.
  */
 
 #define EX(a, i, j, k) (a)[(size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)(ny + 1) * (size_t)(k))]
@@ -31,6 +33,17 @@
 /* in-pass over-relaxation (experiments only; oracle_omega = 1: plain assignment, the reference) */
 #ifndef RELAX
 #define RELAX(dst, val) do { if (oracle_omega == 1.0) (dst) = (val); else (dst) = (dst) + oracle_omega * ((val) - (dst)); } while (0)
+#endif
+#ifndef ORACLE_COLOUR
+/* colour class visited at position cc of a forward (iback = 0) / backward sweep: backward = the forward
+ * sequence reversed, unless an experiment set its own backward sequence (oracle_set_colour_order_backward) */
+#define ORACLE_COLOUR(iback, cc) ((iback) ? (oracle_backward_custom ? oracle_colour_order_b[cc] : oracle_colour_order[3 - (cc)]) : oracle_colour_order[cc])
+#endif
+#ifndef ORACLE_LINE_COLOUR
+/* LINE smoothers, order 1: by default the passes of a call cycle through oracle_line_cycle (1,2,3,0,1,...),
+ * sweep `it` taking positions 3 it .. 3 it + 3 -- the order of the HIP kernels since round 3 (emg3d_amd/
+ * csrc/launch.h: line_sweep_colour); oracle_line_cyclic = 0: the mirrored rule of ORACLE_COLOUR. */
+#define ORACLE_LINE_COLOUR(it, iback, cc) (oracle_line_cyclic ? oracle_line_cycle[(3 * (it) + (cc)) & 3] : ORACLE_COLOUR(iback, cc))
 #endif
 #define CC(a, i, j, k) (a)[(size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)ny * (size_t)(k))]
 
@@ -354,7 +367,7 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
             }
         } else if (order == 1) {
             for (cc = 0; cc < 4; cc++) {
-                c = oracle_colour_order[iback ? 3 - cc : cc];
+                c = ORACLE_COLOUR(iback, cc);
                 for (izh = 1; izh < nz; izh++)
                     for (iyh = 1; iyh < ny; iyh++)
                         for (ixh = 1; ixh < nx; ixh++)
@@ -375,7 +388,7 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
                     for (ty = (tc >> 1) & 1; ty < nty; ty += 2)
                         for (tx = tc & 1; tx < ntx; tx += 2)
                             for (cc = 0; cc < 4; cc++) {
-                                c = oracle_colour_order[iback ? 3 - cc : cc];
+                                c = ORACLE_COLOUR(iback, cc);
                                 for (izh = 1 + tz * bz; izh < nz && izh < 1 + (tz + 1) * bz; izh++)
                                     for (iyh = 1 + ty * by; iyh < ny && iyh < 1 + (ty + 1) * by; iyh++)
                                         for (ixh = 1 + tx * bx; ixh < nx && ixh < 1 + (tx + 1) * bx; ixh++)
@@ -521,7 +534,7 @@ void FN(gauss_seidel_x)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
             }
         } else {
             for (cc = 0; cc < 4; cc++) {
-                c = oracle_colour_order[iback ? 3 - cc : cc];
+                c = ORACLE_LINE_COLOUR(it, iback, cc);
                 for (izh = 1; izh < nz; izh++)
                     for (iyh = 1; iyh < ny; iyh++)
                         if (((iyh & 1) | ((izh & 1) << 1)) == c)
@@ -666,7 +679,7 @@ void FN(gauss_seidel_y)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
             }
         } else {
             for (cc = 0; cc < 4; cc++) {
-                c = oracle_colour_order[iback ? 3 - cc : cc];
+                c = ORACLE_LINE_COLOUR(it, iback, cc);
                 for (izh = 1; izh < nz; izh++)
                     for (ixh = 1; ixh < nx; ixh++)
                         if (((ixh & 1) | ((izh & 1) << 1)) == c)
@@ -810,7 +823,7 @@ void FN(gauss_seidel_z)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
             }
         } else {
             for (cc = 0; cc < 4; cc++) {
-                c = oracle_colour_order[iback ? 3 - cc : cc];
+                c = ORACLE_LINE_COLOUR(it, iback, cc);
                 for (iyh = 1; iyh < ny; iyh++)
                     for (ixh = 1; ixh < nx; ixh++)
                         if (((ixh & 1) | ((iyh & 1) << 1)) == c)

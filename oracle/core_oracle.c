@@ -27,6 +27,25 @@ void oracle_set_colour_order(int a, int b, int c, int d)
     oracle_colour_order[2] = c; oracle_colour_order[3] = d;
 }
 
+/* experiments only: a backward sequence that is not the reverse of the forward one */
+int oracle_colour_order_b[4] = {1, 3, 2, 0};
+int oracle_backward_custom = 0;
+void oracle_set_colour_order_backward(int on, int a, int b, int c, int d)
+{
+    oracle_backward_custom = on;
+    oracle_colour_order_b[0] = a; oracle_colour_order_b[1] = b;
+    oracle_colour_order_b[2] = c; oracle_colour_order_b[3] = d;
+}
+
+/* order 1 of the LINE smoothers: cyclic pass sequence (default, = the HIP kernels) or the mirrored sweeps */
+int oracle_line_cyclic = 1;
+int oracle_line_cycle[4] = {1, 2, 3, 0};
+void oracle_set_line_order(int cyclic, int a, int b, int c, int d)
+{
+    oracle_line_cyclic = cyclic;
+    oracle_line_cycle[0] = a; oracle_line_cycle[1] = b; oracle_line_cycle[2] = c; oracle_line_cycle[3] = d;
+}
+
 /* order 2 of the point smoother: tile extents in nodes and the sequence of the eight tile
  * colours of a FORWARD sweep (backward = reversed). */
 int oracle_tile[3] = {32, 4, 6};

@@ -28,6 +28,7 @@ struct LevelArgs {
 
 int g_point_slab = 0;
 int g_point_tile_min = 1 << 20;
+int g_line_order = 1;
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
 // kernels.hip (k_gs_point_tile), each workgroup's phases separated like its barriers
@@ -186,7 +187,7 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
             continue;
         }
         for (int cc = 0; cc < 4; ++cc) {
-            const int c = emg::sweep_colour(iback, cc);
+            const int c = emg::line_sweep_colour(g_line_order, it, cc);
             if (lr == 1) line_colour<T, 0>(L, c, fac.data(), lfac.data(), vec.data());
             else if (lr == 2) line_colour<T, 1>(L, c, fac.data(), lfac.data(), vec.data());
             else line_colour<T, 2>(L, c, fac.data(), lfac.data(), vec.data());
@@ -210,6 +211,7 @@ extern "C" {
 
 void emu_set_point_slab(int t) { g_point_slab = t; }
 void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
+void emu_set_line_order(int o) { g_line_order = o; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
 {

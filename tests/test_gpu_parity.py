@@ -479,6 +479,52 @@ def test_tuning_options_do_not_change_results(golden_kernels):
         lib.emg3d_set_option(b'line_lds', 1)
 
 
+def test_line_order_option_mirrored_and_cyclic_vs_oracle():
+    """Option line_order: 1 (default) = the colour passes of a line-smoothing call cycle through 1,2,3,0,1,...;
+    0 = mirrored sweeps (rounds 1-2). Both against the oracle in the same order, per call (nu = 3, 2e-12), and
+    on the reduced copy of config 3 the cyclic order must not need more cycles than the mirrored one (oracle:
+    21 against 24 at tol 1e-10)."""
+    from bench import workload
+    lib, olib = _lib.lib(), ocore.lib()
+    rng = np.random.default_rng(77)
+    shape = (20, 14, 18)
+    h = [rng.uniform(5., 15., n) * 1.05 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, 0.9, *sig)
+    s, e0 = mg_ref.Field(grid), mg_ref.Field(grid)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size) + 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    args = (s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
+    ws = workload('triaxial64')
+    g64 = emg3d.TensorMesh(ws['h'], ws['origin'])
+    model = emg3d.Model(g64, **ws['res'])
+    sf = emg3d.get_source_field(g64, ws['source'], ws['frequency'])
+    cycles, fields = {}, {}
+    try:
+        for order in (0, 1):
+            lib.emg3d_set_option(b'line_order', order)
+            olib.oracle_set_line_order(order, 1, 2, 3, 0)
+            for fn in SMOOTHERS[1:]:
+                a, b = e0.copy(), e0.copy()
+                getattr(ocore, fn)(a.fx, a.fy, a.fz, *args, order=1)
+                getattr(core, fn)(b.fx, b.fy, b.fz, *args)
+                assert relerr(b.field, a.field) < 2e-12, (order, fn)
+                fields[(order, fn)] = b.field.copy()
+            e, info = emg3d.solve(model, sf, sslsolver=False, tol=1e-8, return_info=True, **ws['opts'])
+            assert info['exit'] == 0
+            cycles[order], fields[order] = info['it_mg'], e.field.copy()
+    finally:
+        lib.emg3d_set_option(b'line_order', 1)
+        olib.oracle_set_line_order(1, 1, 2, 3, 0)
+    assert all(relerr(fields[(0, fn)], fields[(1, fn)]) > 1e-6 for fn in SMOOTHERS[1:])     # the orders do differ
+    assert relerr(fields[1], fields[0]) < 1e-7                                               # ... the solutions do not
+    assert cycles[1] <= cycles[0] - 1, cycles
+
+
 @pytest.mark.parametrize('shape,lr', [((64, 96, 96), 1), ((96, 64, 96), 2), ((96, 96, 130), 3), ((258, 96, 96), 1),
                                       ((60, 384, 60), 2)])
 @pytest.mark.parametrize('dtype', [complex, float])
