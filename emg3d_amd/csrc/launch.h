@@ -33,7 +33,7 @@ inline int sweep_colour(int iback, int cc)
 // copies of BASELINE.json's configurations: every mirrored pair of sequences (a
 // backward sweep followed by its reverse, the sweep_colour() rule above) is among the slowest of
 // all 576 pairs -- 24 / 11 / 10 cycles to 1e-10 on configs 3 / 2 / 5 --, every cyclic one among the
-// fastest with seven passes per two sweeps -- 21 / 9 / 9 (the reference's sequential order: 17 / 7 / 8).
+// fastest with seven passes per two sweeps -- 21 / 9 / 9 (the reference's sequential order: 17 / 8 / 8).
 // order 0: the mirrored rule (the definition of rounds 1-2, kept for comparison).
 inline int line_sweep_colour(int order, int it, int cc)
 {
