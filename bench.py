@@ -349,7 +349,9 @@ def time_to_tol(name, wl, b, tol=1e-6):
                           _download=False, **wl['opts'])
     torch.cuda.synchronize()
     out['gpu'] = {'cycles': int(info['it_mg']), 'seconds': time.perf_counter() - t0, 'exit': int(info['exit']),
-                  'rel_error': float(info['rel_error']), 'ordering': 'four-colour lines, cyclic passes 1,2,3,0,1,...'}
+                  'rel_error': float(info['rel_error']),
+                  'ordering': ('four-colour lines, cyclic passes 1,2,3,0,1,...' if wl['opts'].get('linerelaxation')
+                               else 'four-colour nodes (tiled on large levels), mirrored sweeps')}
     small = REDUCED_COPY.get(name)
     if small:
         ws = workload(small)
