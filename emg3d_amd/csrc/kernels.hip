@@ -1399,7 +1399,10 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
                 int colours = emg::sweep_colours_packed(iback), nsteps = 4;
                 if (p == 3 && fuse_next) {
                     const int next = emg::sweep_colours_packed(1 - iback);
-                    if (g_skip_repeat) { colours |= (next >> 2) << 8; nsteps = 7; }
+                    // (the first node colour of the next sweep repeats this sweep's last one only under the
+                    // mirrored rule, option point_order = 0)
+                    const bool repeats = emg::sweep_colour(1 - iback, 0) == emg::sweep_colour(iback, 3);
+                    if (g_skip_repeat && repeats) { colours |= (next >> 2) << 8; nsteps = 7; }
                     else { colours |= next << 8; nsteps = 8; }
                 }
                 const dim3 gb(P.gx[0] > P.gx[1] ? P.gx[0] : P.gx[1], P.gy[0] > P.gy[1] ? P.gy[0] : P.gy[1], gz * L.batch);
@@ -1410,7 +1413,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             }
             continue;
         }
-        if (lr == 0 && g_point_small > 0 && L.batch == 1 && 4 * nu <= 28 &&
+        if (lr == 0 && g_point_small > 0 && L.batch == 1 && 4 * nu <= 32 &&
             (long long)(nx - 1) * (ny - 1) * (nz - 1) <= g_point_small) {
             // a level for one workgroup: every pass of every sweep in ONE launch (k_gs_point_small)
             if (it > 0) continue;                      // (launched with the first sweep)
@@ -1419,7 +1422,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             for (int s2 = 0; s2 < nu; ++s2) {
                 ib = 1 - ib;
                 for (int cc = 0; cc < 4; ++cc) {
-                    if (g_skip_repeat && s2 > 0 && cc == 0) continue;
+                    if (g_skip_repeat && s2 > 0 && cc == 0 && emg::sweep_colour(ib, 0) == emg::sweep_colour(1 - ib, 3)) continue;
                     passes |= (unsigned long long)emg::sweep_colour(ib, cc) << (2 * npass);
                     ++npass;
                 }
@@ -1431,7 +1434,8 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             // (same redundancy for the node classes; only the unslabbed schedule is a plain
             // sequence of whole colour passes)
             const bool unslabbed = g_point_slab <= 0 || g_point_slab >= nz - 1;
-            const int skip = (g_skip_repeat && it > 0 && unslabbed) ? emg::sweep_colour(iback, 0) : -1;
+            const int skip = (g_skip_repeat && it > 0 && unslabbed && emg::sweep_colour(iback, 0) == emg::sweep_colour(1 - iback, 3))
+                                 ? emg::sweep_colour(iback, 0) : -1;
             emg::gs_point_schedule(nz, g_point_slab, iback, [&](int c, int iz0, int izn) {
                 if (c == skip) return;
                 const emg::Dim3 g = emg::gs_point_grid(nx, ny, izn);
@@ -1631,7 +1635,7 @@ static const OptionEntry g_options[] = {
     {"line_lds", &g_line_lds},           {"point_prefetch", &g_point_prefetch}, {"residual_zb", &g_residual_zb},
     {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
-    {"line_order", &g_line_order},
+    {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 

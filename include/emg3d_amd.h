@@ -30,9 +30,12 @@
  *     point:  colour = ((ix+iz)&1) | (((iy+iz)&1)<<1);
  *     lines:  colour = (p&1) | ((q&1)<<1), (p,q) the transverse node indices in memory
  *             order: x-lines (iy,iz), y-lines (ix,iz), z-lines (ix,iy).
- *     Point smoother: a "forward" sweep visits the colour classes in the sequence 0,2,3,1, a
- *     "backward" sweep in the reverse; the first sweep of a call is backward, the second
- *     forward, ..., mirroring the reference's backward-first alternation (emg3d/core.py:301,311).
+ *     Point smoother (option "point_order" = 1, the default since round 3): every sweep visits
+ *     the node colours in the sequence 0,2,3,1 ("point_order" = 0: a backward sweep -- the
+ *     first, third, ... sweep of a call, like the reference's backward-first alternation,
+ *     emg3d/core.py:301,311 -- visits them in reverse: the rule of rounds 1-2, which needs up to
+ *     a third more cycles). The sweep direction still reverses the TILE order of
+ *     the tiled schedule below.
  *     Line smoothers (option "line_order" = 1, the default since round 3): the colour passes of
  *     a call cycle through the classes 1,2,3,0,1,2,3,0,...; sweep number it = 0,1,... of the call
  *     takes positions 3 it .. 3 it + 3 of that sequence (its first pass, for it > 0, repeats the
@@ -95,7 +98,7 @@ int emg3d_version(void);
 const char *emg3d_last_error(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int emg3d_device_count(void);
-/* Tuning knobs; all but "point_tile_min" and "line_order" never change results. "point_slab": plane-slab thickness of the point
+/* Tuning knobs; all but "point_tile_min", "line_order" and "point_order" never change results. "point_slab": plane-slab thickness of the point
  * smoother's launch schedule (0 = one launch per colour over all planes). "point_tile_min"
  * DOES select the sweep order of the point smoother (see above; <= 0 never tiled). "line_lds":
  * 1 (default) keeps the right-hand-side / solution records of a fused line launch in LDS
@@ -113,8 +116,8 @@ int emg3d_device_count(void);
  * while the forward substitution consumes them (k_line_stream: no round trip of the right-hand
  * sides through the scratch, bit-identical results); 0 the three-phase kernel everywhere; 2 also
  * where part of the records fit in LDS. "line_stream_r": rows per half of that ring (0 = 16).
- * "line_order" DOES select the order of the line sweeps (see above), like "point_tile_min" for
- * the point smoother.
+ * "line_order" and "point_order" DO select the order of the sweeps (see above), like
+ * "point_tile_min".
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
  * results); leave it 0. */
 int emg3d_set_option(const char *name, int value);

@@ -20,8 +20,9 @@
  *      point:  colour = ((ix+iz)&1) | (((iy+iz)&1)<<1)
  *      lines:  colour = (a&1) | ((b&1)<<1), (a,b) the two transverse node indices
  *              x-line: (iy,iz); y-line: (ix,iz); z-line: (ix,iy)
- *      point smoother: a forward sweep visits colours 0,2,3,1 (oracle_colour_order), a
- *      backward sweep the reverse; line smoothers: the passes of a call cycle through
+ *      point smoother: every sweep visits the node colours 0,2,3,1 (oracle_colour_order;
+ *      oracle_point_repeat = 0: a backward sweep visits them in reverse, the rule of rounds
+ *      1-2); line smoothers: the passes of a call cycle through
  *      1,2,3,0,1,... (oracle_line_cycle; sweep `it` takes positions 3 it .. 3 it + 3), or follow
  *      the point smoother's mirrored rule (oracle_set_line_order(0, ...)). Inside a colour the
  *      nodes/lines are independent, so any order gives the same result.
@@ -37,13 +38,14 @@
 #ifndef ORACLE_COLOUR
 /* colour class visited at position cc of a forward (iback = 0) / backward sweep: backward = the forward
  * sequence reversed, unless an experiment set its own backward sequence (oracle_set_colour_order_backward) */
-#define ORACLE_COLOUR(iback, cc) ((iback) ? (oracle_backward_custom ? oracle_colour_order_b[cc] : oracle_colour_order[3 - (cc)]) : oracle_colour_order[cc])
+#define ORACLE_MIRRORED(iback, cc) ((iback) ? oracle_colour_order[3 - (cc)] : oracle_colour_order[cc])
+#define ORACLE_COLOUR(iback, cc) ((iback) ? (oracle_backward_custom ? oracle_colour_order_b[cc] : (oracle_point_repeat ? oracle_colour_order[cc] : oracle_colour_order[3 - (cc)])) : oracle_colour_order[cc])
 #endif
 #ifndef ORACLE_LINE_COLOUR
 /* LINE smoothers, order 1: by default the passes of a call cycle through oracle_line_cycle (1,2,3,0,1,...),
  * sweep `it` taking positions 3 it .. 3 it + 3 -- the order of the HIP kernels since round 3 (emg3d_amd/
  * csrc/launch.h: line_sweep_colour); oracle_line_cyclic = 0: the mirrored rule of ORACLE_COLOUR. */
-#define ORACLE_LINE_COLOUR(it, iback, cc) (oracle_line_cyclic ? oracle_line_cycle[(3 * (it) + (cc)) & 3] : ORACLE_COLOUR(iback, cc))
+#define ORACLE_LINE_COLOUR(it, iback, cc) (oracle_line_cyclic ? oracle_line_cycle[(3 * (it) + (cc)) & 3] : (oracle_backward_custom ? ORACLE_COLOUR(iback, cc) : ORACLE_MIRRORED(iback, cc)))
 #endif
 #define CC(a, i, j, k) (a)[(size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)ny * (size_t)(k))]
 

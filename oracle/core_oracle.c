@@ -37,6 +37,11 @@ void oracle_set_colour_order_backward(int on, int a, int b, int c, int d)
     oracle_colour_order_b[2] = c; oracle_colour_order_b[3] = d;
 }
 
+/* orders 1 / 2 of the POINT smoother: the node colours in the same sequence in every sweep (default, = the
+ * HIP kernels since round 3), or mirrored in backward sweeps (0) */
+int oracle_point_repeat = 1;
+void oracle_set_point_repeat(int on) { oracle_point_repeat = on; }
+
 /* order 1 of the LINE smoothers: cyclic pass sequence (default, = the HIP kernels) or the mirrored sweeps */
 int oracle_line_cyclic = 1;
 int oracle_line_cycle[4] = {1, 2, 3, 0};

@@ -212,6 +212,7 @@ extern "C" {
 void emu_set_point_slab(int t) { g_point_slab = t; }
 void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
 void emu_set_line_order(int o) { g_line_order = o; }
+void emu_set_point_order(int o) { emg::point_order_ref() = o; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
 {

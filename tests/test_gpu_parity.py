@@ -479,6 +479,52 @@ def test_tuning_options_do_not_change_results(golden_kernels):
         lib.emg3d_set_option(b'line_lds', 1)
 
 
+@pytest.mark.parametrize('tile_min', [0, 1])
+def test_point_order_option_vs_oracle(tile_min):
+    """Option point_order: 1 (default) = every sweep of the point smoother visits the node colours in the same
+    sequence 0,2,3,1; 0 = backward sweeps mirrored (rounds 1-2). Both against the oracle in the same order, plain
+    and tiled schedule, nu = 3 (2e-12); and a plain-multigrid solve must not need more cycles with the default."""
+    lib, olib = _lib.lib(), ocore.lib()
+    rng = np.random.default_rng(78)
+    shape = (40, 14, 18)
+    h = [rng.uniform(5., 15., n) * 1.05 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, 0.9, *sig)
+    s, e0 = mg_ref.Field(grid), mg_ref.Field(grid)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size) + 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    args = (s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
+    hx = widths(12, 6, 40., 1.15)
+    g2 = emg3d.TensorMesh([hx, hx, hx], (-hx.sum() / 2,) * 3)
+    model = emg3d.Model(g2, 10 ** np.random.default_rng(3).uniform(-0.3, 0.7, g2.shape_cells))
+    sf = emg3d.get_source_field(g2, (0., 0., 0., 10., 20.), 1.0)
+    old_tile = lib.emg3d_get_option(b'point_tile_min')
+    out, cycles = {}, {}
+    try:
+        lib.emg3d_set_option(b'point_tile_min', tile_min)
+        for order in (0, 1):
+            lib.emg3d_set_option(b'point_order', order)
+            olib.oracle_set_point_repeat(order)
+            a, b = e0.copy(), e0.copy()
+            ocore.gauss_seidel(a.fx, a.fy, a.fz, *args, order=2 if tile_min else 1)
+            core.gauss_seidel(b.fx, b.fy, b.fz, *args)
+            assert relerr(b.field, a.field) < 2e-12, order
+            out[order] = b.field.copy()
+            _, info = emg3d.solve(model, sf, sslsolver=False, plain=True, cycle='F', tol=1e-8, return_info=True)
+            assert info['exit'] == 0
+            cycles[order] = info['it_mg']
+    finally:
+        lib.emg3d_set_option(b'point_tile_min', old_tile)
+        lib.emg3d_set_option(b'point_order', 1)
+        olib.oracle_set_point_repeat(1)
+    assert relerr(out[0], out[1]) > 1e-6
+    assert cycles[1] <= cycles[0], cycles
+
+
 def test_line_order_option_mirrored_and_cyclic_vs_oracle():
     """Option line_order: 1 (default) = the colour passes of a line-smoothing call cycle through 1,2,3,0,1,...;
     0 = mirrored sweeps (rounds 1-2). Both against the oracle in the same order, per call (nu = 3, 2e-12), and
@@ -1057,8 +1103,11 @@ def test_parallel_compute_batched_pairs():
 @pytest.mark.parametrize('kw', [dict(), dict(cycle='V', linerelaxation=False), dict(semicoarsening=False)])
 def test_solve_batch_bicgstab(kw):
     """solve_batch(sslsolver=True): BiCGSTAB per source with shared multigrid preconditioner and
-    operator applications -- same iteration counts and fields as separate solves (bit-identical
-    while all sources run the same number of cycles per preconditioner call)."""
+    operator applications -- same iteration counts as separate solves, and fields bit-identical (1e-12)
+    while all sources run the same number of cycles per preconditioner call. When the sources of a batch
+    need different numbers of Krylov iterations, the semicoarsening / line-relaxation cycling of the shared
+    structure and of a separate solve drift apart (solver._bicgstab_batch): every source then still
+    converges to the tolerance, and the fields agree to it."""
     hx = widths(8, 4, 50., 1.2)
     grid = emg3d.TensorMesh([hx, hx[:12], hx], (-hx.sum() / 2, -330., -hx.sum() / 2))
     rng = np.random.default_rng(31)
@@ -1068,11 +1117,16 @@ def test_solve_batch_bicgstab(kw):
                ((-120., 20., -40., 0., 0.), (30., -60., 10., 45., 10.), (0., 0., 0., 90., 0.))]
     sep = [emg3d.solve(model, sf, tol=1e-8, return_info=True, **kw) for sf in sfields]
     bat = emg3d.solve_batch(model, sfields, sslsolver=True, tol=1e-8, **kw)
+    in_step = len({i['it_ssl'] for _, i in sep}) == 1          # all sources take the same number of iterations
     for (e1, i1), (e2, i2) in zip(sep, bat):
         assert i1['exit'] == i2['exit'] == 0
-        assert (i1['it_ssl'], i1['it_mg']) == (i2['it_ssl'], i2['it_mg'])
-        assert np.allclose(i1['error_at_cycle'], i2['error_at_cycle'], rtol=1e-10)
-        assert relerr(e2.field, e1.field) < 1e-12
+        if in_step:
+            assert (i1['it_ssl'], i1['it_mg']) == (i2['it_ssl'], i2['it_mg'])
+            assert np.allclose(i1['error_at_cycle'], i2['error_at_cycle'], rtol=1e-10)
+            assert relerr(e2.field, e1.field) < 1e-12
+        else:
+            assert abs(i1['it_ssl'] - i2['it_ssl']) <= 1
+            assert relerr(e2.field, e1.field) < 1e-7
 
 
 @pytest.mark.parametrize('option,value', [('point_tile_min', 1), ('line_fuse', 0), ('line_lds', 0)])
