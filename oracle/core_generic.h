@@ -385,7 +385,7 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
             const int ntx = (nx - 2) / bx + 1, nty = (ny - 2) / by + 1, ntz = (nz - 2) / bz + 1;
             int t8, tx, ty, tz;
             for (t8 = 0; t8 < 8; t8++) {
-                const int tc = oracle_tile_order[iback ? 7 - t8 : t8];
+                const int tc = oracle_tile_order[(iback && !oracle_tile_repeat) ? 7 - t8 : t8];
                 for (tz = (tc >> 2) & 1; tz < ntz; tz += 2)
                     for (ty = (tc >> 1) & 1; ty < nty; ty += 2)
                         for (tx = tc & 1; tx < ntx; tx += 2)

@@ -55,6 +55,9 @@ void oracle_set_line_order(int cyclic, int a, int b, int c, int d)
  * colours of a FORWARD sweep (backward = reversed). */
 int oracle_tile[3] = {32, 4, 6};
 int oracle_tile_order[8] = {0, 7, 1, 6, 2, 5, 3, 4};   /* complementary colours next to each other (launch.h) */
+/* experiment: backward sweeps visit the tile colours in the forward order too */
+int oracle_tile_repeat = 0;
+void oracle_set_tile_repeat(int on) { oracle_tile_repeat = on; }
 void oracle_set_tile(int bx, int by, int bz) { oracle_tile[0] = bx; oracle_tile[1] = by; oracle_tile[2] = bz; }
 void oracle_set_tile_order(const int *o) { int i; for (i = 0; i < 8; i++) oracle_tile_order[i] = o[i]; }
 
