@@ -16,6 +16,12 @@ import emg3d_amd as emg3d
 from oracle import mg_ref
 from helpers import widths
 bad = 0
+cycles_total = 0
+by_solver = {}        # solver -> [solves both converged, GPU cycles, oracle (lexicographic) cycles]
+if os.environ.get('LINE_ORDER') or os.environ.get('POINT_ORDER'):      # compare the sweep orders (cycle totals below)
+    from emg3d_amd import _lib
+    _lib.lib().emg3d_set_option(b'line_order', int(os.environ.get('LINE_ORDER', 1)))
+    _lib.lib().emg3d_set_option(b'point_order', int(os.environ.get('POINT_ORDER', 1)))
 t0 = time.time()
 for seed in [int(x) for x in os.environ.get("SEEDS","").split(",")] if os.environ.get("SEEDS") else range(40):
     rng = np.random.default_rng(int(os.environ.get("SEED_BASE", 11000)) + seed)
@@ -41,6 +47,9 @@ for seed in [int(x) for x in os.environ.get("SEEDS","").split(",")] if os.enviro
         eo, io = mg_ref.solve(vm, mg_ref.Field(og, sfield.field.copy()), tol=1e-10, **dict(kw, maxit=80))
         err = np.linalg.norm(e.field - eo.field) / np.linalg.norm(eo.field)
         air = rho.max() > 1e7
+        cycles_total += int(info['it_mg'])
+        if info['exit'] == 0 and io['exit'] == 0:
+            b = by_solver.setdefault(ssl, [0, 0, 0]); b[0] += 1; b[1] += int(info['it_mg']); b[2] += int(io['it_mg'])
         ok = info['exit'] == 0 and io['exit'] == 0 and err < (1e-5 if air else 1e-8)
         if not ok:
             bad += 1
@@ -50,4 +59,5 @@ for seed in [int(x) for x in os.environ.get("SEEDS","").split(",")] if os.enviro
         print('SEED', seed, shape, ssl, kw, 'EXC', repr(exc)[:300], flush=True)
     if time.time() - t0 > 1100:
         print('time limit at', seed); break
-print('done, failures:', bad, 'seconds %.0f' % (time.time() - t0))
+print('converged solves, cycles GPU / lexicographic oracle, by solver:', by_solver)
+print('done, failures:', bad, 'multigrid cycles in all solves:', cycles_total, 'seconds %.0f' % (time.time() - t0))
