@@ -99,7 +99,8 @@ int g_line_lpw = 0;
 // also where slots 0..3 would fit (~128-block lines: measured equal)
 int g_line_stream = 1;
 // sequence of the colour passes of the LINE smoothers (launch.h: line_sweep_colour): 1 (default) cyclic
-// 1,2,3,0,1,...; 0 mirrored sweeps (0,2,3,1 forward / its reverse backward: rounds 1-2). Like
+// 1,2,3,0,1,...; 0 mirrored sweeps (0,2,3,1 forward / its reverse backward: rounds 1-2); 2 the classes
+// 1,2,3,0 in every sweep (eight launches per two sweeps). Like
 // point_tile_min this selects the ORDER of the Gauss-Seidel sweep, i.e. it is part of the algorithm
 // definition (converged fields are the same; per-sweep values and cycle counts are not).
 int g_line_order = 1;
@@ -1451,7 +1452,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             // line_sweep_colour). A line solve depends on the edges NOT on the line only, and lines of
             // one class do not see each other: solving the class again right away reproduces the same
             // values bit by bit. (The reference's sequential sweeps have the same redundant first line.)
-            if (g_skip_repeat && it > 0 && cc == 0) continue;
+            if (g_skip_repeat && cc == 0 && emg::line_pass_repeats(g_line_order, it)) continue;
             if (lr == 1) launch_line_colour<T, 0>(L, c, (const T *)fac, lfac, (T *)scratch, st);
             else if (lr == 2) launch_line_colour<T, 1>(L, c, (const T *)fac, lfac, (T *)scratch, st);
             else launch_line_colour<T, 2>(L, c, (const T *)fac, lfac, (T *)scratch, st);

@@ -46,12 +46,20 @@ inline int sweep_colour(int iback, int cc)
 // backward sweep followed by its reverse, the sweep_colour() rule above) is among the slowest of
 // all 576 pairs -- 24 / 11 / 10 cycles to 1e-10 on configs 3 / 2 / 5 --, every cyclic one among the
 // fastest with seven passes per two sweeps -- 21 / 9 / 9 (the reference's sequential order: 17 / 8 / 8).
-// order 0: the mirrored rule (the definition of rounds 1-2, kept for comparison).
+// order 0: the mirrored rule (the definition of rounds 1-2, kept for comparison). order 2: the SAME
+// sequence 1,2,3,0 in every sweep -- no pass is shared between sweeps (4 nu launches per call), the
+// oracle needs as few cycles with it as with the reference's sequential sweeps.
 inline int line_sweep_colour(int order, int it, int cc)
 {
     if (order == 0) return mirrored_colour((it + 1) & 1, cc);     // first sweep backward
     const int seq[4] = {1, 2, 3, 0};
+    if (order == 2) return seq[cc];
     return seq[(3 * it + cc) & 3];
+}
+// the first pass of sweep `it` repeats the last pass of the sweep before it (and is not launched)
+inline bool line_pass_repeats(int order, int it)
+{
+    return it > 0 && line_sweep_colour(order, it, 0) == line_sweep_colour(order, it - 1, 3);
 }
 
 // ---- point smoother: colour = ((ix+iz)&1) | (((iy+iz)&1)<<1); global thread (gx,gy,gz);

@@ -45,7 +45,7 @@
 /* LINE smoothers, order 1: by default the passes of a call cycle through oracle_line_cycle (1,2,3,0,1,...),
  * sweep `it` taking positions 3 it .. 3 it + 3 -- the order of the HIP kernels since round 3 (emg3d_amd/
  * csrc/launch.h: line_sweep_colour); oracle_line_cyclic = 0: the mirrored rule of ORACLE_COLOUR. */
-#define ORACLE_LINE_COLOUR(it, iback, cc) (oracle_line_cyclic ? oracle_line_cycle[(3 * (it) + (cc)) & 3] : (oracle_backward_custom ? ORACLE_COLOUR(iback, cc) : ORACLE_MIRRORED(iback, cc)))
+#define ORACLE_LINE_COLOUR(it, iback, cc) (oracle_line_cyclic == 2 ? oracle_line_cycle[(cc) & 3] : oracle_line_cyclic ? oracle_line_cycle[(3 * (it) + (cc)) & 3] : (oracle_backward_custom ? ORACLE_COLOUR(iback, cc) : ORACLE_MIRRORED(iback, cc)))
 #endif
 #define CC(a, i, j, k) (a)[(size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)ny * (size_t)(k))]
 

@@ -527,9 +527,10 @@ def test_point_order_option_vs_oracle(tile_min):
 
 def test_line_order_option_mirrored_and_cyclic_vs_oracle():
     """Option line_order: 1 (default) = the colour passes of a line-smoothing call cycle through 1,2,3,0,1,...;
-    0 = mirrored sweeps (rounds 1-2). Both against the oracle in the same order, per call (nu = 3, 2e-12), and
-    on the reduced copy of config 3 the cyclic order must not need more cycles than the mirrored one (oracle:
-    21 against 24 at tol 1e-10)."""
+    0 = mirrored sweeps (rounds 1-2); 2 = the same sequence 1,2,3,0 in every sweep (4 nu launches, no shared pass).
+    Each against the oracle in the same order, per call (nu = 3, 2e-12), and on the reduced copy of config 3 the
+    cyclic order must not need more cycles than the mirrored one (oracle: 21 against 24 at tol 1e-10), the
+    repeated one not more than the cyclic one."""
     from bench import workload
     lib, olib = _lib.lib(), ocore.lib()
     rng = np.random.default_rng(77)
@@ -551,7 +552,7 @@ def test_line_order_option_mirrored_and_cyclic_vs_oracle():
     sf = emg3d.get_source_field(g64, ws['source'], ws['frequency'])
     cycles, fields = {}, {}
     try:
-        for order in (0, 1):
+        for order in (0, 1, 2):
             lib.emg3d_set_option(b'line_order', order)
             olib.oracle_set_line_order(order, 1, 2, 3, 0)
             for fn in SMOOTHERS[1:]:
@@ -568,7 +569,9 @@ def test_line_order_option_mirrored_and_cyclic_vs_oracle():
         olib.oracle_set_line_order(1, 1, 2, 3, 0)
     assert all(relerr(fields[(0, fn)], fields[(1, fn)]) > 1e-6 for fn in SMOOTHERS[1:])     # the orders do differ
     assert relerr(fields[1], fields[0]) < 1e-7                                               # ... the solutions do not
-    assert cycles[1] <= cycles[0] - 1, cycles
+    assert all(relerr(fields[(2, fn)], fields[(1, fn)]) > 1e-6 for fn in SMOOTHERS[1:])
+    assert relerr(fields[2], fields[0]) < 1e-7
+    assert cycles[1] <= cycles[0] - 1 and cycles[2] <= cycles[1], cycles
 
 
 @pytest.mark.parametrize('shape,lr', [((64, 96, 96), 1), ((96, 64, 96), 2), ((96, 96, 130), 3), ((258, 96, 96), 1),

@@ -160,6 +160,41 @@ def test_smoothers_odd_and_tiny_grids(shape):
         assert relerr(b.field, a.field) < 2e-12, (shape, fn)
 
 
+@pytest.mark.parametrize('order', [0, 2])
+def test_line_orders_other_than_the_default_match_oracle(order):
+    """launch.h: line_sweep_colour with the mirrored (0) and the repeated (2) sequence of the line passes --
+    the kernel bodies walked on the CPU against the oracle in the same order (nu = 3: every sweep of a call
+    differs under the cyclic default, none under order 2)."""
+    rng = np.random.default_rng(50 + order)
+    shape = (9, 6, 7)
+    grid = mg_ref.Grid([rng.uniform(10, 30, n) for n in shape], (0, 0, 0))
+    vm = mg_ref.volume_model(grid, 1.3, *[10 ** rng.uniform(-1, 1, shape) for _ in range(3)])
+    s, e0 = mg_ref.Field(grid), mg_ref.Field(grid)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size) + 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    out = {}
+    try:
+        for o in (1, order):
+            emu.lib().emu_set_line_order(o)
+            ocore.lib().oracle_set_line_order(o, 1, 2, 3, 0)
+            for fn, lr in LR.items():
+                if lr == 0:
+                    continue
+                a, b = e0.copy(), e0.copy()
+                getattr(ocore, fn)(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                                   vm.zeta, *grid.h, 3, order=1)
+                emu.gauss_seidel(b, s, vm, lr, 3)
+                assert relerr(b.field, a.field) < 2e-12, (o, fn)
+                out[(o, fn)] = b.field.copy()
+    finally:
+        emu.lib().emu_set_line_order(1)
+        ocore.lib().oracle_set_line_order(1, 1, 2, 3, 0)
+    assert all(relerr(out[(order, fn)], out[(1, fn)]) > 1e-6 for fn, lr in LR.items() if lr)
+
+
 @pytest.mark.parametrize('slab', [1, 2, 3, 5, 64])
 def test_point_slab_schedule_is_bit_identical(golden_kernels, slab):
     """The skewed plane-slab launch schedule of the point smoother (launch.h) must give

@@ -12,7 +12,7 @@ for name in ('triaxial256', 'marine128', 'salt384'):
     grid = emg3d.TensorMesh(wl['h'], wl['origin'])
     model = emg3d.Model(grid, **wl['res'])
     sf = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
-    for order in (0, 1):
+    for order in [int(x) for x in os.environ.get("ORDERS", "0,1").split(",")]:
         _lib.lib().emg3d_set_option(b'line_order', order)
         for tol in (1e-6, 1e-8):
             torch.cuda.synchronize(); t0 = time.perf_counter()
