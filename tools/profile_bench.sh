@@ -13,7 +13,7 @@ mkdir -p $O
 B="python $R/bench.py --workload $WL --no-256 --no-survey --no-cpu-baseline"
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- $B > $O/trace.log 2>&1
 python $R/tools/rocpd_summary.py $O/trace/run_results.db > $R/gpurun_out/${TAG}_${WL}_kernel_stats.txt
-python $R/tools/trace_by_grid.py $O/trace/run_results.db k_line_colour > $R/gpurun_out/${TAG}_${WL}_line_launches_by_level.txt
+python $R/tools/trace_by_grid.py $O/trace/run_results.db k_line_ > $R/gpurun_out/${TAG}_${WL}_line_launches_by_level.txt
 # (counter collection crashes inside HIP graph replays on this stack: the same kernels, launched eagerly.
 #  Even so rocprofv3 segfaults -- once it hung -- in about every second counter pass over this
 #  134 000-dispatch run, whatever the library options: bounded time, up to three attempts per pass)
