@@ -370,12 +370,18 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
         } else if (order == 1) {
             for (cc = 0; cc < 4; cc++) {
                 c = ORACLE_COLOUR(iback, cc);
-                for (izh = 1; izh < nz; izh++)
-                    for (iyh = 1; iyh < ny; iyh++)
-                        for (ixh = 1; ixh < nx; ixh++)
-                            if ((((ixh + izh) & 1) | (((iyh + izh) & 1) << 1)) == c)
-                                FN(gs_node)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx,
-                                            hy, hz, kx, ky, kz, nx, ny, nz, ixh, iyh, izh);
+                /* (nodes of one colour are independent: threads change nothing, oracle_set_threads) */
+#pragma omp parallel num_threads(oracle_threads) if (oracle_threads > 1)
+                {
+                    int q1, q2, q3;
+#pragma omp for collapse(2) schedule(static)
+                    for (q3 = 1; q3 < nz; q3++)
+                        for (q2 = 1; q2 < ny; q2++)
+                            for (q1 = 1; q1 < nx; q1++)
+                                if ((((q1 + q3) & 1) | (((q2 + q3) & 1) << 1)) == c)
+                                    FN(gs_node)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx,
+                                                hy, hz, kx, ky, kz, nx, ny, nz, q1, q2, q3);
+                }
             }
         } else {
             /* order 2: tiles of oracle_tile[0..2] nodes, eight tile colours
@@ -383,22 +389,29 @@ void FN(gauss_seidel)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *sz
              * reversed); inside a tile the four node colours of order 1. */
             const int bx = oracle_tile[0], by = oracle_tile[1], bz = oracle_tile[2];
             const int ntx = (nx - 2) / bx + 1, nty = (ny - 2) / by + 1, ntz = (nz - 2) / bz + 1;
-            int t8, tx, ty, tz;
+            int t8;
             for (t8 = 0; t8 < 8; t8++) {
                 const int tc = oracle_tile_order[(iback && !oracle_tile_repeat) ? 7 - t8 : t8];
-                for (tz = (tc >> 2) & 1; tz < ntz; tz += 2)
-                    for (ty = (tc >> 1) & 1; ty < nty; ty += 2)
-                        for (tx = tc & 1; tx < ntx; tx += 2)
-                            for (cc = 0; cc < 4; cc++) {
-                                c = ORACLE_COLOUR(iback, cc);
-                                for (izh = 1 + tz * bz; izh < nz && izh < 1 + (tz + 1) * bz; izh++)
-                                    for (iyh = 1 + ty * by; iyh < ny && iyh < 1 + (ty + 1) * by; iyh++)
-                                        for (ixh = 1 + tx * bx; ixh < nx && ixh < 1 + (tx + 1) * bx; ixh++)
-                                            if ((((ixh + izh) & 1) | (((iyh + izh) & 1) << 1)) == c)
-                                                FN(gs_node)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z,
-                                                            zeta, hx, hy, hz, kx, ky, kz, nx, ny, nz,
-                                                            ixh, iyh, izh);
-                            }
+                const int tz0 = (tc >> 2) & 1, ty0 = (tc >> 1) & 1, tx0 = tc & 1;
+                /* (tiles of one tile colour share no edge that either reads or writes: independent) */
+#pragma omp parallel num_threads(oracle_threads) if (oracle_threads > 1)
+                {
+                    int tx, ty, tz, q1, q2, q3, c2, cq;
+#pragma omp for collapse(3) schedule(static)
+                    for (tz = tz0; tz < ntz; tz += 2)
+                        for (ty = ty0; ty < nty; ty += 2)
+                            for (tx = tx0; tx < ntx; tx += 2)
+                                for (cq = 0; cq < 4; cq++) {
+                                    c2 = ORACLE_COLOUR(iback, cq);
+                                    for (q3 = 1 + tz * bz; q3 < nz && q3 < 1 + (tz + 1) * bz; q3++)
+                                        for (q2 = 1 + ty * by; q2 < ny && q2 < 1 + (ty + 1) * by; q2++)
+                                            for (q1 = 1 + tx * bx; q1 < nx && q1 < 1 + (tx + 1) * bx; q1++)
+                                                if ((((q1 + q3) & 1) | (((q2 + q3) & 1) << 1)) == c2)
+                                                    FN(gs_node)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z,
+                                                                zeta, hx, hy, hz, kx, ky, kz, nx, ny, nz,
+                                                                q1, q2, q3);
+                                }
+                }
             }
         }
     }
@@ -535,13 +548,23 @@ void FN(gauss_seidel_x)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
                 }
             }
         } else {
+            /* the lines of a colour class are independent: any order, any number of threads gives the
+             * same values bit by bit (oracle_set_threads; full-size parity tests) */
             for (cc = 0; cc < 4; cc++) {
                 c = ORACLE_LINE_COLOUR(it, iback, cc);
-                for (izh = 1; izh < nz; izh++)
-                    for (iyh = 1; iyh < ny; iyh++)
-                        if (((iyh & 1) | ((izh & 1) << 1)) == c)
-                            FN(gs_line_x)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx, hy,
-                                          hz, kx, ky, kz, nx, ny, nz, iyh, izh, amat, bvec);
+#pragma omp parallel num_threads(oracle_threads) if (oracle_threads > 1)
+                {
+                    T *bv = oracle_threads > 1 ? (T *)malloc(sizeof(T) * (size_t)nr * 7) : bvec;
+                    T *am = bv + nr;
+                    int q1, q2;
+#pragma omp for collapse(2) schedule(static)
+                    for (q2 = 1; q2 < nz; q2++)
+                        for (q1 = 1; q1 < ny; q1++)
+                            if (((q1 & 1) | ((q2 & 1) << 1)) == c)
+                                FN(gs_line_x)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx, hy,
+                                              hz, kx, ky, kz, nx, ny, nz, q1, q2, am, bv);
+                    if (oracle_threads > 1) free(bv);
+                }
             }
         }
     }
@@ -680,13 +703,23 @@ void FN(gauss_seidel_y)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
                 }
             }
         } else {
+            /* the lines of a colour class are independent: any order, any number of threads gives the
+             * same values bit by bit (oracle_set_threads; full-size parity tests) */
             for (cc = 0; cc < 4; cc++) {
                 c = ORACLE_LINE_COLOUR(it, iback, cc);
-                for (izh = 1; izh < nz; izh++)
-                    for (ixh = 1; ixh < nx; ixh++)
-                        if (((ixh & 1) | ((izh & 1) << 1)) == c)
-                            FN(gs_line_y)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx, hy,
-                                          hz, kx, ky, kz, nx, ny, nz, ixh, izh, amat, bvec);
+#pragma omp parallel num_threads(oracle_threads) if (oracle_threads > 1)
+                {
+                    T *bv = oracle_threads > 1 ? (T *)malloc(sizeof(T) * (size_t)nr * 7) : bvec;
+                    T *am = bv + nr;
+                    int q1, q2;
+#pragma omp for collapse(2) schedule(static)
+                    for (q2 = 1; q2 < nz; q2++)
+                        for (q1 = 1; q1 < nx; q1++)
+                            if (((q1 & 1) | ((q2 & 1) << 1)) == c)
+                                FN(gs_line_y)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx, hy,
+                                              hz, kx, ky, kz, nx, ny, nz, q1, q2, am, bv);
+                    if (oracle_threads > 1) free(bv);
+                }
             }
         }
     }
@@ -824,13 +857,23 @@ void FN(gauss_seidel_z)(T *ex, T *ey, T *ez, const T *sx, const T *sy, const T *
                 }
             }
         } else {
+            /* the lines of a colour class are independent: any order, any number of threads gives the
+             * same values bit by bit (oracle_set_threads; full-size parity tests) */
             for (cc = 0; cc < 4; cc++) {
                 c = ORACLE_LINE_COLOUR(it, iback, cc);
-                for (iyh = 1; iyh < ny; iyh++)
-                    for (ixh = 1; ixh < nx; ixh++)
-                        if (((ixh & 1) | ((iyh & 1) << 1)) == c)
-                            FN(gs_line_z)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx, hy,
-                                          hz, kx, ky, kz, nx, ny, nz, ixh, iyh, amat, bvec);
+#pragma omp parallel num_threads(oracle_threads) if (oracle_threads > 1)
+                {
+                    T *bv = oracle_threads > 1 ? (T *)malloc(sizeof(T) * (size_t)nr * 7) : bvec;
+                    T *am = bv + nr;
+                    int q1, q2;
+#pragma omp for collapse(2) schedule(static)
+                    for (q2 = 1; q2 < ny; q2++)
+                        for (q1 = 1; q1 < nx; q1++)
+                            if (((q1 & 1) | ((q2 & 1) << 1)) == c)
+                                FN(gs_line_z)(ex, ey, ez, sx, sy, sz, eta_x, eta_y, eta_z, zeta, hx, hy,
+                                              hz, kx, ky, kz, nx, ny, nz, q1, q2, am, bv);
+                    if (oracle_threads > 1) free(bv);
+                }
             }
         }
     }

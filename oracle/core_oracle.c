@@ -42,6 +42,11 @@ void oracle_set_colour_order_backward(int on, int a, int b, int c, int d)
 int oracle_point_repeat = 1;
 void oracle_set_point_repeat(int on) { oracle_point_repeat = on; }
 
+/* threads of the four-colour / tiled orders (classes of independent nodes, lines, tiles: results do not
+ * depend on it); 1 = serial. The reference order (0) is sequential by definition and never threaded. */
+int oracle_threads = 1;
+void oracle_set_threads(int n) { oracle_threads = n > 1 ? n : 1; }
+
 /* order 1 of the LINE smoothers: cyclic pass sequence (default, = the HIP kernels) or the mirrored sweeps */
 int oracle_line_cyclic = 1;
 int oracle_line_cycle[4] = {1, 2, 3, 0};

@@ -24,6 +24,17 @@ from helpers import relerr, widths
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(scope='module', autouse=True)
+def _oracle_threads():
+    """The oracle's four-colour / tiled orders walk classes of independent nodes, lines and tiles: with threads
+    (oracle_set_threads) the values are the same bit by bit (tests/test_kernel_bodies_cpu.py) and the full-size
+    cases take a fifth of the time. The reference order stays sequential."""
+    from helpers import usable_cores
+    ocore.lib().oracle_set_threads(usable_cores())
+    yield
+    ocore.lib().oracle_set_threads(1)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SMOOTHERS = ('gauss_seidel', 'gauss_seidel_x', 'gauss_seidel_y', 'gauss_seidel_z')

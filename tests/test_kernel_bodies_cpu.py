@@ -160,6 +160,34 @@ def test_smoothers_odd_and_tiny_grids(shape):
         assert relerr(b.field, a.field) < 2e-12, (shape, fn)
 
 
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_oracle_threads_change_nothing(dtype):
+    """oracle_set_threads: the four-colour orders (point 1 / 2, lines 1) with 1 and 6 threads, bit for bit."""
+    rng = np.random.default_rng(8)
+    shape = (37, 13, 15)            # two tiles of 32 nodes in x, several in y and z
+    grid = mg_ref.Grid([rng.uniform(10, 30, n) for n in shape], (0, 0, 0))
+    vm = mg_ref.volume_model(grid, 1.3 if dtype is complex else -1.3, *[10 ** rng.uniform(-1, 1, shape) for _ in range(3)])
+    s, e0 = mg_ref.Field(grid, dtype=dtype), mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+    out = {}
+    try:
+        for nt in (1, 6):
+            ocore.lib().oracle_set_threads(nt)
+            for fn, lr in LR.items():
+                for order in ((1, 2) if lr == 0 else (1,)):
+                    a = e0.copy()
+                    getattr(ocore, fn)(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                                       vm.zeta, *grid.h, 3, order=order)
+                    out[(nt, fn, order)] = a.field.copy()
+    finally:
+        ocore.lib().oracle_set_threads(1)
+    for (nt, fn, order), v in out.items():
+        if nt == 6:
+            assert np.array_equal(v, out[(1, fn, order)]), (fn, order)
+            assert np.any(v != e0.field)
+
+
 @pytest.mark.parametrize('order', [0, 2])
 def test_line_orders_other_than_the_default_match_oracle(order):
     """launch.h: line_sweep_colour with the mirrored (0) and the repeated (2) sequence of the line passes --
