@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -1649,6 +1650,11 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "residual_zb") && value < 1) value = 1;
     if (!std::strcmp(name, "line_lpw") && value != 0 && value != 4 && value != 8 && value != 16 && value != 32)
         return fail(EMG3D_ERR_BADARG, "line_lpw: 0, 4, 8, 16 or 32");
+    // line_debug produces WRONG fields by design (timing experiments): only with the environment's consent
+    if (!std::strcmp(name, "line_debug") && value != 0 && !std::getenv("EMG3D_AMD_ALLOW_DEBUG"))
+        return fail(EMG3D_ERR_BADARG, "line_debug: wrong results by design; set EMG3D_AMD_ALLOW_DEBUG=1 to use it");
+    if (!std::strcmp(name, "line_order") && (value < 0 || value > 2)) return fail(EMG3D_ERR_BADARG, "line_order: 0, 1 or 2");
+    if (!std::strcmp(name, "point_order") && (value < 0 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_order: 0 or 1");
     for (const OptionEntry &o : g_options)
         if (!std::strcmp(name, o.name)) { *o.value = value; return 0; }
     return fail(EMG3D_ERR_BADARG, "set_option: unknown option");

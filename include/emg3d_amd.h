@@ -121,7 +121,8 @@ int emg3d_device_count(void);
  * "line_order" and "point_order" DO select the order of the sweeps (see above), like
  * "point_tile_min".
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
- * results); leave it 0. */
+ * results); a non-zero value is refused unless the environment variable EMG3D_AMD_ALLOW_DEBUG is set.
+ * Out-of-range values of "line_order" (0..2) and "point_order" (0..1) are refused (EMG3D_ERR_BADARG). */
 int emg3d_set_option(const char *name, int value);
 int emg3d_get_option(const char *name);
 /* enumeration of the options (for callers that key cached state -- captured graphs, option-

@@ -361,6 +361,17 @@ def test_option_table_and_fingerprint():
     assert lib.emg3d_set_option(b'line_lpw', 5) != 0                      # only 0, 4, 8, 16, 32
     assert lib.emg3d_set_option(b'residual_zb', 0) == 0 and lib.emg3d_get_option(b'residual_zb') == 1
     lib.emg3d_set_option(b'residual_zb', 8)
+    # options that select the sweep order take their defined values only; the wrong-results debug switch
+    # needs the environment's consent
+    assert lib.emg3d_set_option(b'line_order', 3) != 0 and lib.emg3d_set_option(b'point_order', 2) != 0
+    assert lib.emg3d_get_option(b'line_order') == 1 and lib.emg3d_get_option(b'point_order') == 1
+    had = os.environ.pop('EMG3D_AMD_ALLOW_DEBUG', None)
+    try:
+        assert lib.emg3d_set_option(b'line_debug', 1) != 0 and lib.emg3d_get_option(b'line_debug') == 0
+        assert lib.emg3d_set_option(b'line_debug', 0) == 0
+    finally:
+        if had is not None:
+            os.environ['EMG3D_AMD_ALLOW_DEBUG'] = had
 
 
 def test_bench_helpers_without_a_gpu():
