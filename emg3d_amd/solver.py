@@ -105,7 +105,9 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     in exact arithmetic, but the rounding errors of the smoothers then scale with the residual
     instead of the field, so that the iteration converges to round-off where the stored block
     inverses of the line smoothers would otherwise stall it (air layers, very low frequencies:
-    DESIGN.md 4.3); 'auto' switches it on where model and tolerance call for it.
+    DESIGN.md 4.3); 'auto' switches it on where model and tolerance call for it, and in the middle of
+    a solve whose direct-form cycles stagnate above the tolerance (the cycling then continues on the
+    residual equation instead of returning STAGNATED).
 
     Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``).
     """
@@ -124,6 +126,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
             "with `emg3d.fields.Field`, providing frequency information.")
     var.smoother_omega = _check_omega(extra['smoother_omega'])
     var.residual_form = _residual_form(extra['residual_form'], var, model, sfield)
+    var.residual_form_auto = isinstance(extra['residual_form'], str)      # 'auto': may still switch on a stall
     var.sparse_source = bool(extra['_sparse_source']) and getattr(sfield, '_sparse', None) is not None
     var.download = bool(extra['_download'])
     var.l2_refe = _host_norm(sfield._sparse[1] if var.sparse_source else sfield.field)
@@ -230,7 +233,10 @@ _INFO = (('exit', lambda v: int(v.exit_message != 'CONVERGED')), ('exit_message'
          ('runtime_at_cycle', lambda v: v.runtime_at_cycle), ('error_at_cycle', lambda v: v.error_at_cycle),
          ('log', lambda v: v.log_message),
          # addition of this package (not in the reference):
-         ('smoother_cell_sweeps', lambda v: v.smoother_cell_sweeps))
+         ('smoother_cell_sweeps', lambda v: v.smoother_cell_sweeps),
+         # the finest level ran (True), or ended up running ('switched'), on the residual equation
+         ('residual_form', lambda v: 'switched' if getattr(v, 'residual_form_switched', False)
+          else bool(getattr(v, 'residual_form', False))))
 
 
 def _info_dict(var):

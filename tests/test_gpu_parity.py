@@ -1789,6 +1789,45 @@ def test_residual_form_converges_to_roundoff_with_an_air_layer():
     assert np.allclose(ia['error_at_cycle'], ib['error_at_cycle'], rtol=1e-5)
 
 
+def test_stalled_direct_form_continues_on_the_residual_equation():
+    """A solve whose direct-form cycles stall above the tolerance (found by tools/soak_same_order.py: 40^3,
+    stretched 1.15, blocky tri-axial model, 0.5 Hz, tol 1e-9 -- the direct form's floor is 1.7e-9 there, under
+    the 'auto' rule's radar) must not return STAGNATED where the reference converges: with residual_form='auto'
+    the cycling continues on the residual equation and converges; residual_form=False keeps the old behaviour;
+    the oracle (same ordering) converges in 10 cycles."""
+    rng = np.random.default_rng(83017)
+    shape = (40, 40, 40)
+    h = [widths(n // 2, n // 4, 25., 1.15) for n in shape]
+    grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
+    shape = grid.shape_cells
+    blocks = tuple(max(n // 8, 1) for n in shape)
+    rho = np.kron(10 ** rng.uniform(-0.5, 1.5, blocks), np.ones([-(-n // b) for n, b in zip(shape, blocks)]))
+    rho = np.asfortranarray(rho[:shape[0], :shape[1], :shape[2]])
+    model = emg3d.Model(grid, rho, 1.5 * rho, 2.5 * rho)
+    sfield = emg3d.get_source_field(grid, (10., -20., 30., 40., 10.), 0.5)
+    kw = dict(sslsolver=False, cycle='F', semicoarsening=23, linerelaxation=7, nu_pre=1, nu_post=3, maxit=40)
+    tol, infod = None, None
+    for t in (1e-9, 3e-10, 1e-10, 3e-11):             # the first tolerance under the direct form's floor
+        _, infod = emg3d.solve(model, sfield, tol=t, residual_form=False, return_info=True, **kw)
+        if infod['exit'] == 1:
+            tol = t
+            break
+    assert tol is not None and infod['exit_message'] == 'STAGNATED' and infod['residual_form'] is False
+    e, info = emg3d.solve(model, sfield, tol=tol, return_info=True, **kw)
+    assert info['exit'] == 0 and info['residual_form'] in ('switched', True), (info['exit_message'], info['residual_form'])
+    og = mg_ref.Grid(grid.h, grid.origin)
+    vm = mg_ref.volume_model(og, 0.5, 1 / rho, 1 / (1.5 * rho), 1 / (2.5 * rho))
+    oo = {k: v for k, v in kw.items() if k != 'sslsolver'}
+    eo, io = mg_ref.solve(vm, mg_ref.Field(og, sfield.field.copy()), tol=tol, order=1, **oo)
+    assert io['exit'] == 0
+    assert relerr(e.field, eo.field) < 1e-8
+    if info['residual_form'] == 'switched':            # the stall cost a few cycles, not the solve
+        assert io['it_mg'] < info['it_mg'] <= io['it_mg'] + 8
+    # a solve that converges in direct form is untouched
+    _, i6 = emg3d.solve(model, sfield, tol=1e-6, return_info=True, **kw)
+    assert i6['exit'] == 0 and i6['residual_form'] is False
+
+
 def test_volume_average_adjoint_is_the_transpose():
     """`_VolumeAverage.adjoint_add` (the gradient's way back from a computational grid, reference
     maps._interp_volume_average_adj) is the exact transpose of the linear averaging the same plan
