@@ -4,7 +4,11 @@ logic are exercised) against the oracle's driver in the SAME smoother ordering (
 serial walk): the cycle counts and exit states must be equal and the fields agree to 1e-9 (1e-7 on the ill-conditioned
 models that run in residual form). Found in round 3: a model whose direct form stalls above tol 1e-9 unnoticed by the
 'auto' rule -> the cycling now switches to the residual equation by itself.
-    SEED_BASE=... SEEDS=... python tools/soak_same_order.py"""
+    SEED_BASE=... SEEDS=... python tools/soak_same_order.py
+SSL=bicgstab|cgs|gcrotmk|True: the GPU side solves with that Krylov method (multigrid as preconditioner); then only the
+exit states and the fields (1e-7) are compared. (gcrotmk fails its first preconditioner call on unit-dipole sources, as in the
+reference: the multigrid's divergence rule measures GCROT's unit-norm vectors against the source's norm, emg3d/solver.py:1627.
+Where the oracle's multigrid alone runs into maxit, a converged Krylov solve is reported as DIFFERENT: not a failure.)"""
 import sys, os, time
 root = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
@@ -44,17 +48,19 @@ for seed in seeds:
               nu_pre=int(rng.integers(1, 4)), nu_post=int(rng.integers(1, 4)))
     try:
         rf = {'1': True, '0': False}.get(os.environ.get('RESFORM', ''), 'auto')
-        e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-9, return_info=True, residual_form=rf, **kw)
+        ssl = os.environ.get('SSL', '')            # bicgstab / cgs / gcrotmk / True: the GPU side as a Krylov solve
+        ssl = {'': False, 'True': True}.get(ssl, ssl)
+        e, info = emg3d.solve(model, sfield, sslsolver=ssl, tol=1e-9, return_info=True, residual_form=rf, **kw)
         og = mg_ref.Grid(grid.h, grid.origin)
         inv = lambda p: None if p is None else 1 / p
         vm = mg_ref.volume_model(og, freq, *[inv(p) for p in (props + (None, None))[:3]])
         eo, io = mg_ref.solve(vm, mg_ref.Field(og, sfield.field.copy()), tol=1e-9, order=1, **kw)
         err = relerr(e.field, eo.field)
-        same = info["it_mg"] == io["it_mg"] and info["exit"] == io["exit"]
+        same = info["exit"] == io["exit"] and (bool(ssl) or info["it_mg"] == io["it_mg"])
         # (where the direct form's floor lies above the tolerance -- residual form on -- the system is so ill-conditioned
         # that two iterates with the same residual history differ by 1e-8 in the near-null space of the operator)
-        ok = same and (err < (1e-9 if info['residual_form'] is False else 1e-7) or info['exit'] != 0)
-        print('SEED', seed, shape, 'case', case, 'f', freq, kw, '| exit', info['exit'], io['exit'], 'cycles', info['it_mg'], io['it_mg'],
+        ok = same and (err < (1e-7 if (ssl or info['residual_form'] is not False) else 1e-9) or info['exit'] != 0)
+        print('SEED', seed, shape, 'case', case, 'f', freq, kw, '| exit', info['exit'], io['exit'], 'cycles', info['it_mg'], io['it_mg'], 'krylov it', info.get('it_ssl'),
               'rel.err %.3e %.3e' % (info['rel_error'], io['rel_error']), 'fields %.1e' % err, 'residual form', info['residual_form'], 'ok' if ok else 'DIFFERENT', flush=True)
         bad += 0 if ok else 1
     except Exception as exc:
