@@ -295,6 +295,9 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     vars_ = [new_var() for _ in sfields]
     var = svar = new_var()             # carries the structure of the cycle, shared by all sources
     svar.residual_form = _residual_form(resform, svar, model, first)
+    svar.residual_form_auto = isinstance(resform, str)
+    for v in vars_:
+        v.residual_form = svar.residual_form
     if var.sslsolver not in (None, False, 'bicgstab') or (var.sslsolver and not var.cycle):
         raise ValueError("solve_batch: multigrid, or BiCGSTAB with multigrid as preconditioner.")
     def rec_of(b):
@@ -361,6 +364,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
     it = 0
     # (finest level in residual form, as _cycle.run_cycles does it for one source)
     resform = bool(getattr(svar, 'residual_form', False)) and not svar.sslsolver
+    may_switch = bool(getattr(svar, 'residual_form_auto', False)) and not svar.sslsolver
     if resform:
         lv._b_valid = False
     l2_last = lv.residual(store=resform, norm=True)
@@ -397,6 +401,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
             svar.sc_dir = next(svar.sc_cycle)
         if svar.lr_cycle:
             svar.lr_dir = next(svar.lr_cycle)
+        switch = False
         for b, v in enumerate(vars_):
             if not active[b]:
                 continue
@@ -405,14 +410,30 @@ def _multigrid_batch(lv, svar, vars_, active=None):
             v.sc_dir, v.lr_dir = sc_now, lr_now           # what the log line of this cycle shows
             _print_cycle_info(v, float(l2_last[b]), float(l2_prev[b]))
             v.sc_dir, v.lr_dir = svar.sc_dir, svar.lr_dir
+            stag = float(l2_stag[b, (it - 1) % svar.maxcycle])
+            if may_switch and not resform and it < v.maxit:
+                # (as _cycle.run_cycles: a direct form that stalls above the tolerance goes on in residual form --
+                # here the whole batch does, from the next cycle on)
+                reason = _cycle.stop_reason(v, float(l2_last[b]), stag, it)
+                if reason is not None and reason[0] == "STAGNATED":
+                    switch = True
+                    continue
             try:
-                finished = _terminate(v, float(l2_last[b]), float(l2_stag[b, (it - 1) % svar.maxcycle]), it)
+                finished = _terminate(v, float(l2_last[b]), stag, it)
             except _ConvergenceError:
                 finished = failed[b] = True
             if finished:
                 active[b] = False
                 v.l2 = float(l2_last[b])
                 done[b] = lv.e[b * n:(b + 1) * n].clone()
+        if switch and any(active):
+            resform = svar.residual_form = True
+            lv._b_valid = False
+            lv.residual(store=True, norm=False)
+            l2_stag[:] = np.inf
+            for b, v in enumerate(vars_):
+                if active[b]:
+                    v.residual_form_switched = True
     return done, failed
 
 

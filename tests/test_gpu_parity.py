@@ -1826,6 +1826,13 @@ def test_stalled_direct_form_continues_on_the_residual_equation():
     # a solve that converges in direct form is untouched
     _, i6 = emg3d.solve(model, sfield, tol=1e-6, return_info=True, **kw)
     assert i6['exit'] == 0 and i6['residual_form'] is False
+    # in a batch the same happens for all its sources at once
+    sf2 = emg3d.get_source_field(grid, (-30., 10., -20., 10., 5.), 0.5)
+    out = emg3d.solve_batch(model, [sfield, sf2], tol=tol, **kw)
+    assert [i['exit'] for _, i in out] == [0, 0], [i['exit_message'] for _, i in out]
+    assert relerr(out[0][0].field, eo.field) < 1e-8
+    outd = emg3d.solve_batch(model, [sfield, sf2], tol=tol, residual_form=False, **kw)
+    assert outd[0][1]['exit_message'] == 'STAGNATED'
 
 
 def test_volume_average_adjoint_is_the_transpose():
