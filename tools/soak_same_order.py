@@ -5,6 +5,7 @@ serial walk): the cycle counts and exit states must be equal and the fields agre
 models that run in residual form). Found in round 3: a model whose direct form stalls above tol 1e-9 unnoticed by the
 'auto' rule -> the cycling now switches to the residual equation by itself.
     SEED_BASE=... SEEDS=... python tools/soak_same_order.py
+SIZES=96,128,160,224 CAP=5000000 CAP_SIDE=128 TOL=1e-7: the large classes (streamed lines, tiled point smoother).
 SSL=bicgstab|cgs|gcrotmk|True: the GPU side solves with that Krylov method (multigrid as preconditioner); then only the
 exit states and the fields (1e-7) are compared. (gcrotmk fails its first preconditioner call on unit-dipole sources, as in the
 reference: the multigrid's divergence rule measures GCROT's unit-norm vectors against the source's norm, emg3d/solver.py:1627.
@@ -24,11 +25,13 @@ t0 = time.time()
 base = int(os.environ.get('SEED_BASE', 83000))
 seeds = [int(x) for x in os.environ['SEEDS'].split(',')] if os.environ.get('SEEDS') else range(int(os.environ.get('NSEEDS', 30)))
 limit = float(os.environ.get('TIME_LIMIT', 1500))
+TOL = float(os.environ.get('TOL', 1e-9))
 for seed in seeds:
     rng = np.random.default_rng(base + seed)
-    shape = tuple(int(rng.choice([24, 32, 40, 48, 64, 80, 96, 112])) for _ in range(3))
-    if np.prod(shape) > 96 * 96 * 64:           # keep the oracle's part of a case under a minute or so
-        shape = tuple(min(n, 64) for n in shape)
+    sizes = [int(x) for x in os.environ.get('SIZES', '24,32,40,48,64,80,96,112').split(',')]
+    shape = tuple(int(rng.choice(sizes)) for _ in range(3))
+    if np.prod(shape) > int(os.environ.get('CAP', 96 * 96 * 64)):           # keep the oracle's part of a case under a minute or so
+        shape = tuple(min(n, int(os.environ.get('CAP_SIDE', 64))) for n in shape)
     h = [widths(n // 2, n // 4, 25., float(rng.choice([1.03, 1.08, 1.15]))) for n in shape]
     grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
     shape = tuple(len(x) for x in h)
@@ -50,11 +53,11 @@ for seed in seeds:
         rf = {'1': True, '0': False}.get(os.environ.get('RESFORM', ''), 'auto')
         ssl = os.environ.get('SSL', '')            # bicgstab / cgs / gcrotmk / True: the GPU side as a Krylov solve
         ssl = {'': False, 'True': True}.get(ssl, ssl)
-        e, info = emg3d.solve(model, sfield, sslsolver=ssl, tol=1e-9, return_info=True, residual_form=rf, **kw)
+        e, info = emg3d.solve(model, sfield, sslsolver=ssl, tol=TOL, return_info=True, residual_form=rf, **kw)
         og = mg_ref.Grid(grid.h, grid.origin)
         inv = lambda p: None if p is None else 1 / p
         vm = mg_ref.volume_model(og, freq, *[inv(p) for p in (props + (None, None))[:3]])
-        eo, io = mg_ref.solve(vm, mg_ref.Field(og, sfield.field.copy()), tol=1e-9, order=1, **kw)
+        eo, io = mg_ref.solve(vm, mg_ref.Field(og, sfield.field.copy()), tol=TOL, order=1, **kw)
         err = relerr(e.field, eo.field)
         same = info["exit"] == io["exit"] and (bool(ssl) or info["it_mg"] == io["it_mg"])
         # (where the direct form's floor lies above the tolerance -- residual form on -- the system is so ill-conditioned
