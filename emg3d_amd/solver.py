@@ -109,7 +109,8 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     a solve whose direct-form cycles stagnate above the tolerance (the cycling then continues on the
     residual equation instead of returning STAGNATED).
 
-    Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``).
+    Returns ``efield`` (if none was provided) and/or ``info_dict`` (if ``return_info``; the reference's
+    keys plus ``smoother_cell_sweeps`` and ``residual_form``: False, True or 'switched').
     """
     extra = {name: kwargs.pop(name, default) for name, default in _SOLVE_EXTRAS.items()}
     if extra['plain']:       # plain multigrid: whatever was left at its default is switched off
