@@ -42,13 +42,24 @@ for seed in seeds:
         rho[:, :, -max(shape[2] // 5, 1):] = 1e6
     case = int(rng.integers(0, 3))
     props = [(rho,), (rho, None, 2.0 * rho), (rho, 1.5 * rho, 2.5 * rho)][case]
-    model = emg3d.Model(grid, *props)
+    extras = {}
+    if os.environ.get('EXTRAS'):              # mu_r / epsilon_r, the less common cycle parameters
+        if rng.integers(0, 2):
+            extras['mu_r'] = np.asfortranarray(rng.uniform(1.0, 3.0, shape))
+        if rng.integers(0, 2):
+            extras['epsilon_r'] = np.asfortranarray(rng.uniform(1.0, 80.0, shape))
+    model = emg3d.Model(grid, *props, **extras)
     freq = float(rng.choice([2.0, 0.5, 0.1, -1.0]))
     sfield = emg3d.get_source_field(grid, (float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50)),
                                            float(rng.uniform(0, 90)), float(rng.uniform(-30, 30))), freq)
     kw = dict(cycle=str(rng.choice(['V', 'W', 'F'])), semicoarsening=[False, True, 1, 23, 312][int(rng.integers(0, 5))],
               linerelaxation=[False, True, 2, 45, 7][int(rng.integers(0, 5))], maxit=40,
               nu_pre=int(rng.integers(1, 4)), nu_post=int(rng.integers(1, 4)))
+    if os.environ.get('EXTRAS'):
+        kw.update(nu_init=int(rng.integers(0, 3)), nu_coarse=int(rng.integers(1, 4)), clevel=int(rng.choice([-1, -1, 1, 2, 3])),
+                  nu_pre=int(rng.integers(0, 3)))
+        if kw['nu_pre'] == 0 and kw['nu_post'] == 0:
+            kw['nu_post'] = 1
     try:
         rf = {'1': True, '0': False}.get(os.environ.get('RESFORM', ''), 'auto')
         ssl = os.environ.get('SSL', '')            # bicgstab / cgs / gcrotmk / True: the GPU side as a Krylov solve
@@ -56,7 +67,7 @@ for seed in seeds:
         e, info = emg3d.solve(model, sfield, sslsolver=ssl, tol=TOL, return_info=True, residual_form=rf, **kw)
         og = mg_ref.Grid(grid.h, grid.origin)
         inv = lambda p: None if p is None else 1 / p
-        vm = mg_ref.volume_model(og, freq, *[inv(p) for p in (props + (None, None))[:3]])
+        vm = mg_ref.volume_model(og, freq, *[inv(p) for p in (props + (None, None))[:3]], mu_r=extras.get('mu_r'), epsilon_r=extras.get('epsilon_r'))
         eo, io = mg_ref.solve(vm, mg_ref.Field(og, sfield.field.copy()), tol=TOL, order=1, **kw)
         err = relerr(e.field, eo.field)
         same = info["exit"] == io["exit"] and (bool(ssl) or info["it_mg"] == io["it_mg"])
