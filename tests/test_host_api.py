@@ -399,3 +399,48 @@ def test_model_drops_a_device_snapshot_when_a_property_is_replaced():
     assert model._device_props == {'property_z': 'Z'}
     model.mapping = model.mapping                      # other attributes do not touch it
     assert model._device_props == {'property_z': 'Z'}
+
+
+@pytest.mark.parametrize('auto', [True, False])
+def test_stall_switch_control_flow_without_a_gpu(auto, monkeypatch):
+    """_cycle.run_cycles: a direct form that stagnates above the tolerance goes on in residual form when the
+    caller left residual_form at 'auto' (and only then); scripted residual norms, no device."""
+    from emg3d_amd import _cycle
+    from emg3d_amd._params import MGParameters
+    script = [1.0, 1e-2, 1e-4, 1e-6, 1.1e-6, 1e-8, 1e-10, 1e-12]
+
+    class Top:
+        batch = 1
+        _b_valid = True
+
+        def __init__(self):
+            self.norms, self.calls = iter(script), []
+
+        def residual(self, store=True, norm=False):
+            self.calls.append(('residual', store, norm))
+            return next(self.norms) if norm else None
+
+        def to_residual_equation(self):
+            self.calls.append('to')
+
+        def from_residual_equation(self):
+            self.calls.append('from')
+
+    monkeypatch.setattr(_cycle, '_one_cycle', lambda top, var, it, loud: top.calls.append('cycle'))
+    var = MGParameters(verb=0, sslsolver=False, semicoarsening=False, linerelaxation=False, shape_cells=(8, 8, 8),
+                       tol=1e-9, maxit=20)
+    var.l2_refe = 1.0
+    var.error_at_cycle[0] = 1.0
+    var.residual_form, var.residual_form_auto = False, auto
+    top = Top()
+    _cycle.run_cycles(top, var)
+    if not auto:
+        assert var.exit_message == 'STAGNATED' and var.it == 4 and 'to' not in top.calls
+        return
+    assert var.exit_message == 'CONVERGED' and var.it == 6 and var.l2 == 1e-10
+    assert var.residual_form is True and var.residual_form_switched is True
+    # four cycles in direct form (norm only), the stored residual at the switch, then two cycles in residual form
+    assert top.calls.count('cycle') == 6 and top.calls.count('to') == top.calls.count('from') == 2
+    first_to = top.calls.index('to')
+    assert top.calls[first_to - 1] == ('residual', True, False) and top.calls[:first_to].count('cycle') == 4
+    assert top._b_valid is False
