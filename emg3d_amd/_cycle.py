@@ -341,13 +341,15 @@ def run_cycles(top, var):
             continue
         l2_stag = ring[(it - 1) % var.maxcycle]
         reason = stop_reason(var, l2_last, l2_stag, it)
-        if (reason is not None and reason[0] == "STAGNATED" and it < var.maxit and not resform and top.batch == 1 and
+        if (reason is not None and reason[0] == "STAGNATED" and it < var.maxit and l2_last < 1e-3 * var.l2_refe and
+                not resform and top.batch == 1 and
                 not var.sslsolver and getattr(var, 'residual_form_auto', False)):
             # The direct form has stalled above the tolerance: the floor of the line smoothers' stored
             # block inverses (or of the point smoother's pivots) on this model lies higher than the 'auto'
             # rule of solver._residual_form predicted. The reference's banded LDL^T would go on converging;
             # so do the cycles from here on, on the residual equation (their round-off scales with the
-            # residual). Stagnation is judged afresh after another round of the direction schedule.
+            # residual). Stagnation is judged afresh after another round of the direction schedule. (An
+            # iteration that stagnates before it has gained three orders is not at a round-off floor.)
             resform = var.residual_form = var.residual_form_switched = True
             top._b_valid = False
             top.residual(store=True, norm=False)

@@ -3,7 +3,7 @@ that every class of level -- streamed lines excepted, tools/soak_stream.py -- ev
 logic are exercised) against the oracle's driver in the SAME smoother ordering (threaded, bit-identical with its
 serial walk): the cycle counts and exit states must be equal and the fields agree to 1e-9 (1e-7 on the ill-conditioned
 models that run in residual form). Found in round 3: a model whose direct form stalls above tol 1e-9 unnoticed by the
-'auto' rule -> the cycling now switches to the residual equation by itself.
+'auto' rule, and solves hovering around that floor -> stall switch, contrast factor, residual form below tol 1e-7.
     SEED_BASE=... SEEDS=... python tools/soak_same_order.py
 SIZES=96,128,160,224 CAP=5000000 CAP_SIDE=128 TOL=1e-7: the large classes (streamed lines, tiled point smoother).
 SSL=bicgstab|cgs|gcrotmk|True: the GPU side solves with that Krylov method (multigrid as preconditioner); then only the
@@ -77,6 +77,9 @@ for seed in seeds:
         print('SEED', seed, shape, 'case', case, 'f', freq, kw, '| exit', info['exit'], io['exit'], 'cycles', info['it_mg'], io['it_mg'], 'krylov it', info.get('it_ssl'),
               'rel.err %.3e %.3e' % (info['rel_error'], io['rel_error']), 'fields %.1e' % err, 'residual form', info['residual_form'], 'ok' if ok else 'DIFFERENT', flush=True)
         bad += 0 if ok else 1
+        if os.environ.get('HIST') and not ok:
+            print('   gpu   ', ' '.join('%.2e' % x for x in info['error_at_cycle']))
+            print('   oracle', ' '.join('%.2e' % x for x in io['error_at_cycle']), flush=True)
     except Exception as exc:
         bad += 1
         print('SEED', seed, shape, kw, 'EXC', repr(exc)[:300], flush=True)
