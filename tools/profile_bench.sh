@@ -14,6 +14,9 @@ B="python $R/bench.py --workload $WL --no-256 --no-survey --no-cpu-baseline"
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- $B > $O/trace.log 2>&1
 python $R/tools/rocpd_summary.py $O/trace/run_results.db > $R/gpurun_out/${TAG}_${WL}_kernel_stats.txt
 python $R/tools/trace_by_grid.py $O/trace/run_results.db k_line_ > $R/gpurun_out/${TAG}_${WL}_line_launches_by_level.txt
+# the bench line of this very run (HIP events under the profiler): its per-launch averages against the table above
+grep '^{"metric"' $O/trace.log | tail -1 > $R/gpurun_out/${TAG}_bench_${WL}_profiled_run.json
+if [ -n "$ONLY_TRACE" ]; then head -12 $R/gpurun_out/${TAG}_${WL}_kernel_stats.txt; rm -rf $O/trace; exit 0; fi
 # (counter collection crashes inside HIP graph replays on this stack: the same kernels, launched eagerly.
 #  Even so rocprofv3 segfaults -- once it hung -- in about every second counter pass over this
 #  134 000-dispatch run, whatever the library options: bounded time, up to three attempts per pass)
