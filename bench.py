@@ -200,14 +200,13 @@ class Bench:
         return stats
 
 
-def line_kernel_name(n0):
-    """The HIP kernel that runs a colour pass of lines of n0 blocks on a large level (what rocprofv3
-    lists): k_line_stream where the records of 16 lines do not fit in LDS even without their fifth slot
-    (csrc/kernels.hip: launch_line_colour), else k_line_colour."""
+def line_kernel_name(lr, shape, batch=1, is_complex=True):
+    """The HIP kernel that runs a colour pass of line direction lr (1/2/3) on a level of `shape` cells
+    (what rocprofv3 lists), as the library's own launcher decides it under the current options
+    (emg3d_line_kernel_name: csrc/kernels.hip, line_plan)."""
     from emg3d_amd import _lib
-    padded = n0 + 6                        # upper bound of the padded record rows (stencil.h: line_padded)
-    too_long = (16 * padded * 4 + 80) * 16 > 160 * 1024
-    return 'k_line_stream' if (_lib.lib().emg3d_get_option(b'line_stream') > 0 and too_long) else 'k_line_colour'
+    nx, ny, nz = (int(n) for n in shape)
+    return _lib.lib().emg3d_line_kernel_name(int(lr), nx, ny, nz, int(bool(is_complex)), int(batch)).decode()
 
 
 def smoothers_256(device, n=256, nu=2, reps=5):
@@ -255,9 +254,9 @@ def smoothers_256(device, n=256, nu=2, reps=5):
     # (the tiles where two sweeps meet drop a repeated node colour only under the mirrored node-colour rule)
     skip_node = skip and lib.emg3d_get_option(b'point_order') == 0
     out = {}
-    lk = line_kernel_name(n)
-    names = {0: 'gauss_seidel (k_gs_point_tile)', 1: f'gauss_seidel_x ({lk}<0>)',
-             2: f'gauss_seidel_y ({lk}<1>)', 3: f'gauss_seidel_z ({lk}<2>)'}
+    lk = {lr: line_kernel_name(lr, shape) for lr in (1, 2, 3)}
+    names = {0: 'gauss_seidel (k_gs_point_tile)', 1: f'gauss_seidel_x ({lk[1]}<0>)',
+             2: f'gauss_seidel_y ({lk[2]}<1>)', 3: f'gauss_seidel_z ({lk[3]}<2>)'}
     for lr in (0, 1, 2, 3):
         lv.smooth(lr, nu)                       # builds factors, warms up
         lv.smooth(lr, nu)
@@ -491,8 +490,8 @@ def run_gpu(args):
         tmin = _lib.lib().emg3d_get_option(b'point_tile_min')
         tiled = tmin > 0 and (nx_ - 1) * (ny_ - 1) * (nz_ - 1) >= tmin and (nx_ + 1) * (ny_ + 1) * (nz_ + 1) < 2 ** 31
         hip_names = {0: 'k_gs_point_tile' if tiled else 'k_gs_point'}
-        for d_, n_ in ((1, nx_), (2, ny_), (3, nz_)):
-            hip_names[d_] = f'{line_kernel_name(n_)}<T, DIR={d_ - 1}, ...>'
+        for d_ in (1, 2, 3):
+            hip_names[d_] = f'{line_kernel_name(d_, (nx_, ny_, nz_))}<T, DIR={d_ - 1}, ...>'
         dom = max(stats, key=lambda k: stats[k]['ms'])
         bytes_per_launch = BYTES_PER_CELL_SWEEP[b.case] * n0 / 4.0
         ms_launch = stats[dom]['ms'] / stats[dom]['launches']

@@ -58,6 +58,8 @@ SIGNATURES = {
     'emg3d_get_option': (_ci, [ctypes.c_char_p]),
     'emg3d_option_count': (_ci, []),
     'emg3d_option_name': (ctypes.c_char_p, [_ci]),
+    'emg3d_options_generation': (_ci, []),
+    'emg3d_line_kernel_name': (ctypes.c_char_p, [_ci] * 6),
     'emg3d_core_amat_x': (_ci, [_vp] * 13 + [_ci] * 4),
     'emg3d_core_gauss_seidel': (_ci, [_ci] + [_vp] * 13 + [_ci] * 5),
     'emg3d_core_restrict': (_ci, [_vp] * 15 + [_ci] * 5),
@@ -128,11 +130,19 @@ def check(status, what=''):
                             f"{msg.decode() if msg else ''}")
 
 
+_fingerprint = (None, None)
+
+
 def options_fingerprint():
     """Current values of all run-time options of the library, in its own order (part of the key of
-    everything that is built under them: captured graphs, option-dependent factor buffers)."""
+    everything that is built under them: captured graphs, option-dependent factor buffers). Read again
+    only when the library's generation counter has moved (one ctypes call otherwise)."""
+    global _fingerprint
     L = lib()
-    return tuple(L.emg3d_get_option(L.emg3d_option_name(i)) for i in range(L.emg3d_option_count()))
+    gen = L.emg3d_options_generation()
+    if _fingerprint[0] != gen:
+        _fingerprint = (gen, tuple(L.emg3d_get_option(L.emg3d_option_name(i)) for i in range(L.emg3d_option_count())))
+    return _fingerprint[1]
 
 
 def require_gpu():

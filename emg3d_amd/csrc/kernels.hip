@@ -97,7 +97,8 @@ int g_line_lpw = 0;
 // the largest levels (records of 16 lines do not fit in LDS even without their fifth slot: lines of
 // ~160 blocks and more): k_line_stream -- right-hand sides produced into an LDS ring by the helper
 // waves while the chain waves substitute (1, default); 0: k_line_colour everywhere; 2: k_line_stream
-// also where slots 0..3 would fit (~128-block lines: measured equal)
+// also where slots 0..3 would fit (~128-block lines: measured equal); 3 / 4: like 1 / 2 with the single
+// source run as a group of one of k_line_stream_b (the w records staged through LDS in the backward pass)
 int g_line_stream = 1;
 // sequence of the colour passes of the LINE smoothers (launch.h: line_sweep_colour): 1 (default) cyclic
 // 1,2,3,0,1,...; 0 mirrored sweeps (0,2,3,1 forward / its reverse backward: rounds 1-2); 2 the classes
@@ -106,6 +107,10 @@ int g_line_stream = 1;
 // definition (converged fields are the same; per-sweep values and cycle counts are not).
 int g_line_order = 1;
 int g_line_stream_r = 0;           // rows per chunk of the ring (0: 16)
+// several right-hand sides (emg3d_level::batch > 1): levels whose colour passes would keep their records in
+// the global scratch and whose lines have at least this many blocks run k_line_stream_b -- groups of up
+// to four right-hand sides per workgroup, the factors fetched once per group (<= 0: never)
+int g_line_stream_bmin = 64;
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
@@ -1123,6 +1128,280 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream(emg::Level<T> 
     else quad_backward<T, DIR, 1, QD, true, false>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, 0);
 }
 
+// ---- the streamed colour pass for SEVERAL right-hand sides that share the factors -------------------
+// Sources of one frequency share the model, hence the line factorisations (emg3d/simulations.py:
+// 1453-1464: one frequency, many sources). With the batch as a grid dimension every source's
+// workgroups stream the 2 x 304 B of factors per block again -- 47 % of the bytes of a level-0 colour
+// pass. Here ONE workgroup serves its 16 lines for a group of B <= 4 right-hand sides: a chain quad
+// holds the factor row of a block in registers once and applies it to the B right-hand sides (B
+// independent dependency chains: their instructions interleave), the producer waves fill B rings. Per
+// source the arithmetic is that of k_line_stream / k_line_colour, entry by entry: bit-identical.
+//   LDS: ring [2 buffers][B][2 halves][R rows][16 lines][5 entries]; R = 16 for B <= 2, 8 for B = 3, 4.
+//   RD : depth of the factor prefetch ring in the chain waves (2 for B >= 2: a step of B sources takes
+//        B times as long, so two steps ahead is as far ahead in time as four were for one source).
+template <class T, int HALF, int RD, int B>
+__device__ __forceinline__ void quad_forward_stream_b(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
+                                                      const T *fac, const double *lfac, T *vec, size_t vstride,
+                                                      const T *ringbase, int lpw, int R, int nchunks)
+{
+    const HalfWalk<HALF> W(n0, n0p);
+    const bool active = qline < qend;
+    const int line = min(qline, qend - 1);
+    const int ll = line - line0;
+    const VecRef<T> V = VecRef<T>::global(vec, nlines);
+    T *const dummy = vec + (vstride - emg::LINE_DUMMY);          // (every source's scratch ends with its dummy slots)
+    T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
+    QuadRow<T> ring[RD];
+    const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T> &q, int i) { q.template load<LaneAddr<T, HALF, false>, false>(LA, W.fwd(W.clampi(i))); };
+#pragma unroll
+    for (int d = 0; d < RD; ++d) fetch(ring[d], d);
+    __syncthreads();                                          // chunk 0 of the rings and the middle rows are there
+    T wsel[B], w4p[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) wsel[b] = w4p[b] = emg::zero<T>();
+    const double nz = j != 0 ? 1.0 : 0.0, is0 = 1.0 - nz;
+    const size_t srcelems = (size_t)2 * R * lpw * 5;          // ring of one source, one buffer
+    const size_t bufelems = (size_t)B * srcelems;
+    for (int c = 0; c < nchunks; ++c) {
+        const T *const items = ringbase + (size_t)(c & 1) * bufelems + ((size_t)(HALF * R) * lpw + ll) * 5;
+        const int iend = min((c + 1) * R, W.steps);
+        for (int i0 = c * R; i0 < iend; i0 += RD) {
+#pragma unroll
+            for (int d = 0; d < RD; ++d) {
+                const int k = W.fwd(i0 + d);
+                const QuadRow<T> &q = ring[d];
+                const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
+                T *const o4 = active ? LA.pv4(k) : dslot + 4;
+                T *const oj = active ? LA.pvj(k) : dslot + j;
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    const T v = it[b * srcelems + j], v4 = it[b * srcelems + 4];
+                    T wn, w4;
+                    quad_forward_step(q, v, v4, nz, is0, wsel[b], w4p[b], wn, w4);
+                    oj[b * vstride] = wn;
+                    o4[b * vstride] = w4;
+                }
+                fetch(ring[d], i0 + d + RD);
+            }
+        }
+        lds_barrier();                                        // this chunk is consumed, the next one produced
+    }
+}
+
+// The producers' job in the BACKWARD pass: copy the w records of the next R steps of both half-chains
+// into the ring, in the chains' grouping (stream_produce's: entry 0 of record row k, entries 1..4 of
+// row k - 1 for a mirrored block) -- sixteen lines x 80 B are contiguous in the scratch, so the idle
+// producer waves fetch them as wide coalesced loads and the chain quads need neither a register ring
+// nor four scattered 16-byte loads per step for them.
+template <class T>
+__device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n0, int n0p, int line0, int nl, int lpw,
+                                                 T *buf, int R, int chunk, int pt, int np)
+{
+    const int mk = emg::line_mid(n0);
+    const int items = 2 * R * lpw;
+    for (int it = pt; it < items; it += np) {
+        const int ll = it % lpw, row = (it / lpw) % R, half = it / (R * lpw);
+        const int steps = half ? n0p - 2 - mk : mk;
+        const int ic = max(min(chunk * R + row, steps - 1), 0);
+        const int k = min(max(half ? mk + 2 + ic : mk - 1 - ic, half), n0p - 1);     // HalfWalk::bwd
+        const int lid = line0 + min(ll, nl - 1);
+        const T *const r0 = vec + ((size_t)k * nlines + lid) * 5;
+        const T *const rt = vec + ((size_t)(half ? k - 1 : k) * nlines + lid) * 5;
+        const T a0 = r0[0], a1 = rt[1], a2 = rt[2], a3 = rt[3], a4 = rt[4];
+        T *o = buf + ((size_t)(half * R + row) * lpw + ll) * 5;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+    }
+}
+
+// backward substitution of one half for B right-hand sides (quad_backward, MIDFIRST form, per source);
+// the w records come from the LDS ring (stream_produce_w)
+template <class T, int DIR, int HALF, int RD, int B>
+__device__ __forceinline__ void quad_backward_b(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p, int qline,
+                                                int qend, int line0, int j, const T *fac, const double *lfac, T *vec,
+                                                size_t vstride, size_t boff0, const T *ringbase, int lpw, int R,
+                                                int nchunks)
+{
+    const emg::Axes<T, DIR> A(L, boff0);
+    const int n0 = A.n0();
+    const HalfWalk<HALF> W(n0, n0p);
+    const int mk = W.mk;
+    const int nlines = cntp * cntq;
+    const bool active = qline < qend;
+    const int line = min(qline, qend - 1);
+    const int ll = line - line0;
+    const size_t bs = L.bstride;
+    int i1, i2, lid;
+    emg::line_of_thread<DIR>(colour, cntp, cntq, line % cntp, line / cntp, i1, i2, lid);
+    const int cj = j == 0 ? 0 : (j <= 2 ? 1 : 2), dk = (j == 0 || HALF) ? 0 : 1, dk4 = HALF ? 0 : 1;
+    const int d1 = j == 1 ? 1 : 0, d2 = j == 3 ? 1 : 0;
+    T *const ej = A.E(cj) + A.idx(cj, dk, i1 - d1, i2 - d2);
+    const long sj = (long)A.idx(cj, dk + 1, i1 - d1, i2 - d2) - (long)A.idx(cj, dk, i1 - d1, i2 - d2);
+    T *const e4 = A.E(2) + A.idx(2, dk4, i1, i2);
+    const long s4 = (long)A.idx(2, dk4 + 1, i1, i2) - (long)A.idx(2, dk4, i1, i2);
+    // dummy store targets: the dummy slots of the group's first scratch (global memory, like the field)
+    T *const dslot = vec + (vstride - emg::LINE_DUMMY) + ((threadIdx.x & 63) >> 2) * 5;
+    T *const dj = dslot + j, *const d4 = dslot + 4;
+    const size_t fstep = active ? bs : 0;                     // per-source step of the field pointers
+
+    const VecRef<T> V = VecRef<T>::global(vec, nlines);
+    QuadRow<T> ring[RD];
+    const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T> &q, int i) {
+        q.template load<LaneAddr<T, HALF, false>, false>(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));
+    };
+    // coupling to the middle: B_m (top) / U_{m+1} (bottom)
+    QuadRow<T> qm;
+    qm.load_b(lfac, (size_t)(HALF ? mk + 1 : mk) * nlines + line, j);
+    T x0[B], x4[B], xmine[B];
+    const double own0 = j == 0 ? 1.0 : 0.0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const VecRef<T> Vb = VecRef<T>::global(vec + b * vstride, nlines);
+        T xa, xb;
+        quad_middle<T>(n0, n0p, nlines, line, j, fac, lfac, Vb, xa, xb);
+        const T xq0 = quad_bcast<0>(xa), xq4 = quad_bcast<0>(xb), xq5 = quad_bcast<1>(xb);
+        if (HALF == 0) {
+            const int dkm = j == 0 ? 0 : 1;
+            T *const pm = A.E(cj) + A.idx(cj, mk + dkm, i1 - d1, i2 - d2) + b * bs;
+            *(active ? pm : dj) = xa;
+            T *const p4 = A.E(2) + A.idx(2, mk + 1, i1, i2) + b * bs;
+            T *const p5 = A.E(0) + A.idx(0, mk + 1, i1, i2) + b * bs;
+            *((active && j == 0) ? p4 : ((active && j == 1) ? p5 : d4)) = xb;
+        }
+        x0[b] = HALF ? xq5 : xq0;
+        x4[b] = xq4;
+        xmine[b] = HALF ? own0 * xq5 + (1.0 - own0) * xa : xa;
+    }
+    asm volatile("" ::: "memory");           // keep the ring fetch behind the middle blocks
+#pragma unroll
+    for (int d = 0; d < RD; ++d) fetch(ring[d], d);
+    __syncthreads();                                          // chunk 0 of the w ring is there
+    double upA = qm.bA, upD = qm.bD, up04 = qm.b04, up44 = qm.d4;          // entries of the coupling block
+    T *pej = active ? ej + (long)W.bwd(0) * sj : dj;
+    T *pe4 = active ? e4 + (long)W.bwd(0) * s4 : d4;
+    const long incj = active ? (HALF ? sj : -sj) : 0, inc4 = active ? (HALF ? s4 : -s4) : 0;
+    const double nz = j != 0 ? 1.0 : 0.0;
+    const size_t srcelems = (size_t)2 * R * lpw * 5, bufelems = (size_t)B * srcelems;
+    for (int c = 0; c < nchunks; ++c) {
+        const T *const items = ringbase + (size_t)(c & 1) * bufelems + ((size_t)(HALF * R) * lpw + ll) * 5;
+        const int iend = min((c + 1) * R, W.steps);
+        for (int i0 = c * R; i0 < iend; i0 += RD) {
+#pragma unroll
+            for (int d = 0; d < RD; ++d) {
+                const int k = W.bwd(i0 + d);
+                const QuadRow<T> &q = ring[d];
+                const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
+                const bool real_block = HALF ? k <= n0 - 1 : true;      // uniform over the wave
+                T *const oj = real_block ? pej : dj;
+                T *const o4 = real_block ? pe4 : d4;
+                const size_t ostep = real_block ? fstep : 0;
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    const T wj = it[b * srcelems + j], w4 = it[b * srcelems + 4];
+                    // h = B^T x_prev: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
+                    const T hj = (upA * nz) * x0[b] + (upD * nz) * xmine[b];
+                    const T h4 = up04 * x0[b] + up44 * x4[b];
+                    const T h1 = quad_rot<1>(hj), h2 = quad_rot<2>(hj), h3 = quad_rot<3>(hj);
+                    const T xn = emg::nmad(q.t[4], h4, emg::nmad(q.t[1], h1, emg::nmad(q.t[0], hj, wj))) -
+                                 emg::mad(q.t[3], h3, q.t[2] * h2);
+                    const T xn4 = emg::nmad(q.t44, h4, w4) - quad_sum(q.t[4] * hj);
+                    x0[b] = quad_bcast<0>(xn);
+                    x4[b] = xn4;
+                    xmine[b] = xn;
+                    oj[b * ostep] = xn;
+                    o4[b * ostep] = xn4;
+                }
+                upA = q.bA; upD = q.bD; up04 = q.b04; up44 = q.d4;
+                pej += incj;
+                pe4 += inc4;
+                fetch(ring[d], i0 + d + RD);
+            }
+        }
+        lds_barrier();                                        // this chunk is consumed, the next one copied
+    }
+}
+
+template <class T, int DIR, int B, int RD>
+__global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                                    int lpw, int R, const T *fac, const double *lfac,
+                                                                    T *vec, size_t vstride, size_t boff0)
+{
+    // vec: the scratch of the group's first right-hand side (source b's: b * vstride behind it);
+    // boff0: element offset of the group's first source in the field / source buffers
+    extern __shared__ double2 lsb_smem[];
+    const int nlines = cntp * cntq;
+    const int line0 = blockIdx.x * lpw;
+    const int nl = min(lpw, nlines - line0);
+    T *const ringbase = reinterpret_cast<T *>(lsb_smem);
+    const size_t srcelems = (size_t)2 * R * lpw * 5, bufelems = (size_t)B * srcelems;
+    const int n0 = DIR == 0 ? L.nx : DIR == 1 ? L.ny : L.nz;
+    const int mk = emg::line_mid(n0);
+    const int smax = max(mk, n0p - 2 - mk);
+    const int nchunks = (smax + R - 1) / R;
+    const int wave = threadIdx.x >> 6;
+    if (wave >= 2) {
+        // ---- producers: right-hand sides for the forward pass, w records for the backward pass
+        const int pt = threadIdx.x - 128;
+#pragma unroll 1
+        for (int b = 0; b < B; ++b) {
+            const emg::Axes<T, DIR> A(L, boff0 + b * L.bstride);
+            const VecRef<T> V = VecRef<T>::global(vec + b * vstride, nlines);
+            for (int ll = pt; ll < nl; ll += LS_PROD) {
+                const int lid = line0 + ll;
+                int i1, i2, l2;
+                emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+                T rhs[5];
+                emg::line_rhs<T, DIR>(A, mk, i1, i2, rhs);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *V.p(mk, lid, r) = rhs[r];
+                *V.p4(mk, lid) = rhs[4];
+                *V.p(mk + 1, lid, 0) = emg::line_rhs_e0<T, DIR>(A, min(mk + 1, n0 - 1), i1, i2);
+            }
+            stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, LS_PROD);
+        }
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) {
+#pragma unroll 1
+                for (int b = 0; b < B; ++b) {
+                    const emg::Axes<T, DIR> A(L, boff0 + b * L.bstride);
+                    stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw,
+                                           ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, LS_PROD);
+                }
+            }
+            lds_barrier();
+        }
+        __syncthreads();                                      // the forward chains are done: all w records are written
+#pragma unroll 1
+        for (int b = 0; b < B; ++b)
+            stream_produce_w<T>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, LS_PROD);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) {
+#pragma unroll 1
+                for (int b = 0; b < B; ++b)
+                    stream_produce_w<T>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
+                                        ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, LS_PROD);
+            }
+            lds_barrier();
+        }
+        return;
+    }
+    const int half = wave & 1;
+    const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
+    const int qend = line0 + nl;
+#ifndef LSB_NO_FWD
+    if (half == 0) quad_forward_stream_b<T, 0, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
+    else quad_forward_stream_b<T, 1, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
+#endif
+    __syncthreads();
+#ifndef LSB_NO_BWD
+    if (half == 0) quad_backward_b<T, DIR, 0, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
+    else quad_backward_b<T, DIR, 1, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
+#endif
+}
+
 // Residual + per-block partial sums of |r|^2. A workgroup walks `zb` consecutive planes: the plane
 // above the current one, fetched for the curl, is the next iteration's own plane and is still in
 // the CU's cache then -- with one plane per workgroup the three workgroups that need a plane run on
@@ -1235,6 +1514,116 @@ __global__ void k_blocks_to_amat(T *amat, T *bvec, const T *middle, const double
 
 // --------------------------------------------------------------------------- launchers --
 
+// How one colour pass of a line direction is launched (decided by line_plan, executed by
+// launch_line_colour; exported through emg3d_line_kernel_name so that callers -- bench.py, the tests --
+// name the kernel that runs instead of re-deriving the rule).
+enum LineKind { LK_SEPARATE = 0, LK_COLOUR = 1, LK_STREAM = 2, LK_STREAM_B = 3 };
+struct LinePlan {
+    int kind;        // LineKind
+    int vmode;       // LK_COLOUR: where the records live (k_line_colour's VMODE 0..3)
+    int lpw;         // lines per workgroup
+    int R;           // LK_STREAM / LK_STREAM_B: rows per chunk of the right-hand-side ring
+    size_t smem;     // dynamic LDS of the launch
+    bool shortl;     // the records were laid out with the short granule (lines of <= LINE_SHORT blocks)
+    bool batchk;     // LK_COLOUR: the instantiation with the batch as a grid dimension
+};
+// largest group of right-hand sides one k_line_stream_b workgroup serves (its chain quads hold a factor
+// row once and apply it to all of them)
+constexpr int LSB_MAX = 4;
+// rows per chunk of the ring of a group of g right-hand sides: 2 buffers x g x 2 halves x R x 16 lines x
+// 5 entries must fit the 160 KB of a CU
+inline int stream_rows(int g, size_t elem)
+{
+    int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
+    while (R > 4 && (size_t)2 * g * 2 * R * 16 * 5 * elem > (size_t)160 * 1024) R -= 4;
+    return R;
+}
+template <class T> LinePlan line_plan(const emg::LineClass &lc, int batch)
+{
+    LinePlan P{LK_SEPARATE, 0, 16, 0, 0, emg::line_pad(lc.n0) == emg::LINE_PAD_SHORT, false};
+    if (!(g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max))) return P;
+    P.kind = LK_COLOUR;
+    // lines per workgroup: as few as keeps the workgroup count within one per CU
+    int lpw = 16;
+    if (g_line_lpw > 0) lpw = g_line_lpw;
+    else if (cdiv(lc.lines, 4) * batch <= 256) lpw = 4;      // all right-hand sides count
+    else if (cdiv(lc.lines, 8) * batch <= 256) lpw = 8;
+    // records in LDS if they fit (+ the dummy slots) and every workgroup gets a CU;
+    // line_lds = 2: whenever they fit, with fewer lines per workgroup if the lines are too
+    // long for 16 (experiment)
+    const size_t lds_cu = 160 * 1024;
+    auto rec_bytes = [&](int l, int w) { return ((size_t)l * lc.n0p * w + emg::LINE_DUMMY) * sizeof(T); };
+    if (g_line_lds == 2 && g_line_lpw == 0) {
+        while (lpw > 4 && rec_bytes(lpw, 4) > lds_cu) lpw /= 2;
+    }
+    P.lpw = lpw;
+    const unsigned nwg = cdiv(lc.lines, lpw);
+    // (the QD = 4 kernels hold more than 256 registers: one workgroup per CU whatever its LDS use,
+    // so their records go to LDS whenever they fit; the short-line kernels share a CU and keep
+    // their records in LDS only while every workgroup of the launch gets a CU at once)
+    const bool one_per_cu = !P.shortl && batch == 1;
+    auto fits = [&](size_t smem) {
+        return g_line_lds && smem <= lds_cu &&
+               (g_line_lds >= 2 || one_per_cu || (size_t)nwg <= 256 * (lds_cu / smem));
+    };
+    const size_t smem1 = rec_bytes(lpw, 5);
+    const size_t smem2 = rec_bytes(lpw, 4);
+    P.batchk = batch > 1 || g_line_occ2;
+    const bool streamable = g_line_stream && !P.shortl && !g_line_occ2 && !(g_line_debug & 1) && lpw <= 16 && !fits(smem1) &&
+                            (!fits(smem2) || g_line_stream == 2 || g_line_stream == 4);
+    // the largest levels of a single-source solve: right-hand sides streamed through LDS
+    // (where slots 0..3 of the records fit in LDS -- 128-block lines -- k_line_colour's mode 2 is as fast:
+    // 11.34 against 11.40 ms per config-2 cycle, 1.80-1.91 against 1.82-1.88 ms per call at 256 x 128 x 128).
+    // (k_line_stream has two chain waves = 16 lines per workgroup at most: with line_lpw = 32 the launch
+    // stays with k_line_colour, whose waves 2 / 3 walk lines 16..31; the ring must fit the LDS of a CU)
+    if (streamable && batch == 1 && lc.n0 >= 16 && g_line_stream >= 3 && lpw == 16) {
+        P.kind = LK_STREAM_B;      // (line_stream = 3 / 4: the single source as a group of one -- w records staged too)
+        return P;
+    }
+    if (streamable && batch == 1 && lc.n0 >= 16) {
+        const int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
+        const size_t smem = (size_t)2 * 2 * R * lpw * 5 * sizeof(T);
+        if (smem <= lds_cu) { P.kind = LK_STREAM; P.R = R; P.smem = smem; return P; }
+    }
+    // several right-hand sides on such a level: groups of up to LSB_MAX of them per workgroup, the
+    // factors fetched once per group (k_line_stream_b)
+    // (also where slots 0..3 of the records of ONE source would fit in LDS: with the batch as a grid dimension
+    // those launches fetch the factors once per source)
+    const bool streamable_b = g_line_stream && !P.shortl && !g_line_occ2 && !(g_line_debug & 1) && lpw == 16 && !fits(smem1);
+    if (streamable_b && batch > 1 && g_line_stream_bmin > 0 && lc.n0 >= g_line_stream_bmin) {
+        P.kind = LK_STREAM_B;
+        return P;
+    }
+    if (P.shortl) {              // (records of <= 6 blocks: a few KB, they fit whenever LDS records are on)
+        if (fits(smem1)) { P.vmode = 1; P.smem = smem1; }
+    } else if (fits(smem1)) { P.vmode = 1; P.smem = smem1; }
+    else if (fits(smem2)) { P.vmode = 2; P.smem = smem2; }
+    else if (g_line_lds >= 3 && batch == 1 && !g_line_occ2 && lpw == 16) {
+        // line_lds = 3 (experiment): lines too long for mode 2 keep the record rows around the
+        // middle block in LDS, the outer rows in the global scratch (mode 3)
+        const emg::LineSplit sp = emg::line_split_rows(lc.n0, lc.n0p, lpw, sizeof(T));
+        if (sp.lds_bytes > 0) { P.vmode = 3; P.smem = sp.lds_bytes; P.batchk = false; }
+    }
+    return P;
+}
+
+template <class T, int DIR, int B>
+void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const T *f, const double *lf, T *vec,
+                         size_t vstride, int b0, hipStream_t st)
+{
+    const int lpw = 16;
+    int R = stream_rows(B, sizeof(T));
+    const size_t smem = (size_t)2 * B * 2 * R * lpw * 5 * sizeof(T);
+    const void *kern = (const void *)&k_line_stream_b<T, DIR, B, (B >= 2 ? 2 : emg::LINE_PAD)>;
+    (void)allow_lds(kern, 160 * 1024);
+    T *v0 = vec + (size_t)b0 * vstride;
+    size_t boff0 = (size_t)b0 * L.bstride;
+    const unsigned nwg = cdiv(lc.lines, lpw);
+    void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
+                    (void *)&f, (void *)&lf, (void *)&v0, (void *)&vstride, (void *)&boff0};
+    (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + LS_PROD), args, smem, st);
+}
+
 template <class T, int DIR>
 void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac, T *vec, hipStream_t st)
 {
@@ -1249,83 +1638,60 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
     const size_t vstride = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz);    // scratch of one right-hand side
     const size_t dummy_off = vstride - emg::LINE_DUMMY;
-    if (g_line_fuse == 1 || (g_line_fuse == 2 && lc.lines <= g_line_fuse_max)) {
-        // lines per workgroup: as few as keeps the workgroup count within one per CU
-        int lpw = 16;
-        if (g_line_lpw > 0) lpw = g_line_lpw;
-        else if (cdiv(lc.lines, 4) * L.batch <= 256) lpw = 4;      // all right-hand sides count
-        else if (cdiv(lc.lines, 8) * L.batch <= 256) lpw = 8;
-        // records in LDS if they fit (+ the dummy slots) and every workgroup gets a CU;
-        // line_lds = 2: whenever they fit, with fewer lines per workgroup if the lines are too
-        // long for 16 (experiment)
-        const size_t lds_cu = 160 * 1024;
-        auto rec_bytes = [&](int l, int w) { return ((size_t)l * lc.n0p * w + emg::LINE_DUMMY) * sizeof(T); };
-        if (g_line_lds == 2 && g_line_lpw == 0) {
-            while (lpw > 4 && rec_bytes(lpw, 4) > lds_cu) lpw /= 2;
+    const LinePlan P = line_plan<T>(lc, L.batch);
+    if (P.kind == LK_STREAM) {
+        const int lpw = P.lpw, R = P.R;
+        const void *kern = (const void *)&k_line_stream<T, DIR, emg::LINE_PAD>;
+        (void)allow_lds(kern, 160 * 1024);
+        T *dummyp = vec + dummy_off;
+        void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
+                        (void *)&f, (void *)&lf, (void *)&vec, (void *)&dummyp};
+        (void)hipLaunchKernel(kern, dim3(cdiv(lc.lines, lpw)), dim3(128 + LS_PROD), args, P.smem, st);
+        return;
+    }
+    if (P.kind == LK_STREAM_B) {
+        // groups of at most LSB_MAX right-hand sides, as even as possible (8 -> 4 + 4, 6 -> 3 + 3, 5 -> 3 + 2)
+        const int ng = cdiv(L.batch, LSB_MAX);
+        int b0 = 0;
+        for (int g = 0; g < ng; ++g) {
+            const int gs = L.batch / ng + (g < L.batch % ng ? 1 : 0);
+            if (gs == 4) launch_stream_group<T, DIR, 4>(L, c, lc, f, lf, vec, vstride, b0, st);
+            else if (gs == 3) launch_stream_group<T, DIR, 3>(L, c, lc, f, lf, vec, vstride, b0, st);
+            else if (gs == 2) launch_stream_group<T, DIR, 2>(L, c, lc, f, lf, vec, vstride, b0, st);
+            else launch_stream_group<T, DIR, 1>(L, c, lc, f, lf, vec, vstride, b0, st);
+            b0 += gs;
         }
+        return;
+    }
+    if (P.kind == LK_COLOUR) {
+        const int lpw = P.lpw;
         const unsigned nwg = cdiv(lc.lines, lpw);
-        // (the QD = 4 kernels hold more than 256 registers: one workgroup per CU whatever its LDS use,
-        // so their records go to LDS whenever they fit; the short-line kernels share a CU and keep
-        // their records in LDS only while every workgroup of the launch gets a CU at once)
-        const bool one_per_cu = emg::line_pad(lc.n0) == emg::LINE_PAD && L.batch == 1;
-        auto fits = [&](size_t smem) {
-            return g_line_lds && smem <= lds_cu &&
-                   (g_line_lds >= 2 || one_per_cu || (size_t)nwg <= 256 * (lds_cu / smem));
-        };
-        const size_t smem1 = rec_bytes(lpw, 5);
-        const size_t smem2 = rec_bytes(lpw, 4);
+        const size_t lds_cu = 160 * 1024;
         constexpr int P4 = emg::LINE_PAD, P2 = emg::LINE_PAD_SHORT;
-        const bool shortl = emg::line_pad(lc.n0) == P2;       // the granule the line's records were laid out with
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, false, P4>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, false, P4>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 1, true, P4>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 2, true, P4>), lds_cu);
         (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, 3, false, P4>), lds_cu);
-#define LC_LAUNCH(VM, SMEM, QDV)                                                                                         \
+#define LC_LAUNCH(VM, QDV)                                                                                               \
     do {                                                                                                                 \
         if (L.batch > 1 || (g_line_occ2 && VM == 0))                                                                     \
-            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, true, QDV>), dim3(nwg, L.batch), dim3(LC_THREADS), SMEM, st, L, \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, true, QDV>), dim3(nwg, L.batch), dim3(LC_THREADS), P.smem, st, L, \
                                c, lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);                  \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, false, QDV>), dim3(nwg), dim3(LC_THREADS), SMEM, st, L, c,      \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, false, QDV>), dim3(nwg), dim3(LC_THREADS), P.smem, st, L, c,    \
                                lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off,                               \
                                (VM == 0 && (g_line_debug & 1)) ? ~(size_t)0 : vstride);                                  \
     } while (0)
-        // the largest levels of a single-source solve: right-hand sides streamed through LDS
-        // (where slots 0..3 of the records fit in LDS -- 128-block lines -- k_line_colour's mode 2 is as fast:
-        // 11.34 against 11.40 ms per config-2 cycle, 1.80-1.91 against 1.82-1.88 ms per call at 256 x 128 x 128)
-        if (g_line_stream && !shortl && L.batch == 1 && !g_line_occ2 && !(g_line_debug & 1) && lc.n0 >= 16 && !fits(smem1) &&
-            (!fits(smem2) || g_line_stream >= 2)) {
-            const int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
-            const size_t smem = (size_t)2 * 2 * R * lpw * 5 * sizeof(T);
-            const void *kern = (const void *)&k_line_stream<T, DIR, P4>;
-            (void)allow_lds(kern, lds_cu);
-            T *dummyp = vec + dummy_off;
-            void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
-                            (void *)&f, (void *)&lf, (void *)&vec, (void *)&dummyp};
-            (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + LS_PROD), args, smem, st);
-            return;
-        }
-        if (shortl) {              // (records of <= 6 blocks: a few KB, they fit whenever LDS records are on)
-            if (fits(smem1))
-                LC_LAUNCH(1, smem1, P2);
-            else
-                LC_LAUNCH(0, 0, P2);
-        } else if (fits(smem1))
-            LC_LAUNCH(1, smem1, P4);
-        else if (fits(smem2))
-            LC_LAUNCH(2, smem2, P4);
-        else if (g_line_lds >= 3 && L.batch == 1 && !g_line_occ2 && lpw == 16) {
-            // line_lds = 3 (experiment): lines too long for mode 2 keep the record rows around the
-            // middle block in LDS, the outer rows in the global scratch (mode 3)
-            const emg::LineSplit sp = emg::line_split_rows(lc.n0, lc.n0p, lpw, sizeof(T));
-            if (sp.lds_bytes > 0)
-                hipLaunchKernelGGL((k_line_colour<T, DIR, 3, false, P4>), dim3(nwg), dim3(LC_THREADS), sp.lds_bytes, st, L, c,
-                                   lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);
-            else
-                LC_LAUNCH(0, 0, P4);
-        } else
-            LC_LAUNCH(0, 0, P4);
+        if (P.shortl) {
+            if (P.vmode == 1) LC_LAUNCH(1, P2);
+            else LC_LAUNCH(0, P2);
+        } else if (P.vmode == 1) LC_LAUNCH(1, P4);
+        else if (P.vmode == 2) LC_LAUNCH(2, P4);
+        else if (P.vmode == 3)
+            hipLaunchKernelGGL((k_line_colour<T, DIR, 3, false, P4>), dim3(nwg), dim3(LC_THREADS), P.smem, st, L, c,
+                               lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);
+        else LC_LAUNCH(0, P4);
 #undef LC_LAUNCH
         return;
     }
@@ -1638,8 +2004,10 @@ static const OptionEntry g_options[] = {
     {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
+    {"line_stream_bmin", &g_line_stream_bmin},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
+static int g_options_generation = 0;      // bumped whenever an option changes its value
 
 int emg3d_option_count(void) { return N_OPTIONS; }
 const char *emg3d_option_name(int i) { return (i >= 0 && i < N_OPTIONS) ? g_options[i].name : nullptr; }
@@ -1653,11 +2021,36 @@ int emg3d_set_option(const char *name, int value)
     // line_debug produces WRONG fields by design (timing experiments): only with the environment's consent
     if (!std::strcmp(name, "line_debug") && value != 0 && !std::getenv("EMG3D_AMD_ALLOW_DEBUG"))
         return fail(EMG3D_ERR_BADARG, "line_debug: wrong results by design; set EMG3D_AMD_ALLOW_DEBUG=1 to use it");
+    // rows per chunk of k_line_stream's ring: whole register rings of LINE_PAD blocks (a chunk that ends inside a
+    // ring pass would be read past its end), and two chunks x two halves x 16 lines must fit the LDS of a CU
+    if (!std::strcmp(name, "line_stream_r") && value != 0 && (value < 4 || value > 32 || value % emg::LINE_PAD != 0))
+        return fail(EMG3D_ERR_BADARG, "line_stream_r: 0 (= 16) or a multiple of 4 in 4..32");
     if (!std::strcmp(name, "line_order") && (value < 0 || value > 2)) return fail(EMG3D_ERR_BADARG, "line_order: 0, 1 or 2");
     if (!std::strcmp(name, "point_order") && (value < 0 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_order: 0 or 1");
     for (const OptionEntry &o : g_options)
-        if (!std::strcmp(name, o.name)) { *o.value = value; return 0; }
+        if (!std::strcmp(name, o.name)) {
+            if (*o.value != value) ++g_options_generation;
+            *o.value = value;
+            return 0;
+        }
     return fail(EMG3D_ERR_BADARG, "set_option: unknown option");
+}
+
+int emg3d_options_generation(void) { return g_options_generation; }
+
+const char *emg3d_line_kernel_name(int lr, int nx, int ny, int nz, int is_complex, int batch)
+{
+    if (lr < 1 || lr > 3 || nx < 2 || ny < 2 || nz < 2) return "";
+    // the largest colour class (odd, odd) decides, as it does for the scratch size
+    const emg::LineClass lc = emg::line_class(lr - 1, nx, ny, nz, 3);
+    if (lc.lines <= 0) return "";
+    const LinePlan P = is_complex ? line_plan<cplx>(lc, batch > 1 ? batch : 1) : line_plan<double>(lc, batch > 1 ? batch : 1);
+    switch (P.kind) {
+    case LK_STREAM: return "k_line_stream";
+    case LK_STREAM_B: return "k_line_stream_b";
+    case LK_COLOUR: return "k_line_colour";
+    default: return "k_line_rhs+k_line_forward+k_line_backward";
+    }
 }
 
 int emg3d_get_option(const char *name)

@@ -105,7 +105,8 @@ int emg3d_device_count(void);
  * DOES select the sweep order of the point smoother (see above; <= 0 never tiled). "line_lds":
  * 1 (default) keeps the right-hand-side / solution records of a fused line launch in LDS
  * when they fit, 0 always uses the global scratch. "line_lpw": lines per workgroup of a fused
- * line launch (4, 8, 16; 0 = automatic). "line_fuse":
+ * line launch (4, 8, 16, 32; 0 = automatic; with 32 the streamed kernels, whose two chain waves serve
+ * 16 lines, are not used). "line_fuse":
  * 0 three launches per colour and line direction (rhs, forward, backward), 1 one fused
  * launch, 2 (default) fused for colour classes with at most "line_fuse_max" lines (default:
  * no limit -- the fused launch is the faster one at every size measured). "skip_repeat": 1
@@ -117,7 +118,11 @@ int emg3d_device_count(void);
  * ~128 blocks with 16 lines per workgroup) with the right-hand sides produced into an LDS ring
  * while the forward substitution consumes them (k_line_stream: no round trip of the right-hand
  * sides through the scratch, bit-identical results); 0 the three-phase kernel everywhere; 2 also
- * where part of the records fit in LDS. "line_stream_r": rows per half of that ring (0 = 16).
+ * where part of the records fit in LDS. "line_stream_r": rows per half of that ring (0 = 16; a
+ * multiple of 4 in 4..32, anything else is refused). "line_stream_bmin": with several right-hand sides
+ * (emg3d_level::batch > 1) such passes on lines of at least this many blocks (default 64; <= 0: never)
+ * serve groups of up to four right-hand sides per workgroup, every factor row fetched once per group
+ * (k_line_stream_b; per source the same arithmetic: bit-identical to separate solves).
  * "line_order" and "point_order" DO select the order of the sweeps (see above), like
  * "point_tile_min".
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
@@ -129,6 +134,14 @@ int emg3d_get_option(const char *name);
  * dependent buffers -- on the whole option set): names 0 .. emg3d_option_count()-1 */
 int emg3d_option_count(void);
 const char *emg3d_option_name(int i);
+/* a counter that advances whenever emg3d_set_option changes a value: a cheap key for such caches */
+int emg3d_options_generation(void);
+/* The kernel that runs a colour pass of line direction lr (1/2/3) on a level of (nx,ny,nz) cells with
+ * `batch` right-hand sides under the current options -- "k_line_stream" (right-hand sides through an LDS
+ * ring), "k_line_stream_b" (the same for groups of right-hand sides that share each factor fetch),
+ * "k_line_colour" (three phases in one launch) or the three separate kernels --, decided on the level's
+ * largest colour class by the very rule the launcher uses. For profiles and benchmarks; "" on bad input. */
+const char *emg3d_line_kernel_name(int lr, int nx, int ny, int nz, int is_complex, int batch);
 
 /* ---------------------------------------------------------------- host flavour ---- */
 

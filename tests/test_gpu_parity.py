@@ -624,6 +624,125 @@ def test_streamed_line_kernel_is_bit_identical(shape, lr, dtype):
     assert np.array_equal(out[2], out[0])
 
 
+def _random_level_fields(shape, dtype, seed, freq=0.7, extras=False):
+    """Stretched random tri-axial model on `shape` (oracle volume model) with random source / start fields
+    (PEC faces of the start field zero); extras: with epsilon_r and mu_r (eta gets a real part)."""
+    rng = np.random.default_rng(seed)
+    h = [rng.uniform(5., 15., n) * 1.02 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    kw = dict(mu_r=rng.uniform(0.8, 2.0, shape), epsilon_r=rng.uniform(1., 80., shape)) if extras else {}
+    vm = mg_ref.volume_model(grid, freq if dtype is complex else -abs(freq), *sig, **kw)
+    fields = []
+    for _ in range(2):
+        f = mg_ref.Field(grid, dtype=dtype)
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+        fields.append(f)
+    e0 = fields[1]
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    return grid, vm, fields[0], e0
+
+
+@pytest.mark.parametrize('shape,lr', [((130, 72, 72), 1), ((72, 130, 72), 2), ((72, 72, 258), 3)])
+@pytest.mark.parametrize('batch,dtype', [(2, complex), (3, complex), (4, complex), (5, complex), (4, float), (8, complex)])
+def test_batched_streamed_line_kernel_equals_single_source(shape, lr, batch, dtype):
+    """k_line_stream_b -- one workgroup serves its 16 lines for a group of up to four right-hand sides, every
+    factor row fetched once per group, w records staged through LDS in the backward pass -- against the
+    single-source kernels on the same level: source by source the fields after nu = 3 sweeps must agree BIT
+    FOR BIT (batches of 5 and 8 run as groups of 3 + 2 and 4 + 4). Lines of 130 and 258 blocks (R = 16 / 8
+    rows per chunk, several chunks, a ragged last one), > 1000 lines per colour class (16 per workgroup)."""
+    lib = _lib.lib()
+    if batch >= 5 and lr != 2:
+        pytest.skip('group splitting is direction-independent: one direction is enough')
+    assert lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), batch) == b'k_line_stream_b'
+    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + lr + batch)
+    dev = torch.device('cuda')
+    rng = np.random.default_rng(batch)
+    n = e0.field.size
+    srcs = [s0.field * (1 + b) + (0.3 * b) * rng.standard_normal(n) for b in range(batch)]
+    starts = [e0.field * (1.0 - 0.2 * b) for b in range(batch)]
+    single = DeviceLevel.from_host(vm, dev)
+    want = []
+    for b in range(batch):
+        single.s.copy_(torch.from_numpy(srcs[b]))
+        single.e.copy_(torch.from_numpy(starts[b]))
+        single.smooth(lr, 3)
+        want.append(single.e.cpu().numpy())
+    many = DeviceLevel.from_host(vm, dev, batch=batch)
+    many._factors = single._factors              # the same factor buffers (they depend on the model only)
+    many.s.copy_(torch.from_numpy(np.concatenate(srcs)))
+    many.e.copy_(torch.from_numpy(np.concatenate(starts)))
+    many.smooth(lr, 3)
+    got = many.e.cpu().numpy().reshape(batch, n)
+    for b in range(batch):
+        assert np.any(want[b] != starts[b])
+        assert np.array_equal(got[b], want[b]), (b, relerr(got[b], want[b]))
+    # and the single source as a group of one (option line_stream = 3): the staged-w backward pass alone
+    old = lib.emg3d_get_option(b'line_stream')
+    try:
+        lib.emg3d_set_option(b'line_stream', 3)
+        if lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), 1) == b'k_line_stream_b':
+            single.s.copy_(torch.from_numpy(srcs[0]))
+            single.e.copy_(torch.from_numpy(starts[0]))
+            single.smooth(lr, 3)
+            assert np.array_equal(single.e.cpu().numpy(), want[0])
+    finally:
+        lib.emg3d_set_option(b'line_stream', old)
+
+
+def test_solve_batch_long_lines_equals_separate_solves():
+    """solve_batch on a grid whose finest level runs k_line_stream_b (lines of 256 blocks along x, 72 x 72
+    lines): fields, cycle counts and error histories of four sources bit-identical to separate solves."""
+    lib = _lib.lib()
+    shape = (256, 72, 72)
+    h = [widths(n // 2, n // 4, 30., 1.04) for n in shape]
+    grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
+    assert grid.shape_cells == shape
+    assert lib.emg3d_line_kernel_name(1, *shape, 1, 4) == b'k_line_stream_b'
+    rng = np.random.default_rng(8)
+    rho = 10 ** rng.uniform(-0.5, 0.7, shape)
+    model = emg3d.Model(grid, rho, 1.5 * rho, 2.0 * rho)
+    sfields = [emg3d.get_source_field(grid, (x, y, 5., az, 0.), 1.0)
+               for x, y, az in ((-300., 20., 0.), (100., -60., 45.), (0., 0., 90.), (250., 120., 20.))]
+    kw = dict(cycle='F', semicoarsening=True, linerelaxation=True, tol=1e-6)
+    sep = [emg3d.solve(model, sf, sslsolver=False, return_info=True, **kw) for sf in sfields]
+    bat = emg3d.solve_batch(model, sfields, **kw)
+    for (e1, i1), (e2, i2) in zip(sep, bat):
+        assert i1['exit'] == i2['exit'] == 0 and i1['it_mg'] == i2['it_mg']
+        assert np.array_equal(i1['error_at_cycle'], i2['error_at_cycle'])
+        assert np.array_equal(e1.field, e2.field)
+
+
+@pytest.mark.parametrize('lpw', [32, 16, 8])
+def test_line_lpw_option_on_long_lines_vs_default(lpw):
+    """Option line_lpw on a level with lines of 96+ blocks (advisor finding of round 3: with 32 lines per
+    workgroup the streamed kernel, whose two chain waves serve 16 lines, left lines 16..31 of every
+    workgroup unsmoothed): the launcher must keep such launches with k_line_colour, and the fields must not
+    depend on the option."""
+    lib = _lib.lib()
+    shape = (40, 200, 40)
+    grid, vm, s, e0 = _random_level_fields(shape, complex, 77)
+    args = (s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 2)
+    out = {}
+    old = lib.emg3d_get_option(b'line_lpw')
+    try:
+        for v in (0, lpw):
+            assert lib.emg3d_set_option(b'line_lpw', v) == 0
+            b = e0.copy()
+            core.gauss_seidel_y(b.fx, b.fy, b.fz, *args)
+            out[v] = b.field.copy()
+    finally:
+        lib.emg3d_set_option(b'line_lpw', old)
+    a = e0.copy()
+    ocore.gauss_seidel_y(a.fx, a.fy, a.fz, *args, order=1)
+    assert relerr(out[lpw], a.field) < 2e-12
+    assert np.array_equal(out[lpw], out[0])
+
+
 @pytest.mark.parametrize('shape,kw', [
     ((48, 32, 24), dict(cycle='W', semicoarsening=True, linerelaxation=True)),
     ((24, 40, 16), dict(cycle='V', semicoarsening=2, linerelaxation=2)),
@@ -649,8 +768,8 @@ def test_solve_ragged_grids_vs_oracle(shape, kw):
 
 
 @pytest.mark.parametrize('shape', [(36, 20, 18), (16, 8, 8), (18, 34, 10), (40, 24, 33)])
-@pytest.mark.parametrize('dtype', [complex, float])
-def test_point_tiled_schedule_vs_oracle_tile_order(shape, dtype):
+@pytest.mark.parametrize('dtype,extras', [(complex, False), (float, False), (complex, True), (float, True)])
+def test_point_tiled_schedule_vs_oracle_tile_order(shape, dtype, extras):
     """Tiled point smoother (k_gs_point_tile: LDS tile, eight tile colours) forced on small
     grids with several / partial tiles, against the oracle's order 2; with the precomputed
     eta edge sums (host flavour) and with sums formed on the fly (device flavour, fac = NULL)."""
@@ -659,7 +778,13 @@ def test_point_tiled_schedule_vs_oracle_tile_order(shape, dtype):
     h = [rng.uniform(0.5, 2.0, n) for n in shape]
     grid = mg_ref.Grid(h, (0., 0., 0.))
     sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
-    vm = mg_ref.volume_model(grid, 1.3 if dtype is complex else -1.3, *sig)
+    # extras: epsilon_r / mu_r at 3 MHz -- eta with a real part (the tiled kernel's full-width eta-sum
+    # layout, emg3d_level::flags without ETA_IMAG), zeta = V / mu_r
+    kwx = dict(mu_r=rng.uniform(0.7, 3.0, shape), epsilon_r=rng.uniform(1., 80., shape)) if extras else {}
+    fq = 3e6 if extras else 1.3
+    vm = mg_ref.volume_model(grid, fq if dtype is complex else -fq, *sig, **kwx)
+    if extras and dtype is complex:
+        assert np.abs(vm.eta_x.real).max() > 1e-3 * np.abs(vm.eta_x.imag).max()
     s = mg_ref.Field(grid, dtype=dtype)
     e0 = mg_ref.Field(grid, dtype=dtype)
     for f in (s, e0):
@@ -680,6 +805,7 @@ def test_point_tiled_schedule_vs_oracle_tile_order(shape, dtype):
             assert relerr(b.field, a.field) < 5e-10, (shape, nu)
             # device flavour without the eta-sum buffer
             lv = DeviceLevel.from_host(vm, torch.device('cuda'))
+            assert bool(lv.flags & _lib.LEVEL_ETA_IMAG) == (dtype is complex and not extras)
             lv.s.copy_(torch.from_numpy(s.field))
             lv.e.copy_(torch.from_numpy(e0.field))
             _lib.check(lib.emg3d_dev_gauss_seidel(lv._cref, 0, nu, None, None, None, 0, None), 'gs')
@@ -868,7 +994,7 @@ def test_rccl_single_rank_model_broadcast():
     assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(18))
 def test_randomised_smoother_parity(seed):
     """Randomised sweep over grid shapes (even, odd, 2-cell, long and short lines: every
     middle-block position and padding of the two-sided line solve, every lines-per-workgroup /
@@ -885,7 +1011,15 @@ def test_randomised_smoother_parity(seed):
     sx = 10 ** rng.uniform(-1, 1, shape)
     sy = 10 ** rng.uniform(-1, 1, shape) if case in ('HTI', 'triaxial') else None
     sz = 10 ** rng.uniform(-1, 1, shape) if case in ('VTI', 'triaxial') else None
-    vm = mg_ref.volume_model(grid, freq, sx, sy, sz)
+    # every third case with epsilon_r and mu_r at a frequency where the displacement term matters: eta gets a
+    # real part of the size of its imaginary one (emg3d/models.py:677-691), zeta = V / mu_r
+    extras = {}
+    if seed % 3 == 2:
+        freq = 2e6 if freq > 0 else -2e6
+        extras = dict(mu_r=rng.uniform(0.7, 3.0, shape), epsilon_r=rng.uniform(1., 80., shape))
+    vm = mg_ref.volume_model(grid, freq, sx, sy, sz, **extras)
+    if extras and freq > 0:
+        assert np.abs(vm.eta_x.real).max() > 1e-3 * np.abs(vm.eta_x.imag).max()
     dtype = complex if freq > 0 else float
     s = mg_ref.Field(grid, dtype=dtype)
     e0 = mg_ref.Field(grid, dtype=dtype)
@@ -1263,8 +1397,10 @@ def _oracle_sweeps(fn, vm, grid, s, e0, nu, tiled):
     return A.field
 
 
-def _level_with_host_model(shape, case, seed, stretch=1.03):
-    """_rand_level, keeping the host arrays of the model for the oracle."""
+def _level_with_host_model(shape, case, seed, stretch=1.03, extras=False):
+    """_rand_level, keeping the host arrays of the model for the oracle. extras: with epsilon_r (eta gets a
+    real part a tenth of its imaginary one: eta = -s mu0 V (sigma + s eps0 eps_r), emg3d/models.py:677-691)
+    and mu_r (zeta = V / mu_r)."""
     rng = np.random.default_rng(seed)
     h = [widths(n // 2, n // 4, 25., stretch) if n % 4 == 0 else
          25. * stretch ** np.abs(np.arange(n) - n // 2) for n in shape]
@@ -1282,15 +1418,26 @@ def _level_with_host_model(shape, case, seed, stretch=1.03):
     vm.eta_y = np.asfortranarray(vm.eta_x / 1.5) if case == 'triaxial' else vm.eta_x
     vm.eta_z = np.asfortranarray(vm.eta_x / 2.5) if case in ('VTI', 'triaxial') else vm.eta_x
     vm.zeta = np.asfortranarray(vol)
-    return DeviceLevel.from_host(vm, torch.device('cuda')), grid, vm
+    if extras:
+        disp = np.asfortranarray(-smu0 * vol * (0.1j * 10 ** rng.uniform(-1.5, 0.5, shape)))    # s eps0 eps_r: real eta
+        vm.eta_x = vm.eta_x + disp
+        vm.eta_y = vm.eta_y + disp if case == 'triaxial' else vm.eta_x
+        vm.eta_z = vm.eta_z + disp if case in ('VTI', 'triaxial') else vm.eta_x
+        vm.zeta = np.asfortranarray(vol / rng.uniform(0.7, 3.0, shape))
+    lv = DeviceLevel.from_host(vm, torch.device('cuda'))
+    assert bool(lv.flags & _lib.LEVEL_ETA_IMAG) == (not extras)
+    return lv, grid, vm
 
 
-@pytest.mark.parametrize('shape,case', [((128, 128, 128), 'VTI'), ((256, 256, 256), 'triaxial')])
-def test_full_size_per_sweep_parity_vs_oracle(shape, case):
+@pytest.mark.parametrize('shape,case,extras', [((128, 128, 128), 'VTI', False), ((256, 256, 256), 'triaxial', False),
+                                               ((128, 128, 128), 'VTI', True), ((160, 128, 96), 'triaxial', True)])
+def test_full_size_per_sweep_parity_vs_oracle(shape, case, extras):
     """BASELINE.json configs 2 / 3 sizes, every smoother, nu = 2 (backward + forward sweep, the
     repeated colour pass skipped, the tiled point smoother with its fused sweeps), default
-    library options: per-call values against the oracle in the same ordering, 2e-12 rel-L2."""
-    lv, grid, vm = _level_with_host_model(shape, case, 7)
+    library options: per-call values against the oracle in the same ordering, 2e-12 rel-L2. extras: the
+    same with epsilon_r and mu_r -- eta with a real part, i.e. the tiled point smoother's full-width
+    eta-sum layout (pst_stored_half false) at sizes that reach point_tile_min un-forced."""
+    lv, grid, vm = _level_with_host_model(shape, case, 7, extras=extras)
     s, e0 = _host_fields(lv, grid, 11)
     lv.s.copy_(torch.from_numpy(s))
     nodes = (shape[0] - 1) * (shape[1] - 1) * (shape[2] - 1)
@@ -1353,6 +1500,78 @@ def test_long_line_record_modes_vs_oracle(shape, lr, dtype):
     assert relerr(b.field, a.field) < 1e-11, (shape, fn)
 
 
+@pytest.mark.parametrize('kw,tile_min', [
+    (dict(cycle='F', semicoarsening=True, linerelaxation=True), None),
+    (dict(cycle='V', semicoarsening=False, linerelaxation=False), 1),
+])
+def test_solve_with_epsilon_r_and_mu_r_vs_oracle(kw, tile_min):
+    """A whole solve on a model with epsilon_r AND mu_r (emg3d/models.py:677-691) at a frequency where the
+    displacement current is comparable to the conduction current (eta gets a real part as large as its
+    imaginary one; the level's ETA_IMAG flag is off): line smoothers on every level, and the tiled point
+    smoother in its full-width eta-sum layout (point_tile_min = 1), against the oracle's driver in the same
+    ordering -- same cycle count, converged fields to 1e-8."""
+    lib = _lib.lib()
+    shape = (40, 32, 24)
+    rng = np.random.default_rng(17)
+    # resistive rock (1-10 kOhm m), 1 m cells, 100 kHz: omega eps / sigma ~ 0.3, and the 50 m grid stays well
+    # below the wavelength (~300 m) -- the operator is still diffusion-dominated and multigrid converges
+    h = [widths(n // 2, n // 4, 1., 1.08) for n in shape]
+    grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
+    assert grid.shape_cells == shape
+    rho = 10 ** rng.uniform(3.0, 4.0, shape)
+    eps = rng.uniform(1., 40., shape)
+    mur = rng.uniform(0.8, 2.5, shape)
+    freq = 1e5
+    model = emg3d.Model(grid, rho, 1.5 * rho, 2.5 * rho, mu_r=mur, epsilon_r=eps)
+    sfield = emg3d.get_source_field(grid, (0.5, -1., 0.25, 20., 30.), freq)
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    vm = mg_ref.volume_model(ogrid, freq, 1 / rho, 1 / (1.5 * rho), 1 / (2.5 * rho), mu_r=mur, epsilon_r=eps)
+    assert np.abs(vm.eta_x.real).max() > 0.05 * np.abs(vm.eta_x.imag).max()
+    old = lib.emg3d_get_option(b'point_tile_min')
+    try:
+        if tile_min is not None:
+            lib.emg3d_set_option(b'point_tile_min', tile_min)
+        e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **kw)
+    finally:
+        lib.emg3d_set_option(b'point_tile_min', old)
+    okw = dict(kw, order=1)
+    if tile_min is not None:
+        okw['tile_min'] = tile_min
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **okw)
+    assert info['exit'] == 0 and io['exit'] == 0, (info['exit_message'], io)
+    assert info['it_mg'] == io['it_mg']
+    assert relerr(e.field, eo.field) < 1e-8
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('name', ['marine128', 'triaxial256'])
+def test_full_size_converged_vs_oracle_same_order(name):
+    """BASELINE.json configs 2 and 3 at FULL size, exactly as bench.py builds them, solved to tol 1e-10 on the
+    GPU and by the oracle's multigrid driver in the same smoother ordering (its independent classes walked
+    by threads: bit-identical with the serial walk, tests/test_kernel_bodies_cpu.py): identical cycle
+    counts, identical exit state, converged fields within 1e-10 rel-L2. (Round 3 ran this from
+    tools/full_size_converged.py: 10 / 21 cycles, 1.6e-14 / 4.4e-13; oracle time ~15 s / ~4.5 min on 16
+    threads.) The reference's sequential order reaches the same fixed point; it is compared on the reduced
+    copies (test_bench_workloads_converged_vs_oracle) and at 32^3 against the reference itself."""
+    from bench import workload
+    wl = workload(name)
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **wl['opts'])
+    field = e.field.copy()
+    del e, model
+    torch.cuda.empty_cache()
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in wl['res'].items()}
+    vm = mg_ref.volume_model(ogrid, wl['frequency'], cond['property_x'], cond.get('property_y'), cond.get('property_z'))
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, order=1, **wl['opts'])
+    assert info['exit'] == io['exit'] == 0, (info['exit_message'], io)
+    assert info['it_mg'] == io['it_mg']
+    assert info['rel_error'] == pytest.approx(io['rel_error'], rel=1e-3)
+    assert relerr(field, eo.field) < 1e-10
+
+
 def test_marine128_one_cycle_vs_oracle_same_order():
     """BASELINE.json config 2 itself (bench.py workload 'marine128'): ONE F-cycle with
     semicoarsening and line relaxation on the GPU against the oracle's multigrid driver run in the
@@ -1394,10 +1613,10 @@ def test_bench_workloads_converged_vs_oracle(name):
     eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **wl['opts'])
     assert io['exit'] == 0
     assert relerr(e.field, eo.field) < 1e-8
-    # the four-colour line ordering needs more cycles than the lexicographic one on this kind of
-    # model (triaxial64, W-cycle: 25 against 17 at tol 1e-10; every colour sequence 18-20 against 12
-    # at 1e-8)
-    assert info['it_mg'] <= int(np.ceil(1.6 * io['it_mg']))
+    # the four-colour line ordering needs more cycles than the lexicographic one on this kind of model:
+    # 1.25 x with the cyclic pass sequence of round 3 (triaxial64, W-cycle: 21-22 against 17 at tol 1e-10),
+    # 1.5 x with the mirrored sweeps of rounds 1-2 -- the bound separates the two
+    assert info['it_mg'] <= int(np.ceil(1.3 * io['it_mg']))
 
 
 def _one_cycle_vs_oracle(name, source_index=0):
@@ -1454,7 +1673,7 @@ def test_salt96_other_pairs_converged_vs_oracle(pair):
     eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **wl['opts'])
     assert io['exit'] == 0
     assert relerr(e.field, eo.field) < 1e-8
-    assert info['it_mg'] <= int(np.ceil(1.6 * io['it_mg']))
+    assert info['it_mg'] <= int(np.ceil(1.3 * io['it_mg']))
 
 
 @pytest.mark.slow

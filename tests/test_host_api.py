@@ -382,8 +382,24 @@ def test_bench_helpers_without_a_gpu():
         lean, full = bench.workload(name, with_model=False), bench.workload(name)
         assert lean['res'] is None and full['res'] is not None
         assert all(np.array_equal(a, b) for a, b in zip(lean['h'], full['h'])) and lean['source'] == full['source']
-    assert bench.line_kernel_name(256) == 'k_line_stream' and bench.line_kernel_name(384) == 'k_line_stream'
-    assert bench.line_kernel_name(128) == 'k_line_colour' and bench.line_kernel_name(64) == 'k_line_colour'
+    # the label is the library's own dispatch decision (emg3d_line_kernel_name), per direction and batch
+    for lr in (1, 2, 3):
+        assert bench.line_kernel_name(lr, (256, 256, 256)) == 'k_line_stream'
+        assert bench.line_kernel_name(lr, (128, 128, 128)) == 'k_line_colour'
+        assert bench.line_kernel_name(lr, (256, 256, 256), batch=4) == 'k_line_stream_b'
+        assert bench.line_kernel_name(lr, (64, 64, 64), batch=4) == 'k_line_colour'
+    assert bench.line_kernel_name(1, (384, 256, 256)) == 'k_line_stream' and bench.line_kernel_name(2, (256, 16, 16)) == 'k_line_colour'
+    assert bench.line_kernel_name(2, (128, 128, 128), batch=8) == 'k_line_stream_b'
+    lib = _lib.lib()
+    old = lib.emg3d_get_option(b'line_lpw')
+    try:                        # 32 lines per workgroup: the streamed kernels (16 lines) must not be chosen
+        lib.emg3d_set_option(b'line_lpw', 32)
+        assert bench.line_kernel_name(2, (256, 256, 256)) == 'k_line_colour'
+    finally:
+        lib.emg3d_set_option(b'line_lpw', old)
+    for bad in (3, 6, 36, -4):
+        assert lib.emg3d_set_option(b'line_stream_r', bad) != 0
+    assert lib.emg3d_set_option(b'line_stream_r', 8) == 0 and lib.emg3d_set_option(b'line_stream_r', 0) == 0
     traffic, src = bench.pmc_traffic('triaxial256', 'k_gs_line<y>')
     assert traffic > 3e9 and src['file'].startswith('profiles/r03') and src['measured_in_this_run'] is False
     assert bench.pmc_traffic('no_such_workload', 'k') == (None, None)
