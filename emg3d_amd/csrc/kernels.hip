@@ -430,6 +430,29 @@ __global__ __launch_bounds__(256) void k_line_rhs_xt(emg::Level<T> L, int colour
 // is formed from the partial products T(j,4) c_j that the lanes already hold (quad sum).
 // Records of the next QD blocks are kept in flight in a register ring, so that a wave has
 // 16 lines x QD blocks outstanding instead of 64 lines x 1 block.
+// ---- the arithmetic of the chain steps, written out --------------------------------------------------
+// From here to the end of the line kernels floating-point contraction is OFF and every operation of the
+// forward / middle / backward steps is spelled as a multiplication, an addition or a fused multiply-add
+// (xop::mul / add / sub, emg::mad / nmad). With contraction left to the compiler, `a b - c d` may become
+// fma(a, b, -(c d)) or fma(-c, d, a b) depending on how often the products are used in the surrounding code
+// -- the same source expression then rounds differently in the single-source kernels, in the batched
+// kernel, and even between the unrolled right-hand sides of one batched kernel (measured: 4e-13 after
+// three sweeps). Spelled out, every line kernel performs the same operations in the same order: one
+// source gives the same bits whichever kernel runs it, alone or in a batch.
+#pragma clang fp contract(off)
+namespace xop {
+__device__ __forceinline__ double mul(double a, double b) { return a * b; }
+__device__ __forceinline__ cplx mul(double a, cplx b) { return cplx(a * b.re, a * b.im); }
+__device__ __forceinline__ cplx mul(cplx a, cplx b)
+{
+    return cplx(__builtin_fma(-a.im, b.im, a.re * b.re), __builtin_fma(a.im, b.re, a.re * b.im));
+}
+__device__ __forceinline__ double add(double a, double b) { return a + b; }
+__device__ __forceinline__ cplx add(cplx a, cplx b) { return cplx(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ double sub(double a, double b) { return a - b; }
+__device__ __forceinline__ cplx sub(cplx a, cplx b) { return cplx(a.re - b.re, a.im - b.im); }
+}  // namespace xop
+
 template <int CTRL> __device__ __forceinline__ double dpp_move(double x)
 {
     int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
@@ -445,8 +468,8 @@ template <int LN, class T> __device__ __forceinline__ T quad_bcast(T x) { return
 // sum over the four lanes of every quad (result in all lanes)
 template <class T> __device__ __forceinline__ T quad_sum(T x)
 {
-    x = x + dpp_move<0xB1>(x);   // quad_perm:[1,0,3,2]
-    x = x + dpp_move<0x4E>(x);   // quad_perm:[2,3,0,1]
+    x = xop::add(x, dpp_move<0xB1>(x));   // quad_perm:[1,0,3,2]
+    x = xop::add(x, dpp_move<0x4E>(x));   // quad_perm:[2,3,0,1]
     return x;
 }
 // cyclic shift inside every quad: lane j receives the value of lane (j + R) & 3
@@ -640,15 +663,15 @@ __device__ __forceinline__ void quad_forward_step(const QuadRow<T> &q, const T v
                                                   const double is0, T &wsel, T &w4p, T &wn, T &w4)
 {
     // c_j = rhs_j - (B w_prev)_j ; row 0: the row sum ; row j: B(j,j) w_j
-    const T rowsum = quad_sum(q.bA * wsel);
-    const T cj = emg::nmad(q.bD * nz, wsel, emg::nmad(is0, rowsum, v));
-    const T c4 = v4 - q.d4 * w4p;
+    const T rowsum = quad_sum(xop::mul(q.bA, wsel));
+    const T cj = emg::nmad(xop::mul(q.bD, nz), wsel, emg::nmad(is0, rowsum, v));
+    const T c4 = emg::nmad(q.d4, w4p, v4);
     const T c1 = quad_rot<1>(cj), c2 = quad_rot<2>(cj), c3 = quad_rot<3>(cj);
     // w_j = sum_m T(j,m) c_m ; w_4 from the partial products T(j,4) c_j
     // two accumulators, four fused multiply-adds per complex product (cplx.h: mad)
-    wn = emg::mad(q.t[4], c4, emg::mad(q.t[1], c1, q.t[0] * cj)) + emg::mad(q.t[3], c3, q.t[2] * c2);
-    w4 = emg::mad(q.t44, c4, quad_sum(q.t[4] * cj));
-    wsel = nz * wn + is0 * w4;
+    wn = xop::add(emg::mad(q.t[4], c4, emg::mad(q.t[1], c1, xop::mul(q.t[0], cj))), emg::mad(q.t[3], c3, xop::mul(q.t[2], c2)));
+    w4 = emg::mad(q.t44, c4, quad_sum(xop::mul(q.t[4], cj)));
+    wsel = emg::mad(nz, wn, xop::mul(is0, w4));
     w4p = w4;
 }
 
@@ -744,10 +767,10 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
             const T y = m < 4 ? *V.p(kt, line, m) : *V.p4(kt, line);
-            q0 += lf[m - 1] * y;
-            z[m] -= lf[3 + m] * y;
+            q0 = emg::mad(lf[m - 1], y, q0);
+            z[m] = emg::nmad(lf[3 + m], y, z[m]);
         }
-        z[0] -= q0;
+        z[0] = xop::sub(z[0], q0);
     }
     {   // bottom coupling U_{m+1} w_{m+2}; w_{m+2} = slots (m+2, 0), (m+1, 1..4); U of an
         // identity padding block is zero, so no guard is needed
@@ -756,13 +779,15 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
             const T y = m < 4 ? *V.p(mk + 1, line, m) : *V.p4(mk + 1, line);
-            q0 += lf[m - 1] * y;
-            z[m] -= lf[3 + m] * y;
+            q0 = emg::mad(lf[m - 1], y, q0);
+            z[m] = emg::nmad(lf[3 + m], y, z[m]);
         }
-        z[5] -= q0;
+        z[5] = xop::sub(z[5], q0);
     }
-    xa = emg::mad(ta[4], z[4], emg::mad(ta[2], z[2], ta[0] * z[0])) + emg::mad(ta[5], z[5], emg::mad(ta[3], z[3], ta[1] * z[1]));
-    xb = emg::mad(tb[4], z[4], emg::mad(tb[2], z[2], tb[0] * z[0])) + emg::mad(tb[5], z[5], emg::mad(tb[3], z[3], tb[1] * z[1]));
+    xa = xop::add(emg::mad(ta[4], z[4], emg::mad(ta[2], z[2], xop::mul(ta[0], z[0]))),
+                 emg::mad(ta[5], z[5], emg::mad(ta[3], z[3], xop::mul(ta[1], z[1]))));
+    xb = xop::add(emg::mad(tb[4], z[4], emg::mad(tb[2], z[2], xop::mul(tb[0], z[0]))),
+                 emg::mad(tb[5], z[5], emg::mad(tb[3], z[3], xop::mul(tb[1], z[1]))));
 }
 
 // Backward substitution of one half, outwards from the middle block, fused with the scatter
@@ -836,7 +861,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     x[0] = HALF ? xq5 : xq0;
     x[4] = xq4;
     const double own0 = j == 0 ? 1.0 : 0.0;
-    T xmine = HALF ? own0 * xq5 + (1.0 - own0) * xa : xa;   // this lane's own entry of x
+    T xmine = HALF ? emg::mad(own0, xq5, xop::mul(1.0 - own0, xa)) : xa;   // this lane's own entry of x
     double upA = qm.bA, upD = qm.bD, up04 = qm.b04, up44 = qm.d4;          // entries of the coupling block
     // running scatter pointers (surplus quads: the dummy slots, not advanced): no per-lane
     // 64-bit multiply per step
@@ -849,16 +874,8 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
         for (int d = 0; d < QD; ++d) {
             const int k = W.bwd(i0 + d);
             const QuadRow<T> &q = ring[d];
-            // h = B^T x_prev: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
-            const T hj = (upA * nz) * x[0] + (upD * nz) * xmine;
-            const T h4 = up04 * x[0] + up44 * x[4];
-            const T h1 = quad_rot<1>(hj), h2 = quad_rot<2>(hj), h3 = quad_rot<3>(hj);
-            const T xn = emg::nmad(q.t[4], h4, emg::nmad(q.t[1], h1, emg::nmad(q.t[0], hj, q.v))) -
-                         emg::mad(q.t[3], h3, q.t[2] * h2);
-            const T x4 = emg::nmad(q.t44, h4, q.v4) - quad_sum(q.t[4] * hj);
-            x[0] = quad_bcast<0>(xn);
-            x[4] = x4;
-            xmine = xn;
+            T xn, x4;
+            quad_backward_step(q, q.v, q.v4, nz, upA, upD, up04, up44, x[0], x[4], xmine, xn, x4);
             upA = q.bA; upD = q.bD; up04 = q.b04; up44 = q.d4;
             const bool real_block = HALF ? k <= n0 - 1 : true;      // uniform over the wave
             T *const oj = real_block ? pej : dj;
@@ -870,6 +887,26 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
             fetch(ring[d], i0 + d + QD);
         }
     }
+}
+
+// One block step of a backward half-chain for one right-hand side: (wj, w4) = this lane's entries j and 4 of
+// the block's w record, q its factor record, (upA, upD, up04, up44) the coupling to the block solved before;
+// updates the carried x_0 / x_4 / own entry and returns the block's x_j and x_4.
+template <class T>
+__device__ __forceinline__ void quad_backward_step(const QuadRow<T> &q, const T wj, const T w4, const double nz,
+                                                   const double upA, const double upD, const double up04,
+                                                   const double up44, T &x0, T &x4, T &xmine, T &xn, T &xn4)
+{
+    // h = B^T x_prev: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
+    const T hj = emg::mad(xop::mul(upA, nz), x0, xop::mul(xop::mul(upD, nz), xmine));
+    const T h4 = emg::mad(up04, x0, xop::mul(up44, x4));
+    const T h1 = quad_rot<1>(hj), h2 = quad_rot<2>(hj), h3 = quad_rot<3>(hj);
+    xn = xop::sub(emg::nmad(q.t[4], h4, emg::nmad(q.t[1], h1, emg::nmad(q.t[0], hj, wj))),
+                  emg::mad(q.t[3], h3, xop::mul(q.t[2], h2)));
+    xn4 = xop::sub(emg::nmad(q.t44, h4, w4), quad_sum(xop::mul(q.t[4], hj)));
+    x0 = quad_bcast<0>(xn);
+    x4 = xn4;
+    xmine = xn;
 }
 
 template <class T, int DIR, int QD>
@@ -1271,7 +1308,7 @@ __device__ __forceinline__ void quad_backward_b(const emg::Level<T> &L, int colo
         }
         x0[b] = HALF ? xq5 : xq0;
         x4[b] = xq4;
-        xmine[b] = HALF ? own0 * xq5 + (1.0 - own0) * xa : xa;
+        xmine[b] = HALF ? emg::mad(own0, xq5, xop::mul(1.0 - own0, xa)) : xa;
     }
     asm volatile("" ::: "memory");           // keep the ring fetch behind the middle blocks
 #pragma unroll
@@ -1299,16 +1336,8 @@ __device__ __forceinline__ void quad_backward_b(const emg::Level<T> &L, int colo
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
                     const T wj = it[b * srcelems + j], w4 = it[b * srcelems + 4];
-                    // h = B^T x_prev: h_0 = 0, h_m = B(0,m) x_0 + B(m,m) x_m
-                    const T hj = (upA * nz) * x0[b] + (upD * nz) * xmine[b];
-                    const T h4 = up04 * x0[b] + up44 * x4[b];
-                    const T h1 = quad_rot<1>(hj), h2 = quad_rot<2>(hj), h3 = quad_rot<3>(hj);
-                    const T xn = emg::nmad(q.t[4], h4, emg::nmad(q.t[1], h1, emg::nmad(q.t[0], hj, wj))) -
-                                 emg::mad(q.t[3], h3, q.t[2] * h2);
-                    const T xn4 = emg::nmad(q.t44, h4, w4) - quad_sum(q.t[4] * hj);
-                    x0[b] = quad_bcast<0>(xn);
-                    x4[b] = xn4;
-                    xmine[b] = xn;
+                    T xn, xn4;
+                    quad_backward_step(q, wj, w4, nz, upA, upD, up04, up44, x0[b], x4[b], xmine[b], xn, xn4);
                     oj[b * ostep] = xn;
                     o4[b * ostep] = xn4;
                 }
@@ -1401,6 +1430,8 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T
     else quad_backward_b<T, DIR, 1, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
 #endif
 }
+
+#pragma clang fp contract(fast)      // (end of the spelled-out section: the compiler's default again)
 
 // Residual + per-block partial sums of |r|^2. A workgroup walks `zb` consecutive planes: the plane
 // above the current one, fetched for the curl, is the next iteration's own plane and is still in

@@ -658,6 +658,8 @@ def test_batched_streamed_line_kernel_equals_single_source(shape, lr, batch, dty
     lib = _lib.lib()
     if batch >= 5 and lr != 2:
         pytest.skip('group splitting is direction-independent: one direction is enough')
+    if dtype is float and lr != 3:
+        pytest.skip('the records of 16 real 130-block lines fit in LDS: k_line_colour')
     assert lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), batch) == b'k_line_stream_b'
     grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + lr + batch)
     dev = torch.device('cuda')

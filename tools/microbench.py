@@ -22,7 +22,7 @@ import emg3d_amd as emg3d                       # noqa: E402
 from bench import widths, BYTES_PER_CELL_SWEEP  # noqa: E402
 
 
-def make_level(n, case, stretch=1.03, shape=None, eta_real=False):
+def make_level(n, case, stretch=1.03, shape=None, eta_real=False, batch=1):
     shape = shape or (n, n, n)
     rng = np.random.default_rng(1)
     h = [widths(m - 2 * (m // 4), m // 4, 25., stretch) for m in shape]
@@ -41,12 +41,16 @@ def make_level(n, case, stretch=1.03, shape=None, eta_real=False):
     vm.eta_y = np.asfortranarray(vm.eta_x / 1.5) if case == 'triaxial' else vm.eta_x
     vm.eta_z = np.asfortranarray(vm.eta_x / 2.5) if case in ('VTI', 'triaxial') else vm.eta_x
     vm.zeta = np.asfortranarray(vol)
-    lv = DeviceLevel.from_host(vm, torch.device('cuda'))
+    lv = DeviceLevel.from_host(vm, torch.device('cuda'), batch=batch)
     gen = torch.Generator(device='cuda').manual_seed(1)
+    one = DeviceLevel.from_host(vm, torch.device('cuda')) if batch > 1 else lv
     for t in (lv.e, lv.s):
-        t.copy_(torch.complex(torch.randn(grid.n_edges, generator=gen, device='cuda', dtype=torch.float64),
-                              torch.randn(grid.n_edges, generator=gen, device='cuda', dtype=torch.float64)))
-    lv.pec_zero()
+        for b in range(batch):                    # every right-hand side its own values, PEC faces zeroed
+            one.e.copy_(torch.complex(torch.randn(grid.n_edges, generator=gen, device='cuda', dtype=torch.float64),
+                                      torch.randn(grid.n_edges, generator=gen, device='cuda', dtype=torch.float64)))
+            one.pec_zero()
+            t[b * grid.n_edges:(b + 1) * grid.n_edges].copy_(one.e)
+    del one
     return lv, grid
 
 
@@ -81,15 +85,16 @@ def main():
     ap.add_argument('--fused-only', action='store_true', help='line smoothers: the default fused launches only')
     ap.add_argument('--eta-real', action='store_true', help='eta with a real part (as with epsilon_r)')
     ap.add_argument('--opt', action='append', default=[], help='library option name=value (repeatable)')
+    ap.add_argument('--batch', type=int, default=1, help='right-hand sides that share the level (lines only)')
     args = ap.parse_args()
     lib = _lib.lib()
     for o in args.opt:
         k, v = o.split('=')
         assert lib.emg3d_set_option(k.encode(), int(v)) == 0, o
     shape = tuple(int(x) for x in args.shape.split(',')) if args.shape else None
-    lv, grid = make_level(args.n, args.case, shape=shape, eta_real=args.eta_real)
+    lv, grid = make_level(args.n, args.case, shape=shape, eta_real=args.eta_real, batch=args.batch)
     nc = grid.n_cells
-    print(f"# {shape or args.n} {args.case}, nu={args.nu}")
+    print(f"# {shape or args.n} {args.case}, nu={args.nu}, batch={args.batch}")
     if args.what in ('point', 'all'):
         lib.emg3d_set_option(b'point_tile_min', 1)
         med, mn = timeit(lambda: lv.smooth(0, args.nu))
@@ -106,7 +111,8 @@ def main():
             lib.emg3d_set_option(b'line_fuse', fuse)
             for lr in (1, 2, 3):
                 med, mn = timeit(lambda: lv.smooth(lr, args.nu), reps=5, warm=1)
-                report(f"gauss_seidel_{'xyz'[lr - 1]} (line) fuse={fuse}", med, nc, args.nu, args.case)
+                kn = lib.emg3d_line_kernel_name(lr, *grid.shape_cells, 1, args.batch).decode()
+                report(f"gauss_seidel_{'xyz'[lr - 1]} fuse={fuse} {kn} /source", med / args.batch, nc, args.nu, args.case)
         lib.emg3d_set_option(b'line_fuse', 2)
     if args.what in ('residual', 'all'):
         med, mn = timeit(lambda: lv.residual(store=True, norm=False))
