@@ -84,10 +84,10 @@ def workload(name, source_index=0, with_model=True):
         return dict(h=[hx, hx, hz], origin=origin, res=res, source=src, frequency=1.0,
                     opts=opts, case='VTI', label=f"{n}^3 stretched marine halfspace, VTI, "
                     "x-dipole, 1 Hz, F-cycle + semicoarsening + line relaxation")
-    if name in ('triaxial256', 'triaxial128', 'triaxial64'):
+    if name in ('triaxial512', 'triaxial256', 'triaxial128', 'triaxial64'):
         # config 3: stretched grid, blocky tri-axial model, W-cycle + sc + lr
         n = int(name[8:])
-        h = widths(n // 2, n // 4, 25., 1.03 if n == 256 else 1.06)
+        h = widths(n // 2, n // 4, 25., {512: 1.015, 256: 1.03}.get(n, 1.06))
         origin = (-h.sum() / 2,) * 3
         res = None
         if with_model:
@@ -510,6 +510,8 @@ def run_gpu(args):
                        'cells': n0, 'cycle': wl['opts']['cycle'],
                        'cell_sweeps_per_step': work / args.steps,
                        'rel_error_after_run': l2,
+                       'line_factors': b.hier.line_factors,
+                       'hbm_allocated_gb': torch.cuda.max_memory_allocated() / 1e9,
                        'parallelism': f'{world} independent sources, 1 per GPU',
                        'model_distribution': None if world == 1 else
                        'parallel.broadcast_model from rank 0 (one broadcast per property array, received '
@@ -742,7 +744,11 @@ def main():
     ap.add_argument('--no-ttt', action='store_true', help="skip the time-to-tolerance block")
     ap.add_argument('--no-256', action='store_true',
                     help="skip the separate 256^3 smoother measurement ('smoothers_256')")
+    ap.add_argument('--line-factors', default=None, choices=['resident', 'rebuild', 'single'],
+                    help="factor-memory policy of the hierarchy (solver.Hierarchy; default: resident)")
     args = ap.parse_args()
+    if args.line_factors:
+        os.environ['EMG3D_AMD_LINE_FACTORS'] = args.line_factors
     if 'RANK' not in os.environ and args.gpus > 1:
         raise SystemExit(_spawn_ranks(args))
     if args.opt:

@@ -63,6 +63,7 @@ def smooth_level(lv, nu, lr_dir, var):
     point, fewer cycles on models where the multi-colour ordering costs cycles)."""
     axes = _LR_AXES[current_lr_dir(lr_dir, lv.grid)]
     omega = getattr(var, 'smoother_omega', 1.0)
+    lv._factor_keep = axes             # (policy 'rebuild': the directions that should not make room)
     for lr in axes or (0,):
         if omega != 1.0:
             lv.keep_field()
@@ -182,6 +183,7 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None):
     depth = int(var.clevel[var.sc_dir])
     steps = coarse_schedule(var.cycle, var.cycmax, depth, first_level, budget, var.nu_pre, var.nu_coarse,
                             var.nu_post)
+    clv.work.factor_epoch += 1         # (policy 'rebuild': coarse levels start a correction without factors)
     runner = CoarseCorrection(clv, first_level, var)
     if graphed is None:
         graphed = first_level == 1 and var.verb < 5 and USE_GRAPHS and CONCURRENT == 0

@@ -59,6 +59,10 @@ class Workspace:
         self._pin, self._pin_used, self._pins = None, 0, []
         self.ws = None
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
+        # line factors of the hierarchy's levels: 'resident' (every direction a level has used stays in
+        # HBM: 304 B per cell and direction) or 'rebuild' (DeviceLevel.line_factors)
+        self.factor_policy = 'resident'
+        self.factor_epoch = 0          # advanced by every coarse-grid correction (_cycle.coarse_correction)
 
     def upload(self, a):
         """Small host array -> device tensor through a pinned staging pool, asynchronously on
@@ -140,14 +144,19 @@ class DeviceLevel:
 
     # ---------------------------------------------------------------------------------
     @classmethod
-    def from_host(cls, vmodel, device, work=None, batch=1):
-        """Upload a host ``VolumeModel`` (finest level)."""
+    def from_host(cls, vmodel, device, work=None, batch=1, line_factors='resident'):
+        """Upload a host ``VolumeModel`` (finest level). line_factors: 'resident' | 'rebuild' | 'single', the factor
+        memory policy of the whole hierarchy (``line_factors`` / ``_line_factor_slots``)."""
+        if line_factors not in ('resident', 'rebuild', 'single'):
+            raise ValueError(f"`line_factors` must be 'resident', 'rebuild' or 'single'. Provided: {line_factors!r}.")
         work = work or Workspace(device)
+        work.factor_policy = line_factors
         if hasattr(vmodel, 'device_arrays'):
             # emg3d_amd.models.VolumeModel: form eta / zeta in HBM from the conductivities
             ex, ey, ez, zeta = vmodel.device_arrays(device)
             top = cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case, ex, ey, ez,
                       zeta, ex.dtype, work, device, batch)
+            top.is_top = True
             nx, ny, nz = top.grid.shape_cells
             work.need_gs(batch * max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
                                      for lr in (1, 2, 3)))
@@ -165,6 +174,7 @@ class DeviceLevel:
         top = cls(meshes.BaseMesh(vmodel.grid.h, vmodel.grid.origin), vmodel.case,
                   upload(vmodel.eta_x, ndt), upload(vmodel.eta_y, ndt), upload(vmodel.eta_z, ndt),
                   upload(vmodel.zeta, np.float64), dtype, work, device, batch)
+        top.is_top = True
         nx, ny, nz = top.grid.shape_cells
         work.need_gs(batch * max(_lib.lib().emg3d_gs_scratch_bytes(lr, nx, ny, nz, top.is_complex)
                                  for lr in (1, 2, 3)))
@@ -188,9 +198,53 @@ class DeviceLevel:
         return hit[1]
 
     # ------------------------------------------------------------------- kernels ------
+    def _line_factor_slots(self, lr):
+        """Policy 'rebuild': a level holds TWO factor buffers (the two directions of a line-relaxation
+        code; 608 instead of 912 B per cell with all three directions in use; policy 'single': ONE buffer,
+        304 B per cell, re-factorised at every change of direction) and re-factorises when a
+        direction is asked for that neither holds -- emg3d_dev_line_setup into the same buffer, i.e. the same
+        addresses whatever the direction. The finest level keeps its buffers from cycle to cycle: when the
+        code advances (4 -> 5 -> 6: (y,z) -> (x,z) -> (x,y)) one direction is rebuilt per cycle, the
+        direction that is not part of the new code makes room. A coarse level starts every coarse-grid
+        correction with empty buffers (``work.factor_epoch``) and rebuilds at its first smoothing call of the
+        correction: what a correction launches then does not depend on what ran before it -- the condition
+        for replaying it from a captured graph."""
+        lib = _lib.lib()
+        work = self.work
+        slots = self.__dict__.get('_slots')
+        if slots is None:
+            nx, ny, nz = self.grid.shape_cells
+            nf = max(lib.emg3d_line_fac_bytes(d, nx, ny, nz, self.is_complex) for d in (1, 2, 3))
+            nl = max(lib.emg3d_line_lfac_bytes(d, nx, ny, nz) for d in (1, 2, 3))
+            slots = self._slots = [{'dir': None, 'used': 0,
+                                    'fac': torch.empty(nf, dtype=torch.uint8, device=self.device),
+                                    'lfac': torch.empty(nl, dtype=torch.uint8, device=self.device)}
+                                   for _ in range(1 if work.factor_policy == 'single' else 2)]
+            self._slot_epoch, self._slot_clock, self.factor_rebuilds = work.factor_epoch, 0, 0
+        if not self.__dict__.get('is_top', False) and self._slot_epoch != work.factor_epoch:
+            for sl in slots:
+                sl['dir'] = None
+            self._slot_epoch = work.factor_epoch
+        self._slot_clock += 1
+        for sl in slots:
+            if sl['dir'] == lr:
+                sl['used'] = self._slot_clock
+                return sl['fac'], sl['lfac']
+        keep = self.__dict__.get('_factor_keep', ())
+        free = [sl for sl in slots if sl['dir'] is None] or [sl for sl in slots if sl['dir'] not in keep]
+        victim = min(free or slots, key=lambda sl: sl['used'])
+        _lib.check(lib.emg3d_dev_line_setup(self._cref, lr, _ptr(victim['fac']), _ptr(victim['lfac']), _stream()),
+                   'emg3d_dev_line_setup')
+        victim['dir'], victim['used'] = lr, self._slot_clock
+        self.factor_rebuilds += 1
+        return victim['fac'], victim['lfac']
+
     def line_factors(self, lr):
         """Block factorisation of all lines of direction lr (1/2/3), built on first use
-        and kept for the lifetime of the level (the model does not change in a solve)."""
+        and kept for the lifetime of the level (the model does not change in a solve) -- or, with the
+        hierarchy's policy 'rebuild', held in one of two buffers per level (``_line_factor_slots``)."""
+        if self.work.factor_policy in ('rebuild', 'single'):
+            return self._line_factor_slots(lr)
         if lr not in self._factors:
             lib = _lib.lib()
             nx, ny, nz = self.grid.shape_cells

@@ -14,6 +14,8 @@ Differences from the reference that are intended:
   value is used (level 0, or ``verb > 4``);
 * coarse grids / models / weights are built once per (level, sc_dir) and reused.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -523,9 +525,17 @@ def _device():
 class Hierarchy:
     """Level 0 on the device for one (model, frequency): upload once, cycle many times."""
 
-    def __init__(self, vmodel, device=None, batch=1):
+    def __init__(self, vmodel, device=None, batch=1, line_factors=None):
+        """line_factors: 'resident' (default; or the environment's EMG3D_AMD_LINE_FACTORS) keeps the line
+        factorisation of every direction a level has used in HBM -- 304 B per cell and direction, ~1.5 kB per
+        cell of the finest level for the whole hierarchy with three directions; 'rebuild' keeps two directions
+        per level and re-factorises on change (``DeviceLevel._line_factor_slots``): ~1.1 kB per cell, one
+        more factorisation per level and cycle when the line-relaxation code cycles; 'single' keeps one
+        direction per level and re-factorises at every change of direction."""
         self.device = device or _device()
-        self.top = DeviceLevel.from_host(vmodel, self.device, batch=batch)
+        line_factors = line_factors or os.environ.get('EMG3D_AMD_LINE_FACTORS', 'resident')
+        self.line_factors = line_factors
+        self.top = DeviceLevel.from_host(vmodel, self.device, batch=batch, line_factors=line_factors)
         self.shape = tuple(vmodel.grid.shape_cells)
         self.sval = complex(vmodel._sval)
 

@@ -1708,6 +1708,57 @@ def test_config4_eight_sources_batch_equals_separate_and_oracle():
     assert relerr(sep[7][0].field, eo.field) < 1e-8
 
 
+@pytest.mark.parametrize('kw', [dict(cycle='W', semicoarsening=True, linerelaxation=True),
+                                dict(cycle='F', semicoarsening=False, linerelaxation=7),
+                                dict(cycle='V', semicoarsening=True, linerelaxation=2, sslsolver=True)])
+def test_line_factor_policy_rebuild_equals_resident(kw):
+    """Hierarchy(line_factors='rebuild' / 'single'): two / one factor buffers per level, re-factorised when the line-relaxation
+    code asks for a direction neither holds (the finest level from cycle to cycle, coarse levels inside every
+    coarse-grid correction, also when that correction is replayed from a captured graph: > 3 occurrences of
+    every variant here). Same factors, same kernels: fields, cycle counts and error histories bit-identical to
+    the resident policy; the line-factor bytes of the hierarchy drop to at most 2/3."""
+    shape = (32, 24, 40)
+    rng = np.random.default_rng(3)
+    h = [widths(n // 2, n // 4, 30., 1.1) for n in shape]
+    grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
+    rho = 10 ** rng.uniform(-0.5, 1.0, shape)
+    model = emg3d.Model(grid, rho, 1.5 * rho, 2.5 * rho)
+    sfield = emg3d.get_source_field(grid, (3., -2., 1., 20., 30.), 0.8)
+    opts = dict({'sslsolver': False, 'tol': 1e-11, 'maxit': 40}, **kw)
+    vmodel = emg3d.models.VolumeModel(model, sfield)
+    out, nbytes = {}, {}
+
+    def factor_bytes(lv, seen):
+        if id(lv) in seen:
+            return 0
+        seen.add(id(lv))
+        n = sum(f.numel() + lf.numel() for k, (f, lf) in lv._factors.items() if k in (1, 2, 3))
+        n += sum(sl['fac'].numel() + sl['lfac'].numel() for sl in lv.__dict__.get('_slots', []))
+        return n + sum(factor_bytes(link['level'], seen) for link in lv.children.values())
+    for policy in ('resident', 'rebuild', 'single'):
+        hier = solver.Hierarchy(vmodel, line_factors=policy)
+        e, info = emg3d.solve(model, sfield, return_info=True, hierarchy=hier, **opts)
+        e2, info2 = emg3d.solve(model, sfield, return_info=True, hierarchy=hier, **opts)     # reused: graphs replayed from the start
+        assert np.array_equal(e.field, e2.field) and info['it_mg'] == info2['it_mg']
+        out[policy] = (e.field.copy(), info)
+        nbytes[policy] = factor_bytes(hier.top, set())
+        if policy != 'resident':
+            assert hier.top.factor_rebuilds >= 3
+        del hier
+    e1, i1 = out['resident']
+    for policy in ('rebuild', 'single'):
+        e2, i2 = out[policy]
+        assert i1['exit'] == i2['exit'] and i1['it_mg'] == i2['it_mg'] and i1['it_mg'] >= 6
+        assert np.array_equal(i1['error_at_cycle'], i2['error_at_cycle'])
+        assert np.array_equal(e1, e2)
+    if kw['linerelaxation'] in (True, 7):
+        # (two / one buffer per level, each sized for the level's largest direction: on the slab-shaped levels of
+        # a semicoarsened hierarchy the padded records of short lines cost more than a third)
+        assert nbytes['single'] < nbytes['rebuild'] <= 0.9 * nbytes['resident'] and nbytes['single'] <= 0.5 * nbytes['resident']
+    with pytest.raises(ValueError, match='line_factors'):
+        solver.Hierarchy(vmodel, line_factors='sometimes')
+
+
 def test_hierarchy_field_follows_a_solve_that_has_nothing_to_do():
     """A solve that takes the zero-source / already-converged shortcut on a reused hierarchy must
     leave THIS solve's field in HBM (receivers and the gradient read it there), not the previous
