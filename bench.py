@@ -330,6 +330,53 @@ def survey_8(device):
     return out
 
 
+def survey_config5(device, name='salt384'):
+    """BASELINE.json config 5 on ONE GPU: 4 frequencies x 2 sources on the 384 x 256 x 256 salt-like model as whole
+    solves to tol 1e-6. Sources of one frequency share the model, hence every level's line factorisation: the two
+    sources of a frequency are solved TOGETHER (solver.solve_batch; on the levels with long lines one workgroup
+    serves its lines for both right-hand sides per factor fetch, k_line_stream_b) -- against one after the other
+    on a hierarchy they share (what `parallel.compute(reuse=True)` does). Fields are bit-identical either way."""
+    import torch
+    import emg3d_amd as emg3d
+    from emg3d_amd import solver, models
+    wls = [workload(name, source_index=i) for i in range(8)]         # pair index = 2 x frequency index + source
+    grid = emg3d.TensorMesh(wls[0]['h'], wls[0]['origin'])
+    model = emg3d.Model(grid, **wls[0]['res'])
+    opts = {k: v for k, v in wls[0]['opts'].items() if k != 'sslsolver'}
+    opts.update(tol=1e-6, verb=0)
+    out = {'workload': f'config 5: 4 frequencies x 2 sources, {grid.shape_cells} salt-like model, whole solves to '
+           'tol 1e-6 (setup of the hierarchy of each frequency included)'}
+    for tag, together in (('one_by_one', False), ('two_sources_of_a_frequency_together', True)):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        its, work, per_freq = [], 0.0, []
+        for fi in range(4):
+            tf = time.perf_counter()
+            pair = wls[2 * fi:2 * fi + 2]
+            sfs = [emg3d.get_source_field(grid, w['source'], w['frequency']) for w in pair]
+            if together:
+                res = emg3d.solve_batch(model, sfs, keep_fields=False, **opts)
+            else:
+                hier = solver.Hierarchy(models.VolumeModel(model, sfs[0]))
+                res = [emg3d.solve(model, sf, sslsolver=False, return_info=True, hierarchy=hier, _download=False, **opts)
+                       for sf in sfs]
+                del hier
+            for _, info in res:
+                its.append(int(info['it_mg']))
+                work += info['smoother_cell_sweeps']
+            torch.cuda.synchronize(device)
+            torch.cuda.empty_cache()
+            per_freq.append({'frequency': pair[0]['frequency'], 'seconds': time.perf_counter() - tf})
+        dt = time.perf_counter() - t0
+        out[tag] = {'seconds': dt, 'ms_per_source': dt / 8 * 1e3, 'Mcell_sweeps_per_s': work / dt / 1e6,
+                    'cycles': its, 'per_frequency': per_freq}
+    return out
+
+
+# Cycles to tol 1e-6 of config 5's pairs by frequency (0.25 / 0.5 / 1 / 2 Hz; bench.py's `survey_config5`
+# measures them): the cost estimates a multi-rank run hands to parallel.shard (longest-processing-time first)
+PAIR_COSTS = {'salt384': [c for c in (9, 9, 9, 9) for _ in range(2)]}
+
 REDUCED_COPY = {'triaxial256': 'triaxial64', 'marine128': 'marine64', 'salt384': 'salt96'}
 
 
@@ -393,7 +440,7 @@ def pmc_traffic(workload_name, kernel):
     FETCH_SIZE / WRITE_SIZE in separate passes of this very command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured in this run, counters cannot be read
     from inside the process; (None, None) if there is no entry for this workload and kernel."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 doc = json.load(f)
@@ -430,7 +477,14 @@ def run_gpu(args):
     # rank 0 builds the model; the others receive it through the product's broadcast (one RCCL
     # broadcast per property array over xGMI, the received arrays stay in HBM and eta / zeta are
     # formed from them on the device: parallel.broadcast_model)
-    wl = workload(args.workload, source_index=rank if world > 1 else 0, with_model=(rank == 0))
+    # which (source, frequency) pair this rank cycles on: its own source; for a workload whose pairs differ in
+    # cost (config 5: cycles to tolerance by frequency, PAIR_COSTS) the first pair of the rank's share under the
+    # product's longest-processing-time sharding -- with as many ranks as pairs every rank has exactly one
+    pair = rank if world > 1 else 0
+    if world > 1 and args.workload in PAIR_COSTS:
+        costs = PAIR_COSTS[args.workload]
+        pair = (parallel.shard(len(costs), rank, world, costs) or [rank % len(costs)])[0]
+    wl = workload(args.workload, source_index=pair, with_model=(rank == 0))
     model = None
     if rank == 0:
         model = emg3d.Model(emg3d.TensorMesh(wl['h'], wl['origin']), **wl['res'])
@@ -512,7 +566,7 @@ def run_gpu(args):
                        'rel_error_after_run': l2,
                        'line_factors': b.hier.line_factors,
                        'hbm_allocated_gb': torch.cuda.max_memory_allocated() / 1e9,
-                       'parallelism': f'{world} independent sources, 1 per GPU',
+                       'parallelism': f'{world} independent sources, 1 per GPU', 'pair_of_rank_0': pair,
                        'model_distribution': None if world == 1 else
                        'parallel.broadcast_model from rank 0 (one broadcast per property array, received '
                        f'arrays stay in HBM), backend {backend}', 'broadcast_ms': broadcast_ms},
@@ -551,6 +605,12 @@ def run_gpu(args):
             out['survey_8_sources'] = survey_8(device)
         except Exception as exc:        # informational block: never takes the bench line down
             out['survey_8_sources'] = {'error': repr(exc)}
+    if rank == 0 and world == 1 and not args.no_survey:
+        torch.cuda.empty_cache()
+        try:
+            out['survey_config5'] = survey_config5(device)
+        except Exception as exc:        # informational block: never takes the bench line down
+            out['survey_config5'] = {'error': repr(exc)}
     if world > 1:
         parallel.finalize()
     if out is not None:

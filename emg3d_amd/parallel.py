@@ -44,7 +44,8 @@ def init(backend=None):
         backend = 'nccl' if use_gpu else 'gloo'
     device = torch.device('cpu')
     if use_gpu and backend == 'nccl':
-        local = int(os.environ.get('LOCAL_RANK', rank % max(torch.cuda.device_count(), 1)))
+        # (more ranks than visible devices -- a dry run of the multi-rank path on a smaller box -- share them)
+        local = int(os.environ.get('LOCAL_RANK', rank)) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         device = torch.device('cuda', local)
     if world > 1 and not dist.is_initialized():

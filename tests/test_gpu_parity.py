@@ -1742,7 +1742,7 @@ def test_line_factor_policy_rebuild_equals_resident(kw):
         assert np.array_equal(e.field, e2.field) and info['it_mg'] == info2['it_mg']
         out[policy] = (e.field.copy(), info)
         nbytes[policy] = factor_bytes(hier.top, set())
-        if policy != 'resident':
+        if policy != 'resident' and kw['linerelaxation'] in (True, 7):
             assert hier.top.factor_rebuilds >= 3
         del hier
     e1, i1 = out['resident']
@@ -1757,6 +1757,51 @@ def test_line_factor_policy_rebuild_equals_resident(kw):
         assert nbytes['single'] < nbytes['rebuild'] <= 0.9 * nbytes['resident'] and nbytes['single'] <= 0.5 * nbytes['resident']
     with pytest.raises(ValueError, match='line_factors'):
         solver.Hierarchy(vmodel, line_factors='sometimes')
+
+
+@pytest.mark.slow
+def test_512_cubed_w_cycle_with_rebuilt_line_factors():
+    """512^3 (134 M cells, 403 M unknowns) on ONE GPU: the tri-axial workload of config 3 at twice its edge length,
+    W-cycle with semicoarsening and line relaxation, hierarchy policy 'rebuild' (two line-factor buffers per level:
+    with all three directions resident the hierarchy would need ~315 GB). One cycle reduces the error
+    by more than an order of magnitude (tools/big_cube.py compared this very cycle with the oracle in the same
+    ordering: 1.1e-12 rel-L2, profiles/r04_big_cube.txt), and the operator on the finest level keeps the
+    size-independent properties of test_full_size_operator_properties: linear, complex symmetric, residual(0) = s."""
+    from bench import workload
+    if torch.cuda.get_device_properties(0).total_memory < 250e9:
+        pytest.skip('needs the 288 GB of an MI355X')
+    wl = workload('triaxial512')
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    assert grid.shape_cells == (512, 512, 512)
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    hier = solver.Hierarchy(emg3d.models.VolumeModel(model, sfield), line_factors='rebuild')
+    _, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-30, maxit=1, return_info=True, hierarchy=hier,
+                          _download=False, **wl['opts'])
+    assert info['it_mg'] == 1 and np.isfinite(info['rel_error']) and info['rel_error'] < 0.05
+    assert hier.top.factor_rebuilds == 2 and len(hier.top._slots) == 2
+    assert torch.cuda.max_memory_allocated() < 200e9
+    lv = hier.top
+    x, y = _rand_field(lv, grid, 2), _rand_field(lv, grid, 3)
+    lv.s.zero_()
+
+    def A(v):
+        lv.e.copy_(v)
+        lv.residual(store=True, norm=False)
+        return -lv.r.clone()
+    ax, ay = A(x), A(y)
+    a, b = 0.7 - 0.2j, -1.3 + 0.5j
+    lin = A(a * x + b * y)
+    assert (torch.linalg.norm(lin - (a * ax + b * ay)) / torch.linalg.norm(lin)).item() < 1e-13
+    xay, yax = torch.sum(x * ay).item(), torch.sum(y * ax).item()
+    assert abs(xay - yax) / abs(xay) < 1e-11
+    lv.s.copy_(x)
+    lv.e.zero_()
+    n = lv.residual(store=True, norm=True)
+    assert torch.equal(lv.r, x)
+    assert n == pytest.approx(torch.linalg.norm(x).item(), rel=1e-13)
+    del hier, lv, x, y, ax, ay, lin
+    torch.cuda.empty_cache()
 
 
 def test_hierarchy_field_follows_a_solve_that_has_nothing_to_do():
@@ -1882,6 +1927,99 @@ def test_device_krylov_matches_scipy_iteration(method, dtype, monkeypatch):
     assert info['it_mg'] == var.it
     assert np.allclose(info['error_at_cycle'], var.error_at_cycle, rtol=1e-6)      # multigrid cycles and Krylov steps
     assert relerr(e.field, x) < 1e-9
+
+
+_TWO_RANK_COMPUTE = r"""
+import os, sys, pickle
+import numpy as np
+import torch, torch.distributed as dist
+root = os.environ['EMG3D_TEST_ROOT']
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
+import emg3d_amd as emg3d
+from emg3d_amd import parallel
+from helpers import widths
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+# the process group exists before the product's code runs (a launcher's job): collectives over gloo, every rank
+# on the box's one GPU -- parallel.init() must join it as it is and still put the solves on cuda:0
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+hx = widths(8, 4, 50., 1.2)
+grid = emg3d.TensorMesh([hx, hx[:12], hx], (-hx.sum() / 2, -330., -hx.sum() / 2))
+model = None
+if rank == 0:
+    rng = np.random.default_rng(5)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells), property_z=10 ** rng.uniform(0, 0.7, grid.shape_cells))
+sources = {f'S{i}': (-160. + 70. * i, 20. * i - 30., 10., 15. * i, 0.) for i in range(5)}
+freqs = {'f1': 1.0, 'f2': 3.0}
+rng = np.random.default_rng(9)
+rec = (rng.uniform(-150, 150, 6), rng.uniform(-100, 100, 6), rng.uniform(-100, 100, 6), 0., 0.)
+opts = {'sslsolver': False, 'tol': 1e-8, 'verb': 0}
+costs = [3., 1., 1., 1., 2., 2., 1., 1., 1., 1.]
+out = parallel.compute(model, grid if rank == 0 else None, sources, freqs, opts, receivers=rec, costs=costs)
+bat = parallel.compute(model, grid if rank == 0 else None, sources, freqs, opts, receivers=rec, costs=costs, batch=2,
+                       keep_fields=False)
+res = {'rank': rank, 'mine': sorted(k for k in out if k != '_all_info'),
+       'fields': {k: out[k][0].field for k in out if k != '_all_info'},
+       'responses': {k: out[k][1]['responses'] for k in out if k != '_all_info'},
+       'it': {k: out[k][1]['it_mg'] for k in out if k != '_all_info'},
+       'batched_responses': {k: bat[k][1]['responses'] for k in bat if k != '_all_info'},
+       'all_info_keys': sorted(out['_all_info']) if rank == 0 else None,
+       'all_responses': {k: v['responses'] for k, v in out['_all_info'].items()} if rank == 0 else None}
+# what broadcast_model leaves behind on a rank that received the model: property arrays in HBM
+m2 = parallel.broadcast_model(model, 0, torch.device('cuda', 0))
+res['device_props'] = {n: (str(t.device), tuple(t.shape)) for n, t in m2.__dict__.get('_device_props', {}).items()}
+res['prop_x_sum'] = float(np.sum(m2.property_x))
+with open(os.path.join(os.environ['EMG3D_TEST_OUT'], f'rank{rank}.pkl'), 'wb') as f:
+    pickle.dump(res, f)
+parallel.finalize()
+"""
+
+
+def test_parallel_compute_two_ranks_real_solves_on_one_gpu(tmp_path):
+    """parallel.compute with TWO ranks and real solves (the multi-GPU path short of RCCL: a gloo process group that
+    exists before the product's code runs, both ranks on this box's one GPU): the model goes from rank 0 to rank 1
+    through broadcast_model (property arrays stay in HBM there), the 10 pairs are shared out by longest-processing-
+    time-first, every pair is solved exactly once, rank 0 gathers every pair's info and responses, and each field
+    and response equals, bit for bit, what a single process computes for that pair; batched pairs (batch = 2)
+    give the same responses."""
+    import pickle
+    import subprocess
+    import sys
+    from emg3d_amd import parallel
+    script = tmp_path / 'two_ranks.py'
+    script.write_text(_TWO_RANK_COMPUTE)
+    env = dict(os.environ, EMG3D_TEST_ROOT=ROOT, EMG3D_TEST_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import socket
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [pickle.load(open(tmp_path / f'rank{k}.pkl', 'rb')) for k in (0, 1)]
+    sources = {f'S{i}': (-160. + 70. * i, 20. * i - 30., 10., 15. * i, 0.) for i in range(5)}
+    freqs = {'f1': 1.0, 'f2': 3.0}
+    pairs = parallel.srcfreq_pairs(sources, freqs)
+    costs = [3., 1., 1., 1., 2., 2., 1., 1., 1., 1.]
+    for k in (0, 1):
+        assert res[k]['mine'] == sorted(pairs[i] for i in parallel.shard(10, k, 2, costs))
+        assert res[k]['device_props'] and all(d == 'cuda:0' for d, _ in res[k]['device_props'].values())
+    assert res[0]['prop_x_sum'] == res[1]['prop_x_sum']
+    assert sorted(res[0]['mine'] + res[1]['mine']) == sorted(pairs) == res[0]['all_info_keys']
+    # the same pairs in this (single) process
+    hx = widths(8, 4, 50., 1.2)
+    grid = emg3d.TensorMesh([hx, hx[:12], hx], (-hx.sum() / 2, -330., -hx.sum() / 2))
+    rng = np.random.default_rng(5)
+    model = emg3d.Model(grid, 10 ** rng.uniform(-0.5, 0.5, grid.shape_cells), property_z=10 ** rng.uniform(0, 0.7, grid.shape_cells))
+    rng = np.random.default_rng(9)
+    rec = (rng.uniform(-150, 150, 6), rng.uniform(-100, 100, 6), rng.uniform(-100, 100, 6), 0., 0.)
+    one = parallel.compute(model, grid, sources, freqs, {'sslsolver': False, 'tol': 1e-8, 'verb': 0}, receivers=rec)
+    for k in (0, 1):
+        for key in res[k]['mine']:
+            assert np.array_equal(res[k]['fields'][key], one[key][0].field), (k, key)
+            assert np.array_equal(res[k]['responses'][key], one[key][1]['responses'])
+            assert np.array_equal(res[k]['batched_responses'][key], one[key][1]['responses'])
+            assert res[k]['it'][key] == one[key][1]['it_mg']
+            assert np.array_equal(res[0]['all_responses'][key], one[key][1]['responses'])
 
 
 @pytest.mark.parametrize('backend', ['gloo', 'nccl'])

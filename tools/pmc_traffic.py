@@ -1,4 +1,4 @@
-"""Turn the two PMC passes of a bench run into profiles/<round>_pmc_traffic.json (round: env PMC_ROUND, default r03).
+"""Turn the two PMC passes of a bench run into profiles/<round>_pmc_traffic.json (round: env PMC_ROUND, default r04).
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/f -o run -- python bench.py ...
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/w -o run -- python bench.py ...
@@ -66,7 +66,7 @@ def main():
         res['k_gs_point_tile'] = {'bytes_per_launch': 2 * fetch[k][1] * 1024 + write.get(k, (0, 0, 0))[1] * 1024,
                                   'kernels': {'k_gs_point_tile': {'read': 2 * fetch[k][1] * 1024, 'write': write.get(k, (0, 0, 0))[1] * 1024,
                                                                   'grid': fetch[k][0], 'launches': fetch[k][2]}}}
-    rnd = os.environ.get('PMC_ROUND', 'r03')
+    rnd = os.environ.get('PMC_ROUND', 'r04')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', f'{rnd}_pmc_traffic.json')
     try:
         with open(path) as f:

@@ -4,7 +4,7 @@
 #   two PMC passes of the same command (separate runs, no trace options combined with --pmc), and
 #   the same three passes over the 256^3 smoother measurement (tools/microbench.py: the north-star
 #   kernel k_gs_point_tile); summaries under gpurun_out/ -- copy what is to be judged to profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 WL=${2:-triaxial256}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -44,7 +44,7 @@ MF=$(ls $O/mf/*counter_collection.csv | head -1); MW=$(ls $O/mw/*counter_collect
 cd $R && python tools/pmc_traffic.py smoothers_256 $MF $MW > $R/gpurun_out/${TAG}_pmc_traffic_smoothers256.log 2>&1
 python tools/pmc_summary.py $MF 16581375 > $R/gpurun_out/${TAG}_pmc_fetch_smoothers256.txt
 python tools/pmc_summary.py $MW 16581375 > $R/gpurun_out/${TAG}_pmc_write_smoothers256.txt
-cp $R/profiles/r03_pmc_traffic.json $R/gpurun_out/${TAG}_pmc_traffic.json 2>/dev/null
+cp $R/profiles/${TAG}_pmc_traffic.json $R/gpurun_out/${TAG}_pmc_traffic.json 2>/dev/null
 cat $O/mtrace.log | grep -E "gauss|residual"
 rm -rf $O/trace $O/mtrace $O/f $O/w $O/mf $O/mw   # raw traces stay on the box: gpurun_out is capped at 64 MiB
 head -30 $R/gpurun_out/${TAG}_${WL}_kernel_stats.txt; tail -5 $R/gpurun_out/${TAG}_pmc_traffic_$WL.log
