@@ -198,6 +198,13 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None):
     entry = cache.get(key)
     if entry is None or entry['graph'] is None:
         if entry is None:
+            # graphs captured under other option values will not be replayed again (the options select kernels
+            # and buffers): drop them, and with them the option-dependent factor buffers they kept alive
+            stale = [k for k in cache if k[-1] != key[-1]]
+            if stale:
+                for k in stale:
+                    del cache[k]
+                _drop_stale_point_factors(clv)
             entry = cache[key] = {'work': None, 'graph': None, 'seen': 0}
         if entry['seen'] < GRAPH_AFTER:
             before = var.smoother_cell_sweeps
@@ -216,6 +223,20 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None):
         entry['graph'] = graph
     entry['graph'].replay()
     var.smoother_cell_sweeps += entry['work']
+
+
+def _drop_stale_point_factors(lv, seen=None):
+    """The eta-sum buffers of the point smoother are kept per value of the option point_tile_min
+    (DeviceLevel.point_factors); once no graph of another option set is left, only the current value's are."""
+    seen = set() if seen is None else seen
+    if id(lv) in seen:
+        return
+    seen.add(id(lv))
+    now = ('point', _lib.lib().emg3d_get_option(b'point_tile_min'))
+    for k in [k for k in lv._factors if isinstance(k, tuple) and k[0] == 'point' and k != now]:
+        del lv._factors[k]
+    for link in lv.children.values():
+        _drop_stale_point_factors(link['level'], seen)
 
 
 # ------------------------------------------------------------------ termination ---------
@@ -319,18 +340,24 @@ def run_cycles(top, var):
     while True:
         l2_prev = l2_last
         ring[(it - 1) % var.maxcycle] = l2_last
-        if resform:
-            top.to_residual_equation()
+        entered = False
         try:
+            if resform:
+                top.to_residual_equation()
+                entered = True
             _one_cycle(top, var, it, loud)
+            if resform:
+                top.from_residual_equation()
+                entered = False
         except BaseException:
-            if resform:        # (e, s) hold (d, r): give the caller's field and source back before unwinding
-                top.abandon_residual_equation()
+            if entered:        # (e, s) hold (d, r): give the caller's field and source back before unwinding
+                try:
+                    top.abandon_residual_equation()
+                except Exception:      # (a HIP error took the cycle down: the copies fail too -- the first error counts)
+                    pass
             raise
         it += 1
         var.it += 1
-        if resform:
-            top.from_residual_equation()
         l2_last = top.residual(store=resform, norm=True)
         record_cycle(var, l2_last, l2_prev)
         if var.sc_cycle:
@@ -345,7 +372,7 @@ def run_cycles(top, var):
         reason = stop_reason(var, l2_last, l2_stag, it)
         if (reason is not None and reason[0] == "STAGNATED" and it < var.maxit and l2_last < 1e-3 * var.l2_refe and
                 not resform and top.batch == 1 and
-                not var.sslsolver and getattr(var, 'residual_form_auto', False)):
+                not var.sslsolver and getattr(var, 'residual_form_auto', False) and _can_switch(top)):
             # The direct form has stalled above the tolerance: the floor of the line smoothers' stored
             # block inverses (or of the point smoother's pivots) on this model lies higher than the 'auto'
             # rule of solver._residual_form predicted. The reference's banded LDL^T would go on converging;
@@ -361,6 +388,16 @@ def run_cycles(top, var):
         if terminate(var, l2_last, l2_stag, it):
             break
     var.l2 = l2_last
+
+
+def _can_switch(top):
+    """The residual form needs two more field-sized buffers on the finest level: reserved here, before the
+    switch; without the memory for them the solve ends as it would have without the switch (STAGNATED)."""
+    try:
+        top.reserve_residual_equation()
+    except torch.cuda.OutOfMemoryError:
+        return False
+    return True
 
 
 def _one_cycle(top, var, it, loud):

@@ -308,13 +308,19 @@ class DeviceLevel:
             _ptr(w.ws), _ptr(w.ws), w.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
 
     # ---- finest level in residual form (_cycle.run_cycles): the cycle works on A d = r from d = 0
+    def reserve_residual_equation(self):
+        """The two field-sized buffers of the residual form (allocated on first use; a caller that switches
+        to it in the middle of a solve reserves them first and stays in direct form if HBM is short)."""
+        if self.__dict__.get('_x_kept') is None:
+            self._x_kept, self._b_kept = torch.empty_like(self.e), torch.empty_like(self.s)
+            self._b_valid = False
+        _ = self.r
+
     def to_residual_equation(self):
         """Before a cycle: r = s - A e is in ``self.r`` (residual(store=True)). Keeps e and s aside,
         then s <- r, e <- 0."""
         nbytes = self.e.numel() * self.e.element_size()
-        if self.__dict__.get('_x_kept') is None:
-            self._x_kept, self._b_kept = torch.empty_like(self.e), torch.empty_like(self.s)
-            self._b_valid = False
+        self.reserve_residual_equation()
         cp = _lib.lib().emg3d_dev_copy
         _lib.check(cp(_ptr(self._x_kept), _ptr(self.e), nbytes, _stream()), 'emg3d_dev_copy')
         if not self._b_valid:                     # the source of a solve does not change between its cycles

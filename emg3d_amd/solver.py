@@ -417,7 +417,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
             svar.sc_dir = next(svar.sc_cycle)
         if svar.lr_cycle:
             svar.lr_dir = next(svar.lr_cycle)
-        switch = False
+        switch, stalled = False, []
         for b, v in enumerate(vars_):
             if not active[b]:
                 continue
@@ -433,6 +433,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
                 reason = _cycle.stop_reason(v, float(l2_last[b]), stag, it)
                 if reason is not None and reason[0] == "STAGNATED" and l2_last[b] < 1e-3 * v.l2_refe:
                     switch = True
+                    stalled.append(b)
                     continue
             try:
                 finished = _terminate(v, float(l2_last[b]), stag, it)
@@ -443,10 +444,16 @@ def _multigrid_batch(lv, svar, vars_, active=None):
                 v.l2 = float(l2_last[b])
                 done[b] = lv.e[b * n:(b + 1) * n].clone()
         if switch and any(active):
+            # From the next cycle on the WHOLE batch cycles on the residual equation (one set of launches serves
+            # all right-hand sides): after a switch a source's arithmetic depends on its batch-mates -- every
+            # source still active records it (info['residual_form'] == 'switched'); until then fields, counts
+            # and histories are those of separate solves. Stagnation is judged afresh only for the sources that
+            # stalled; the others keep their histories (a source that truly stagnates is still caught on time).
             resform = svar.residual_form = True
             lv._b_valid = False
             lv.residual(store=True, norm=False)
-            l2_stag[:] = np.inf
+            for b in stalled:
+                l2_stag[b, :] = np.inf
             for b, v in enumerate(vars_):
                 if active[b]:
                     v.residual_form_switched = True

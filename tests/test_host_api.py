@@ -436,6 +436,9 @@ def test_stall_switch_control_flow_without_a_gpu(auto, monkeypatch):
             self.calls.append(('residual', store, norm))
             return next(self.norms) if norm else None
 
+        def reserve_residual_equation(self):          # (the two extra buffers, reserved before the switch)
+            self.calls.append('reserve')
+
         def to_residual_equation(self):
             self.calls.append('to')
 
@@ -459,4 +462,5 @@ def test_stall_switch_control_flow_without_a_gpu(auto, monkeypatch):
     assert top.calls.count('cycle') == 6 and top.calls.count('to') == top.calls.count('from') == 2
     first_to = top.calls.index('to')
     assert top.calls[first_to - 1] == ('residual', True, False) and top.calls[:first_to].count('cycle') == 4
+    assert top.calls.index('reserve') < first_to
     assert top._b_valid is False
