@@ -373,9 +373,9 @@ def survey_config5(device, name='salt384'):
     return out
 
 
-# Cycles to tol 1e-6 of config 5's pairs by frequency (0.25 / 0.5 / 1 / 2 Hz; bench.py's `survey_config5`
-# measures them): the cost estimates a multi-rank run hands to parallel.shard (longest-processing-time first)
-PAIR_COSTS = {'salt384': [c for c in (9, 9, 9, 9) for _ in range(2)]}
+# Cycles to tol 1e-6 of config 5's pairs by frequency (0.25 / 0.5 / 1 / 2 Hz: 9 / 7 / 5 / 4, measured by
+# `survey_config5`, profiles/r04_bench_triaxial256.json): the cost estimates a multi-rank run hands to parallel.shard (longest-processing-time first)
+PAIR_COSTS = {'salt384': [c for c in (9, 7, 5, 4) for _ in range(2)]}
 
 REDUCED_COPY = {'triaxial256': 'triaxial64', 'marine128': 'marine64', 'salt384': 'salt96'}
 
