@@ -334,7 +334,7 @@ def survey_config5(device, name='salt384'):
     """BASELINE.json config 5 on ONE GPU: 4 frequencies x 2 sources on the 384 x 256 x 256 salt-like model as whole
     solves to tol 1e-6. Sources of one frequency share the model, hence every level's line factorisation: the two
     sources of a frequency are solved TOGETHER (solver.solve_batch; on the levels with long lines one workgroup
-    serves its lines for both right-hand sides per factor fetch, k_line_stream_b) -- against one after the other
+    serves its lines for both right-hand sides per factor fetch, k_line_stream) -- against one after the other
     on a hierarchy they share (what `parallel.compute(reuse=True)` does). Fields are bit-identical either way."""
     import torch
     import emg3d_amd as emg3d

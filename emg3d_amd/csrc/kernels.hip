@@ -95,10 +95,9 @@ int g_point_small = 512;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
 // the largest levels (records of 16 lines do not fit in LDS even without their fifth slot: lines of
-// ~160 blocks and more): k_line_stream -- right-hand sides produced into an LDS ring by the helper
-// waves while the chain waves substitute (1, default); 0: k_line_colour everywhere; 2: k_line_stream
-// also where slots 0..3 would fit (~128-block lines: measured equal); 3 / 4: like 1 / 2 with the single
-// source run as a group of one of k_line_stream_b (the w records staged through LDS in the backward pass)
+// ~160 blocks and more): k_line_stream -- right-hand sides and w records staged through an LDS ring by
+// producer waves while the chain waves substitute (1, default); 0: k_line_colour everywhere; 2: k_line_stream
+// also where slots 0..3 would fit (~128-block lines: measured equal)
 int g_line_stream = 1;
 // sequence of the colour passes of the LINE smoothers (launch.h: line_sweep_colour): 1 (default) cyclic
 // 1,2,3,0,1,...; 0 mirrored sweeps (0,2,3,1 forward / its reverse backward: rounds 1-2); 2 the classes
@@ -108,7 +107,7 @@ int g_line_stream = 1;
 int g_line_order = 1;
 int g_line_stream_r = 0;           // rows per chunk of the ring (0: 16)
 // several right-hand sides (emg3d_level::batch > 1): levels whose colour passes would keep their records in
-// the global scratch and whose lines have at least this many blocks run k_line_stream_b -- groups of up
+// the global scratch and whose lines have at least this many blocks run k_line_stream -- groups of up
 // to four right-hand sides per workgroup, the factors fetched once per group (<= 0: never)
 int g_line_stream_bmin = 64;
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
@@ -1013,25 +1012,41 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
     else quad_backward<T, DIR, 1, QD, BATCH, SPLIT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
-// ---- fused colour pass with STREAMED right-hand sides (the largest levels) ---------------------
+// ---- fused colour pass with STREAMED records (the largest levels): k_line_stream -----------------
 // k_line_colour runs right-hand sides, forward and backward substitution one after the other, and
 // on the levels whose records do not fit the LDS of a CU the right-hand sides make a round trip
 // through the global scratch (written by the first phase, read by the second: 160 B per block of
-// the pass's ~1450). Here four producer waves PRODUCE the right-hand sides of the
+// the pass's ~1450). Here six producer waves PRODUCE the right-hand sides of the
 // next R block rows into an LDS ring while the two chain waves CONSUME the current R rows in their
 // forward half-chains: the right-hand sides never leave the CU, and their assembly (a bandwidth
-// phase) overlaps the forward substitution (a latency chain). Same arithmetic, entry by entry, as
-// k_line_colour (stencil.h: line_rhs_e0 / line_rhs_t, quad_forward_step): bit-identical results.
+// phase) overlaps the forward substitution (a latency chain). In the backward pass the producers
+// copy the w records of the next R steps into the same ring (wide coalesced loads by otherwise idle
+// waves; the chain quads keep no register ring for them). Same arithmetic, entry by entry, as
+// k_line_colour (stencil.h: line_rhs_e0 / line_rhs_t, quad_forward_step, quad_backward_step):
+// bit-identical results.
 //
-// LDS: ring [2 buffers][2 halves][R rows][lpw lines][5 entries] -- item (half, step i) holds the five
-// right-hand-side entries of the block that half's chain works on at step i, already in the
-// chain's grouping (bottom half = mirrored blocks: entry 0 of record row k, entries 1..4 of row
-// k - 1). The w / solution records stay in the global scratch (with them in LDS only 8 lines of 256
-// blocks fit a workgroup, and half-filled chain waves cost more than the bytes save: measured).
-// Four producer waves: with two the producers, one memory round trip per item, are what the
-// chains wait for. One workgroup barrier (LDS-only: the chains' factor prefetch stays in flight)
-// per R = 16 steps. The producers also put the raw right-hand sides of the rows the middle block
-// reads (row m, and entry 0 of row m + 1) into the records.
+// The same workgroup can serve its 16 lines for a GROUP of B <= 4 right-hand sides that share the
+// factors -- the sources of one frequency (emg3d/simulations.py:1453-1464): a chain quad holds the
+// factor row of a block in registers once and applies it to the B right-hand sides (B independent
+// dependency chains: their instructions interleave), the producers fill B rings. With the batch as a
+// grid dimension (k_line_colour<BATCH>) every source's workgroups stream the 2 x 304 B of factors per
+// block again -- 47 % of the bytes of a level-0 colour pass, and PMC shows no merging in L2 (12-13 GB
+// per launch of two sources against 5.2-5.6 GB for one). Measured at 256^3 (profiles/r04_batch_lines_*):
+// 0.73-0.76 x the single-source time per source for B = 2, 0.69-0.75 x for B = 4.
+//
+// LDS: ring [2 buffers][B][2 halves][R rows][16 lines][5 entries] -- item (source, half, step i) holds
+// the five right-hand-side (forward) / w (backward) entries of the block that half's chain works on
+// at step i, already in the chain's grouping (bottom half = mirrored blocks: entry 0 of record row k,
+// entries 1..4 of row k - 1). R = 16 for B <= 2, 8 for B = 3, 4 (160 KB). The w / solution records
+// live in the global scratch (with them in LDS only 8 lines of 256 blocks fit a workgroup, and half-
+// filled chain waves cost more than the bytes save: measured). Six producer waves: the kernel is held
+// to 256 registers by its chain waves' SIMD partners anyway, so two more than the four that one source
+// needs cost nothing and keep more loads in flight (y / z lines of one source: -4...-6 %). One
+// workgroup barrier (LDS-only: the chains' factor prefetch stays in flight) per R steps. The producers
+// also put the raw right-hand sides of the rows the middle block reads (row m, and entry 0 of row
+// m + 1) into the records.
+//   RD : depth of the factor prefetch ring in the chain waves (4 for one source; 2 for B >= 2: a step
+//        of B sources takes B times as long, so two steps ahead is as far ahead in time).
 template <class T, int DIR>
 __device__ __forceinline__ void stream_produce(const emg::Axes<T, DIR> &A, int colour, int cntp, int cntq, int n0p,
                                                int line0, int nl, int lpw, T *buf, int R, int chunk, int pt, int np)
@@ -1061,123 +1076,11 @@ __device__ __forceinline__ void stream_produce(const emg::Axes<T, DIR> &A, int c
     }
 }
 
-// forward half-chain that takes its right-hand sides from the LDS ring (see k_line_stream)
-template <class T, int HALF, int QD>
-__device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
-                                                    const T *fac, const double *lfac, const VecRef<T> V, T *dummy,
-                                                    T *dummy4, const T *ringbase, int lpw, int R, int nchunks)
-{
-    const HalfWalk<HALF> W(n0, n0p);
-    const bool active = qline < qend;
-    const int line = min(qline, qend - 1);
-    const int ll = line - line0;
-    T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
-    T *const dslot4 = dummy4 + ((threadIdx.x & 63) >> 2) * 5;
-    QuadRow<T> ring[QD];
-    const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
-    auto fetch = [&](QuadRow<T> &q, int i) { q.template load<LaneAddr<T, HALF, false>, false>(LA, W.fwd(W.clampi(i))); };
-#pragma unroll
-    for (int d = 0; d < QD; ++d) fetch(ring[d], d);
-    __syncthreads();                                          // chunk 0 of the ring and the middle rows are there
-    T wsel = emg::zero<T>(), w4p = emg::zero<T>();
-    const double nz = j != 0 ? 1.0 : 0.0, is0 = 1.0 - nz;
-    const size_t bufelems = (size_t)2 * R * lpw * 5;
-    for (int c = 0; c < nchunks; ++c) {
-        const T *const items = ringbase + (size_t)(c & 1) * bufelems + ((size_t)(HALF * R) * lpw + ll) * 5;
-        const int iend = min((c + 1) * R, W.steps);
-        for (int i0 = c * R; i0 < iend; i0 += QD) {
-#pragma unroll
-            for (int d = 0; d < QD; ++d) {
-                const int k = W.fwd(i0 + d);
-                const QuadRow<T> &q = ring[d];
-                const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
-                const T v = it[j], v4 = it[4];
-                T wn, w4;
-                quad_forward_step(q, v, v4, nz, is0, wsel, w4p, wn, w4);
-                T *const o4 = active ? LA.pv4(k) : dslot4 + 4;
-                T *const oj = active ? LA.pvj(k) : dslot + j;
-                *oj = wn;
-                *o4 = w4;
-                fetch(ring[d], i0 + d + QD);
-            }
-        }
-        lds_barrier();                                        // this chunk is consumed, the next one produced
-    }
-}
+constexpr int LS_PROD = 384;                 // producer threads of k_line_stream (6 waves; + 2 chain waves)
 
-constexpr int LS_PROD = 256;                 // producer threads of k_line_stream (4 waves; + 2 chain waves)
-// (Measured, not adopted: the same kernel with the records in LDS behind the ring on the levels whose
-// records fit -- 64-block lines: 0.350 -> 0.376 ms per call, the cycle 0.5 % slower: there the right-
-// hand sides are a 4 us phase, and six waves with 256 registers walk the chains slower than four
-// with 276.)
-template <class T, int DIR, int QD = emg::LINE_PAD>
-__global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                                  int lpw, int R, const T *fac, const double *lfac,
-                                                                  T *vec, T *dummy)
-{
-    extern __shared__ double2 ls_smem[];
-    const emg::Axes<T, DIR> A(L);
-    const int n0 = A.n0();
-    const int nlines = cntp * cntq;
-    const int line0 = blockIdx.x * lpw;
-    const int nl = min(lpw, nlines - line0);
-    T *const ringbase = reinterpret_cast<T *>(ls_smem);
-    const size_t bufelems = (size_t)2 * R * lpw * 5;
-    const VecRef<T> V = VecRef<T>::global(vec, nlines);
-    T *const dum = dummy;
-    const int mk = emg::line_mid(n0);
-    const int smax = max(mk, n0p - 2 - mk);
-    const int nchunks = (smax + R - 1) / R;
-    const int wave = threadIdx.x >> 6;
-    if (wave >= 2) {
-        // ---- producers
-        const int pt = threadIdx.x - 128;
-        for (int ll = pt; ll < nl; ll += LS_PROD) {
-            const int lid = line0 + ll;
-            int i1, i2, l2;
-            emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
-            T rhs[5];
-            emg::line_rhs<T, DIR>(A, mk, i1, i2, rhs);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *V.p(mk, lid, r) = rhs[r];
-            *V.p4(mk, lid) = rhs[4];
-            *V.p(mk + 1, lid, 0) = emg::line_rhs_e0<T, DIR>(A, min(mk + 1, n0 - 1), i1, i2);
-        }
-        stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase, R, 0, pt, LS_PROD);
-        __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            if (c + 1 < nchunks)
-                stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + (size_t)((c + 1) & 1) * bufelems, R,
-                                       c + 1, pt, LS_PROD);
-            lds_barrier();
-        }
-        return;
-    }
-    const int half = wave & 1;
-    const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
-    const int qend = line0 + nl;
-    if (half == 0) quad_forward_stream<T, 0, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dum, dum, ringbase, lpw, R, nchunks);
-    else quad_forward_stream<T, 1, QD>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, V, dum, dum, ringbase, lpw, R, nchunks);
-    __syncthreads();
-    // (six waves share four SIMDs: 256 registers per lane -- the middle block is solved before the
-    // backward pass's register ring is filled, as in the batched k_line_colour)
-    if (half == 0) quad_backward<T, DIR, 0, QD, true, false>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, 0);
-    else quad_backward<T, DIR, 1, QD, true, false>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, 0);
-}
-
-// ---- the streamed colour pass for SEVERAL right-hand sides that share the factors -------------------
-// Sources of one frequency share the model, hence the line factorisations (emg3d/simulations.py:
-// 1453-1464: one frequency, many sources). With the batch as a grid dimension every source's
-// workgroups stream the 2 x 304 B of factors per block again -- 47 % of the bytes of a level-0 colour
-// pass. Here ONE workgroup serves its 16 lines for a group of B <= 4 right-hand sides: a chain quad
-// holds the factor row of a block in registers once and applies it to the B right-hand sides (B
-// independent dependency chains: their instructions interleave), the producer waves fill B rings. Per
-// source the arithmetic is that of k_line_stream / k_line_colour, entry by entry: bit-identical.
-//   LDS: ring [2 buffers][B][2 halves][R rows][16 lines][5 entries]; R = 16 for B <= 2, 8 for B = 3, 4.
-//   RD : depth of the factor prefetch ring in the chain waves (2 for B >= 2: a step of B sources takes
-//        B times as long, so two steps ahead is as far ahead in time as four were for one source).
+// forward half-chain that takes its right-hand sides from the LDS ring, for B right-hand sides
 template <class T, int HALF, int RD, int B>
-__device__ __forceinline__ void quad_forward_stream_b(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
+__device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
                                                       const T *fac, const double *lfac, T *vec, size_t vstride,
                                                       const T *ringbase, int lpw, int R, int nchunks)
 {
@@ -1254,7 +1157,7 @@ __device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n
 // backward substitution of one half for B right-hand sides (quad_backward, MIDFIRST form, per source);
 // the w records come from the LDS ring (stream_produce_w)
 template <class T, int DIR, int HALF, int RD, int B>
-__device__ __forceinline__ void quad_backward_b(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p, int qline,
+__device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p, int qline,
                                                 int qend, int line0, int j, const T *fac, const double *lfac, T *vec,
                                                 size_t vstride, size_t boff0, const T *ringbase, int lpw, int R,
                                                 int nchunks)
@@ -1320,6 +1223,10 @@ __device__ __forceinline__ void quad_backward_b(const emg::Level<T> &L, int colo
     const long incj = active ? (HALF ? sj : -sj) : 0, inc4 = active ? (HALF ? s4 : -s4) : 0;
     const double nz = j != 0 ? 1.0 : 0.0;
     const size_t srcelems = (size_t)2 * R * lpw * 5, bufelems = (size_t)B * srcelems;
+    constexpr bool PAIRED = DIR == 0 && RD % 2 == 0;          // (steps come in pairs: W.steps is a multiple of 4)
+    T hold_j[B], hold_4[B];
+    T *hold_oj = dj, *hold_o4 = d4;
+    size_t hold_step = 0;
     for (int c = 0; c < nchunks; ++c) {
         const T *const items = ringbase + (size_t)(c & 1) * bufelems + ((size_t)(HALF * R) * lpw + ll) * 5;
         const int iend = min((c + 1) * R, W.steps);
@@ -1338,9 +1245,25 @@ __device__ __forceinline__ void quad_backward_b(const emg::Level<T> &L, int colo
                     const T wj = it[b * srcelems + j], w4 = it[b * srcelems + 4];
                     T xn, xn4;
                     quad_backward_step(q, wj, w4, nz, upA, upD, up04, up44, x0[b], x4[b], xmine[b], xn, xn4);
-                    oj[b * ostep] = xn;
-                    o4[b * ostep] = xn4;
+                    if (PAIRED && (d & 1) == 0) {
+                        // x-lines: a lane's results of consecutive blocks are neighbours in memory (16 B each).
+                        // Stored step by step a 128-B line is touched eight times, ~1.2 us apart with four
+                        // right-hand sides, and the open lines of an XCD's 32 workgroups (5000 each) overflow its
+                        // L2: every piece goes to HBM as its own sector write (PMC: 1.27 GB written per
+                        // source-launch against 0.79 GB for one source). The even step of a pair is held and
+                        // stored together with the odd one: 32 contiguous bytes at a time.
+                        hold_j[b] = xn; hold_4[b] = xn4;
+                    } else if (PAIRED) {
+                        hold_oj[b * hold_step] = hold_j[b];
+                        oj[b * ostep] = xn;
+                        hold_o4[b * hold_step] = hold_4[b];
+                        o4[b * ostep] = xn4;
+                    } else {
+                        oj[b * ostep] = xn;
+                        o4[b * ostep] = xn4;
+                    }
                 }
+                if (PAIRED && (d & 1) == 0) { hold_oj = oj; hold_o4 = o4; hold_step = ostep; }
                 upA = q.bA; upD = q.bD; up04 = q.b04; up44 = q.d4;
                 pej += incj;
                 pe4 += inc4;
@@ -1351,18 +1274,20 @@ __device__ __forceinline__ void quad_backward_b(const emg::Level<T> &L, int colo
     }
 }
 
-template <class T, int DIR, int B, int RD>
-__global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+// NPROD: producer threads (four waves for a single source; six for groups -- with the kernel held to 256
+// registers by its six waves anyway, two more producer waves cost nothing and keep more loads in flight)
+template <class T, int DIR, int B, int RD, int NPROD>
+__global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                                     int lpw, int R, const T *fac, const double *lfac,
                                                                     T *vec, size_t vstride, size_t boff0)
 {
     // vec: the scratch of the group's first right-hand side (source b's: b * vstride behind it);
     // boff0: element offset of the group's first source in the field / source buffers
-    extern __shared__ double2 lsb_smem[];
+    extern __shared__ double2 ls_smem[];
     const int nlines = cntp * cntq;
     const int line0 = blockIdx.x * lpw;
     const int nl = min(lpw, nlines - line0);
-    T *const ringbase = reinterpret_cast<T *>(lsb_smem);
+    T *const ringbase = reinterpret_cast<T *>(ls_smem);
     const size_t srcelems = (size_t)2 * R * lpw * 5, bufelems = (size_t)B * srcelems;
     const int n0 = DIR == 0 ? L.nx : DIR == 1 ? L.ny : L.nz;
     const int mk = emg::line_mid(n0);
@@ -1376,7 +1301,7 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T
         for (int b = 0; b < B; ++b) {
             const emg::Axes<T, DIR> A(L, boff0 + b * L.bstride);
             const VecRef<T> V = VecRef<T>::global(vec + b * vstride, nlines);
-            for (int ll = pt; ll < nl; ll += LS_PROD) {
+            for (int ll = pt; ll < nl; ll += NPROD) {
                 const int lid = line0 + ll;
                 int i1, i2, l2;
                 emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
@@ -1387,7 +1312,7 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T
                 *V.p4(mk, lid) = rhs[4];
                 *V.p(mk + 1, lid, 0) = emg::line_rhs_e0<T, DIR>(A, min(mk + 1, n0 - 1), i1, i2);
             }
-            stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, LS_PROD);
+            stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD);
         }
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
@@ -1396,7 +1321,7 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T
                 for (int b = 0; b < B; ++b) {
                     const emg::Axes<T, DIR> A(L, boff0 + b * L.bstride);
                     stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw,
-                                           ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, LS_PROD);
+                                           ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD);
                 }
             }
             lds_barrier();
@@ -1404,14 +1329,14 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T
         __syncthreads();                                      // the forward chains are done: all w records are written
 #pragma unroll 1
         for (int b = 0; b < B; ++b)
-            stream_produce_w<T>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, LS_PROD);
+            stream_produce_w<T>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD);
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
             if (c + 1 < nchunks) {
 #pragma unroll 1
                 for (int b = 0; b < B; ++b)
                     stream_produce_w<T>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
-                                        ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, LS_PROD);
+                                        ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD);
             }
             lds_barrier();
         }
@@ -1421,13 +1346,13 @@ __global__ __launch_bounds__(128 + LS_PROD, 1) void k_line_stream_b(emg::Level<T
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
 #ifndef LSB_NO_FWD
-    if (half == 0) quad_forward_stream_b<T, 0, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
-    else quad_forward_stream_b<T, 1, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
+    if (half == 0) quad_forward_stream<T, 0, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
+    else quad_forward_stream<T, 1, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
 #endif
     __syncthreads();
 #ifndef LSB_NO_BWD
-    if (half == 0) quad_backward_b<T, DIR, 0, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
-    else quad_backward_b<T, DIR, 1, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
+    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
+    else quad_backward_stream<T, DIR, 1, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
 #endif
 }
 
@@ -1548,17 +1473,17 @@ __global__ void k_blocks_to_amat(T *amat, T *bvec, const T *middle, const double
 // How one colour pass of a line direction is launched (decided by line_plan, executed by
 // launch_line_colour; exported through emg3d_line_kernel_name so that callers -- bench.py, the tests --
 // name the kernel that runs instead of re-deriving the rule).
-enum LineKind { LK_SEPARATE = 0, LK_COLOUR = 1, LK_STREAM = 2, LK_STREAM_B = 3 };
+enum LineKind { LK_SEPARATE = 0, LK_COLOUR = 1, LK_STREAM = 3 };
 struct LinePlan {
     int kind;        // LineKind
     int vmode;       // LK_COLOUR: where the records live (k_line_colour's VMODE 0..3)
     int lpw;         // lines per workgroup
-    int R;           // LK_STREAM / LK_STREAM_B: rows per chunk of the right-hand-side ring
+    int R;           // LK_STREAM / LK_STREAM: rows per chunk of the right-hand-side ring
     size_t smem;     // dynamic LDS of the launch
     bool shortl;     // the records were laid out with the short granule (lines of <= LINE_SHORT blocks)
     bool batchk;     // LK_COLOUR: the instantiation with the batch as a grid dimension
 };
-// largest group of right-hand sides one k_line_stream_b workgroup serves (its chain quads hold a factor
+// largest group of right-hand sides one k_line_stream workgroup serves (its chain quads hold a factor
 // row once and apply it to all of them)
 constexpr int LSB_MAX = 4;
 // rows per chunk of the ring of a group of g right-hand sides: 2 buffers x g x 2 halves x R x 16 lines x
@@ -1601,28 +1526,23 @@ template <class T> LinePlan line_plan(const emg::LineClass &lc, int batch)
     const size_t smem2 = rec_bytes(lpw, 4);
     P.batchk = batch > 1 || g_line_occ2;
     const bool streamable = g_line_stream && !P.shortl && !g_line_occ2 && !(g_line_debug & 1) && lpw <= 16 && !fits(smem1) &&
-                            (!fits(smem2) || g_line_stream == 2 || g_line_stream == 4);
+                            (!fits(smem2) || g_line_stream >= 2);
     // the largest levels of a single-source solve: right-hand sides streamed through LDS
     // (where slots 0..3 of the records fit in LDS -- 128-block lines -- k_line_colour's mode 2 is as fast:
     // 11.34 against 11.40 ms per config-2 cycle, 1.80-1.91 against 1.82-1.88 ms per call at 256 x 128 x 128).
     // (k_line_stream has two chain waves = 16 lines per workgroup at most: with line_lpw = 32 the launch
     // stays with k_line_colour, whose waves 2 / 3 walk lines 16..31; the ring must fit the LDS of a CU)
-    if (streamable && batch == 1 && lc.n0 >= 16 && g_line_stream >= 3 && lpw == 16) {
-        P.kind = LK_STREAM_B;      // (line_stream = 3 / 4: the single source as a group of one -- w records staged too)
+    if (streamable && batch == 1 && lc.n0 >= 16) {
+        P.kind = LK_STREAM;      // (a single source: a group of one)
         return P;
     }
-    if (streamable && batch == 1 && lc.n0 >= 16) {
-        const int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
-        const size_t smem = (size_t)2 * 2 * R * lpw * 5 * sizeof(T);
-        if (smem <= lds_cu) { P.kind = LK_STREAM; P.R = R; P.smem = smem; return P; }
-    }
     // several right-hand sides on such a level: groups of up to LSB_MAX of them per workgroup, the
-    // factors fetched once per group (k_line_stream_b)
+    // factors fetched once per group (k_line_stream)
     // (also where slots 0..3 of the records of ONE source would fit in LDS: with the batch as a grid dimension
     // those launches fetch the factors once per source)
     const bool streamable_b = g_line_stream && !P.shortl && !g_line_occ2 && !(g_line_debug & 1) && lpw == 16 && !fits(smem1);
     if (streamable_b && batch > 1 && g_line_stream_bmin > 0 && lc.n0 >= g_line_stream_bmin) {
-        P.kind = LK_STREAM_B;
+        P.kind = LK_STREAM;
         return P;
     }
     if (P.shortl) {              // (records of <= 6 blocks: a few KB, they fit whenever LDS records are on)
@@ -1640,19 +1560,19 @@ template <class T> LinePlan line_plan(const emg::LineClass &lc, int batch)
 
 template <class T, int DIR, int B>
 void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const T *f, const double *lf, T *vec,
-                         size_t vstride, int b0, hipStream_t st)
+                         size_t vstride, int b0, int lpw, hipStream_t st)
 {
-    const int lpw = 16;
     int R = stream_rows(B, sizeof(T));
     const size_t smem = (size_t)2 * B * 2 * R * lpw * 5 * sizeof(T);
-    const void *kern = (const void *)&k_line_stream_b<T, DIR, B, (B >= 2 ? 2 : emg::LINE_PAD)>;
+    constexpr int NPROD = LS_PROD;
+    const void *kern = (const void *)&k_line_stream<T, DIR, B, (B >= 2 ? 2 : emg::LINE_PAD), NPROD>;
     (void)allow_lds(kern, 160 * 1024);
     T *v0 = vec + (size_t)b0 * vstride;
     size_t boff0 = (size_t)b0 * L.bstride;
     const unsigned nwg = cdiv(lc.lines, lpw);
     void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
                     (void *)&f, (void *)&lf, (void *)&v0, (void *)&vstride, (void *)&boff0};
-    (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + LS_PROD), args, smem, st);
+    (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + NPROD), args, smem, st);
 }
 
 template <class T, int DIR>
@@ -1671,25 +1591,15 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const size_t dummy_off = vstride - emg::LINE_DUMMY;
     const LinePlan P = line_plan<T>(lc, L.batch);
     if (P.kind == LK_STREAM) {
-        const int lpw = P.lpw, R = P.R;
-        const void *kern = (const void *)&k_line_stream<T, DIR, emg::LINE_PAD>;
-        (void)allow_lds(kern, 160 * 1024);
-        T *dummyp = vec + dummy_off;
-        void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
-                        (void *)&f, (void *)&lf, (void *)&vec, (void *)&dummyp};
-        (void)hipLaunchKernel(kern, dim3(cdiv(lc.lines, lpw)), dim3(128 + LS_PROD), args, P.smem, st);
-        return;
-    }
-    if (P.kind == LK_STREAM_B) {
         // groups of at most LSB_MAX right-hand sides, as even as possible (8 -> 4 + 4, 6 -> 3 + 3, 5 -> 3 + 2)
         const int ng = cdiv(L.batch, LSB_MAX);
         int b0 = 0;
         for (int g = 0; g < ng; ++g) {
             const int gs = L.batch / ng + (g < L.batch % ng ? 1 : 0);
-            if (gs == 4) launch_stream_group<T, DIR, 4>(L, c, lc, f, lf, vec, vstride, b0, st);
-            else if (gs == 3) launch_stream_group<T, DIR, 3>(L, c, lc, f, lf, vec, vstride, b0, st);
-            else if (gs == 2) launch_stream_group<T, DIR, 2>(L, c, lc, f, lf, vec, vstride, b0, st);
-            else launch_stream_group<T, DIR, 1>(L, c, lc, f, lf, vec, vstride, b0, st);
+            if (gs == 4) launch_stream_group<T, DIR, 4>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
+            else if (gs == 3) launch_stream_group<T, DIR, 3>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
+            else if (gs == 2) launch_stream_group<T, DIR, 2>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
+            else launch_stream_group<T, DIR, 1>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
             b0 += gs;
         }
         return;
@@ -2078,7 +1988,6 @@ const char *emg3d_line_kernel_name(int lr, int nx, int ny, int nz, int is_comple
     const LinePlan P = is_complex ? line_plan<cplx>(lc, batch > 1 ? batch : 1) : line_plan<double>(lc, batch > 1 ? batch : 1);
     switch (P.kind) {
     case LK_STREAM: return "k_line_stream";
-    case LK_STREAM_B: return "k_line_stream_b";
     case LK_COLOUR: return "k_line_colour";
     default: return "k_line_rhs+k_line_forward+k_line_backward";
     }

@@ -115,14 +115,16 @@ int emg3d_device_count(void);
  * "tile_fuse": 1 (default) lets the tiles of the tiled point smoother where two consecutive
  * sweeps meet run both sweeps on one LDS copy (same operations, one load / store less).
  * "line_stream": 1 (default) runs the colour passes of lines too long for LDS records (more than
- * ~128 blocks with 16 lines per workgroup) with the right-hand sides produced into an LDS ring
- * while the forward substitution consumes them (k_line_stream: no round trip of the right-hand
- * sides through the scratch, bit-identical results); 0 the three-phase kernel everywhere; 2 also
- * where part of the records fit in LDS. "line_stream_r": rows per half of that ring (0 = 16; a
- * multiple of 4 in 4..32, anything else is refused). "line_stream_bmin": with several right-hand sides
+ * ~128 blocks with 16 lines per workgroup) with the right-hand sides (forward pass) and the w records
+ * (backward pass) staged through an LDS ring by producer waves while the chain waves substitute
+ * (k_line_stream: no round trip of the right-hand sides through the scratch, bit-identical results); 0 the
+ * three-phase kernel everywhere; 2 also where part of the records fit in LDS. "line_stream_r": rows per
+ * half of that ring (0 = 16; a multiple of 4 in 4..32, anything else is refused; fewer where several
+ * right-hand sides share the LDS). "line_stream_bmin": with several right-hand sides
  * (emg3d_level::batch > 1) such passes on lines of at least this many blocks (default 64; <= 0: never)
- * serve groups of up to four right-hand sides per workgroup, every factor row fetched once per group
- * (k_line_stream_b; per source the same arithmetic: bit-identical to separate solves).
+ * serve GROUPS of up to four right-hand sides per workgroup, every factor row fetched once per group
+ * (k_line_stream<.., B>; per source the same arithmetic: bit-identical to separate solves) -- with the batch
+ * as a grid dimension every source's workgroups fetch the factors again.
  * "line_order" and "point_order" DO select the order of the sweeps (see above), like
  * "point_tile_min".
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
@@ -137,10 +139,10 @@ const char *emg3d_option_name(int i);
 /* a counter that advances whenever emg3d_set_option changes a value: a cheap key for such caches */
 int emg3d_options_generation(void);
 /* The kernel that runs a colour pass of line direction lr (1/2/3) on a level of (nx,ny,nz) cells with
- * `batch` right-hand sides under the current options -- "k_line_stream" (right-hand sides through an LDS
- * ring), "k_line_stream_b" (the same for groups of right-hand sides that share each factor fetch),
- * "k_line_colour" (three phases in one launch) or the three separate kernels --, decided on the level's
- * largest colour class by the very rule the launcher uses. For profiles and benchmarks; "" on bad input. */
+ * `batch` right-hand sides under the current options -- "k_line_stream" (records staged through an LDS
+ * ring; with batch > 1: groups of right-hand sides per factor fetch), "k_line_colour" (three phases in one
+ * launch) or the three separate kernels --, decided on the level's largest colour class by the very rule
+ * the launcher uses. For profiles and benchmarks; "" on bad input. */
 const char *emg3d_line_kernel_name(int lr, int nx, int ny, int nz, int is_complex, int batch);
 
 /* ---------------------------------------------------------------- host flavour ---- */

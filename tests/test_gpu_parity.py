@@ -650,9 +650,8 @@ def _random_level_fields(shape, dtype, seed, freq=0.7, extras=False):
 @pytest.mark.parametrize('shape,lr', [((130, 72, 72), 1), ((72, 130, 72), 2), ((72, 72, 258), 3)])
 @pytest.mark.parametrize('batch,dtype', [(2, complex), (3, complex), (4, complex), (5, complex), (4, float), (8, complex)])
 def test_batched_streamed_line_kernel_equals_single_source(shape, lr, batch, dtype):
-    """k_line_stream_b -- one workgroup serves its 16 lines for a group of up to four right-hand sides, every
-    factor row fetched once per group, w records staged through LDS in the backward pass -- against the
-    single-source kernels on the same level: source by source the fields after nu = 3 sweeps must agree BIT
+    """k_line_stream with B > 1 -- one workgroup serves its 16 lines for a group of up to four right-hand sides,
+    every factor row fetched once per group -- against the single-source launches on the same level: source by source the fields after nu = 3 sweeps must agree BIT
     FOR BIT (batches of 5 and 8 run as groups of 3 + 2 and 4 + 4). Lines of 130 and 258 blocks (R = 16 / 8
     rows per chunk, several chunks, a ragged last one), > 1000 lines per colour class (16 per workgroup)."""
     lib = _lib.lib()
@@ -660,7 +659,7 @@ def test_batched_streamed_line_kernel_equals_single_source(shape, lr, batch, dty
         pytest.skip('group splitting is direction-independent: one direction is enough')
     if dtype is float and lr != 3:
         pytest.skip('the records of 16 real 130-block lines fit in LDS: k_line_colour')
-    assert lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), batch) == b'k_line_stream_b'
+    assert lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), batch) == b'k_line_stream'
     grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + lr + batch)
     dev = torch.device('cuda')
     rng = np.random.default_rng(batch)
@@ -683,28 +682,17 @@ def test_batched_streamed_line_kernel_equals_single_source(shape, lr, batch, dty
     for b in range(batch):
         assert np.any(want[b] != starts[b])
         assert np.array_equal(got[b], want[b]), (b, relerr(got[b], want[b]))
-    # and the single source as a group of one (option line_stream = 3): the staged-w backward pass alone
-    old = lib.emg3d_get_option(b'line_stream')
-    try:
-        lib.emg3d_set_option(b'line_stream', 3)
-        if lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), 1) == b'k_line_stream_b':
-            single.s.copy_(torch.from_numpy(srcs[0]))
-            single.e.copy_(torch.from_numpy(starts[0]))
-            single.smooth(lr, 3)
-            assert np.array_equal(single.e.cpu().numpy(), want[0])
-    finally:
-        lib.emg3d_set_option(b'line_stream', old)
 
 
 def test_solve_batch_long_lines_equals_separate_solves():
-    """solve_batch on a grid whose finest level runs k_line_stream_b (lines of 256 blocks along x, 72 x 72
+    """solve_batch on a grid whose finest level runs k_line_stream (lines of 256 blocks along x, 72 x 72
     lines): fields, cycle counts and error histories of four sources bit-identical to separate solves."""
     lib = _lib.lib()
     shape = (256, 72, 72)
     h = [widths(n // 2, n // 4, 30., 1.04) for n in shape]
     grid = emg3d.TensorMesh(h, [-w.sum() / 2 for w in h])
     assert grid.shape_cells == shape
-    assert lib.emg3d_line_kernel_name(1, *shape, 1, 4) == b'k_line_stream_b'
+    assert lib.emg3d_line_kernel_name(1, *shape, 1, 4) == b'k_line_stream'
     rng = np.random.default_rng(8)
     rho = 10 ** rng.uniform(-0.5, 0.7, shape)
     model = emg3d.Model(grid, rho, 1.5 * rho, 2.0 * rho)

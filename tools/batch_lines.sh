@@ -1,7 +1,7 @@
 #!/bin/bash
 # Level-0 line passes with several right-hand sides (through gpurun): time per source and HBM traffic per launch
 # (FETCH_SIZE / WRITE_SIZE, separate passes) of the batched launches at 256^3, with the batch as a grid dimension
-# (line_stream_bmin=0: k_line_colour<BATCH>) and with groups of right-hand sides per factor fetch (k_line_stream_b).
+# (line_stream_bmin=0: k_line_colour<BATCH>) and with groups of right-hand sides per factor fetch (k_line_stream).
 #   bash tools/batch_lines.sh [shape]      -> gpurun_out/batch_lines/
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -17,6 +17,8 @@ for B in 2 4; do
   python $R/tools/microbench.py lines --shape $SHAPE --fused-only --batch $B
 done
 } > $O/timing_${SHAPE//,/x}.txt 2>&1
+cat $O/timing_${SHAPE//,/x}.txt | grep -v amdgpu.ids
+if [ -n "$TIMING_ONLY" ]; then exit 0; fi
 for cfg in "1 line_stream=1" "1 line_stream=3" "2 line_stream_bmin=0" "2 line_stream_bmin=64" "4 line_stream_bmin=0" "4 line_stream_bmin=64"; do
   set -- $cfg
   B=$1; OPT=$2
