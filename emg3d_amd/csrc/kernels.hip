@@ -1039,9 +1039,10 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
 // at step i, already in the chain's grouping (bottom half = mirrored blocks: entry 0 of record row k,
 // entries 1..4 of row k - 1). R = 16 for B <= 2, 8 for B = 3, 4 (160 KB). The w / solution records
 // live in the global scratch (with them in LDS only 8 lines of 256 blocks fit a workgroup, and half-
-// filled chain waves cost more than the bytes save: measured). Six producer waves: the kernel is held
-// to 256 registers by its chain waves' SIMD partners anyway, so two more than the four that one source
-// needs cost nothing and keep more loads in flight (y / z lines of one source: -4...-6 %). One
+// filled chain waves cost more than the bytes save: measured). Producer waves: four for one source
+// (with two the producers, one memory round trip per item, are what the chains wait for), six for
+// groups -- the kernel is held to 256 registers by its chain waves' SIMD partners anyway, so two more
+// cost nothing and keep more loads in flight (B = 2: 0.84-0.87 -> 0.73-0.76 x per source). One
 // workgroup barrier (LDS-only: the chains' factor prefetch stays in flight) per R steps. The producers
 // also put the raw right-hand sides of the rows the middle block reads (row m, and entry 0 of row
 // m + 1) into the records.
@@ -1076,7 +1077,7 @@ __device__ __forceinline__ void stream_produce(const emg::Axes<T, DIR> &A, int c
     }
 }
 
-constexpr int LS_PROD = 384;                 // producer threads of k_line_stream (6 waves; + 2 chain waves)
+constexpr int LS_PROD = 384;                 // producer threads of k_line_stream for groups (6 waves; one source: 4; + 2 chain waves)
 
 // forward half-chain that takes its right-hand sides from the LDS ring, for B right-hand sides
 template <class T, int HALF, int RD, int B>
@@ -1156,7 +1157,7 @@ __device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n
 
 // backward substitution of one half for B right-hand sides (quad_backward, MIDFIRST form, per source);
 // the w records come from the LDS ring (stream_produce_w)
-template <class T, int DIR, int HALF, int RD, int B>
+template <class T, int DIR, int HALF, int RD, int B, bool PAIR>
 __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p, int qline,
                                                 int qend, int line0, int j, const T *fac, const double *lfac, T *vec,
                                                 size_t vstride, size_t boff0, const T *ringbase, int lpw, int R,
@@ -1223,7 +1224,7 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
     const long incj = active ? (HALF ? sj : -sj) : 0, inc4 = active ? (HALF ? s4 : -s4) : 0;
     const double nz = j != 0 ? 1.0 : 0.0;
     const size_t srcelems = (size_t)2 * R * lpw * 5, bufelems = (size_t)B * srcelems;
-    constexpr bool PAIRED = DIR == 0 && RD % 2 == 0;          // (steps come in pairs: W.steps is a multiple of 4)
+    constexpr bool PAIRED = PAIR && DIR == 0 && RD % 2 == 0;  // (steps come in pairs: W.steps is a multiple of 4)
     T hold_j[B], hold_4[B];
     T *hold_oj = dj, *hold_o4 = d4;
     size_t hold_step = 0;
@@ -1276,7 +1277,7 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
 
 // NPROD: producer threads (four waves for a single source; six for groups -- with the kernel held to 256
 // registers by its six waves anyway, two more producer waves cost nothing and keep more loads in flight)
-template <class T, int DIR, int B, int RD, int NPROD>
+template <class T, int DIR, int B, int RD, int NPROD, bool PAIR>
 __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                                     int lpw, int R, const T *fac, const double *lfac,
                                                                     T *vec, size_t vstride, size_t boff0)
@@ -1351,8 +1352,8 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
 #endif
     __syncthreads();
 #ifndef LSB_NO_BWD
-    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
-    else quad_backward_stream<T, DIR, 1, RD, B>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
+    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
+    else quad_backward_stream<T, DIR, 1, RD, B, PAIR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
 #endif
 }
 
@@ -1564,8 +1565,11 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
 {
     int R = stream_rows(B, sizeof(T));
     const size_t smem = (size_t)2 * B * 2 * R * lpw * 5 * sizeof(T);
-    constexpr int NPROD = LS_PROD;
-    const void *kern = (const void *)&k_line_stream<T, DIR, B, (B >= 2 ? 2 : emg::LINE_PAD), NPROD>;
+    // one source: four producer waves and unpaired stores (in a config-3 cycle six waves / paired x-line stores
+    // measure the same to 0.5 %: tools/ab_cycle.py); groups: six producer waves, x-line stores in pairs
+    constexpr int RD = B >= 2 ? 2 : emg::LINE_PAD;
+    constexpr int NPROD = B >= 2 ? LS_PROD : 256;
+    const void *kern = (const void *)&k_line_stream<T, DIR, B, RD, NPROD, (B >= 2)>;
     (void)allow_lds(kern, 160 * 1024);
     T *v0 = vec + (size_t)b0 * vstride;
     size_t boff0 = (size_t)b0 * L.bstride;
