@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
 // grid dimension (k_line_colour<BATCH>) every source's workgroups stream the 2 x 304 B of factors per
 // block again -- 47 % of the bytes of a level-0 colour pass, and PMC shows no merging in L2 (12-13 GB
 // per launch of two sources against 5.2-5.6 GB for one). Measured at 256^3 (profiles/r04_batch_lines_*):
-// 0.73-0.76 x the single-source time per source for B = 2, 0.69-0.75 x for B = 4.
+// 0.78-0.79 x the single-source time per source for B = 2, 0.72-0.76 x for B = 4.
 //
 // LDS: ring [2 buffers][B][2 halves][R rows][16 lines][5 entries] -- item (source, half, step i) holds
 // the five right-hand-side (forward) / w (backward) entries of the block that half's chain works on

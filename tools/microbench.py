@@ -76,7 +76,7 @@ def report(name, ms, ncells, nsweeps, case):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['point', 'lines', 'residual', 'around', 'all'])
+    ap.add_argument('what', choices=['point', 'lines', 'residual', 'around', 'all', 'batchcmp'])
     ap.add_argument('--n', type=int, default=256)
     ap.add_argument('--case', default='triaxial')
     ap.add_argument('--slabs', default='0,2,4,8,16,32')
@@ -92,6 +92,8 @@ def main():
         k, v = o.split('=')
         assert lib.emg3d_set_option(k.encode(), int(v)) == 0, o
     shape = tuple(int(x) for x in args.shape.split(',')) if args.shape else None
+    if args.what == 'batchcmp':
+        return batchcmp(args, shape)
     lv, grid = make_level(args.n, args.case, shape=shape, eta_real=args.eta_real, batch=args.batch)
     nc = grid.n_cells
     print(f"# {shape or args.n} {args.case}, nu={args.nu}, batch={args.batch}")
@@ -121,6 +123,38 @@ def main():
         report("residual (norm only, incl. sync)", med, nc, 1, args.case)
     if args.what in ('around', 'all'):
         around(lv, grid)
+
+
+def batchcmp(args, shape):
+    """Line passes with 1, 2 and 4 right-hand sides on ONE level in ONE process, interleaved over several rounds
+    (consecutive processes on one box differ by up to 8 %: clocks): ms per source and call, medians over the
+    rounds, and the ratio to the single source of the same round. The batched levels share the single level's
+    factor buffers."""
+    lib = _lib.lib()
+    one, grid = make_level(args.n, args.case, shape=shape)
+    levels = {1: one}
+    for b in (2, 4):
+        levels[b], _ = make_level(args.n, args.case, shape=shape, batch=b)
+        levels[b]._factors = one._factors
+    for lr in (1, 2, 3):
+        one.smooth(lr, args.nu)
+    rounds = 5
+    res = {(b, lr): [] for b in levels for lr in (1, 2, 3)}
+    for r in range(rounds):
+        for lr in (1, 2, 3):
+            for b, lv in levels.items():
+                med, _ = timeit(lambda: lv.smooth(lr, args.nu), reps=3, warm=1)
+                res[(b, lr)].append(med / b)
+    print(f"# {grid.shape_cells} {args.case}, nu={args.nu}: ms per source and call of {4 * args.nu - (args.nu - 1)} launches, "
+          f"median of {rounds} interleaved rounds (ratio to one source: median of the per-round ratios)")
+    for lr in (1, 2, 3):
+        base = np.array(res[(1, lr)])
+        line = f"gauss_seidel_{'xyz'[lr - 1]}:"
+        for b in levels:
+            v = np.array(res[(b, lr)])
+            kn = lib.emg3d_line_kernel_name(lr, *grid.shape_cells, 1, b).decode()
+            line += f"  B={b} {kn} {np.median(v):.3f} ms ({np.median(v / base):.3f} x)"
+        print(line, flush=True)
 
 
 def around(lv, grid):
