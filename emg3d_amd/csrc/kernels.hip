@@ -110,6 +110,9 @@ int g_line_stream_r = 0;           // rows per chunk of the ring (0: 16)
 // the global scratch and whose lines have at least this many blocks run k_line_stream -- groups of up
 // to four right-hand sides per workgroup, the factors fetched once per group (<= 0: never)
 int g_line_stream_bmin = 64;
+// one source: the coupling entries of a block (8 reals) recomputed by the producer waves from zeta / h and handed
+// to the chain waves through a second LDS ring instead of being fetched from the lfac records (1, default; 0: fetched)
+int g_line_stream_lf = 1;
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
@@ -497,7 +500,8 @@ template <class T> struct QuadRow {
         d4 = lf[7];
     }
     // RECS = false: factors and coupling only (the streamed kernel takes its right-hand sides from LDS)
-    template <class A, bool RECS = true> __device__ __forceinline__ void load(const A &a, int k)
+    // LF = false: without the coupling entries (k_line_stream for one source takes them from its LDS ring)
+    template <class A, bool RECS = true, bool LF = true> __device__ __forceinline__ void load(const A &a, int k)
     {
         const char *f = a.fac + (size_t)k * a.frow, *lf = a.lfac + (size_t)k * a.lrow;
 #pragma unroll
@@ -516,10 +520,20 @@ template <class T> struct QuadRow {
             v = *a.pvj(k);
         }
         if constexpr (RECS) v4 = *a.pv4(k);
-        bA = *reinterpret_cast<const double *>(lf + a.la);
-        bD = *reinterpret_cast<const double *>(lf + a.ld);
-        b04 = *reinterpret_cast<const double *>(lf + a.l04);
-        d4 = *reinterpret_cast<const double *>(lf + a.l4);
+        if constexpr (LF) {
+            bA = *reinterpret_cast<const double *>(lf + a.la);
+            bD = *reinterpret_cast<const double *>(lf + a.ld);
+            b04 = *reinterpret_cast<const double *>(lf + a.l04);
+            d4 = *reinterpret_cast<const double *>(lf + a.l4);
+        }
+    }
+    // the coupling entries of this lane from the eight values of a record (lfac layout)
+    __device__ __forceinline__ void take_b(const double *lf, int j)
+    {
+        bA = lf[j == 0 ? 3 : j - 1];
+        bD = lf[4 + max(j, 1) - 1];
+        b04 = lf[3];
+        d4 = lf[7];
     }
 };
 
@@ -1048,9 +1062,12 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
 // m + 1) into the records.
 //   RD : depth of the factor prefetch ring in the chain waves (4 for one source; 2 for B >= 2: a step
 //        of B sources takes B times as long, so two steps ahead is as far ahead in time).
+// lfo != nullptr: also the eight coupling entries of the item's block (stencil.h: line_coupling -- from the zeta
+// values the right-hand side needs anyway) into the coupling ring [2 halves][R rows][lpw lines][8]
 template <class T, int DIR>
 __device__ __forceinline__ void stream_produce(const emg::Axes<T, DIR> &A, int colour, int cntp, int cntq, int n0p,
-                                               int line0, int nl, int lpw, T *buf, int R, int chunk, int pt, int np)
+                                               int line0, int nl, int lpw, T *buf, int R, int chunk, int pt, int np,
+                                               double *lfo = nullptr)
 {
     const int n0 = A.n0();
     const int items = 2 * R * lpw;
@@ -1074,16 +1091,25 @@ __device__ __forceinline__ void stream_produce(const emg::Axes<T, DIR> &A, int c
         o[0] = keep0 * rhs[0];
 #pragma unroll
         for (int r = 1; r < 5; ++r) o[r] = keept * rhs[r];
+        if (lfo) {
+            double c[8];
+            emg::line_coupling<T, DIR>(A, k, i1, i2, half != 0, c);
+            double *lo = lfo + ((size_t)(half * R + row) * lpw + ll) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lo[r] = c[r];
+        }
     }
 }
 
 constexpr int LS_PROD = 384;                 // producer threads of k_line_stream for groups (6 waves; one source: 4; + 2 chain waves)
 
 // forward half-chain that takes its right-hand sides from the LDS ring, for B right-hand sides
-template <class T, int HALF, int RD, int B>
+// LFR: the coupling entries come from the coupling ring (lfring), not from the lfac records
+template <class T, int HALF, int RD, int B, bool LFR>
 __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
                                                       const T *fac, const double *lfac, T *vec, size_t vstride,
-                                                      const T *ringbase, int lpw, int R, int nchunks)
+                                                      const T *ringbase, int lpw, int R, int nchunks,
+                                                      const double *lfring)
 {
     const HalfWalk<HALF> W(n0, n0p);
     const bool active = qline < qend;
@@ -1094,7 +1120,7 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
     T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
     QuadRow<T> ring[RD];
     const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
-    auto fetch = [&](QuadRow<T> &q, int i) { q.template load<LaneAddr<T, HALF, false>, false>(LA, W.fwd(W.clampi(i))); };
+    auto fetch = [&](QuadRow<T> &q, int i) { q.template load<LaneAddr<T, HALF, false>, false, !LFR>(LA, W.fwd(W.clampi(i))); };
 #pragma unroll
     for (int d = 0; d < RD; ++d) fetch(ring[d], d);
     __syncthreads();                                          // chunk 0 of the rings and the middle rows are there
@@ -1111,8 +1137,11 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
 #pragma unroll
             for (int d = 0; d < RD; ++d) {
                 const int k = W.fwd(i0 + d);
-                const QuadRow<T> &q = ring[d];
+                QuadRow<T> &q = ring[d];
                 const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
+                if constexpr (LFR)
+                    q.take_b(lfring + (size_t)(c & 1) * ((size_t)2 * R * lpw * 8) +
+                             ((size_t)(HALF * R + (i0 + d - c * R)) * lpw + ll) * 8, j);
                 T *const o4 = active ? LA.pv4(k) : dslot + 4;
                 T *const oj = active ? LA.pvj(k) : dslot + j;
 #pragma unroll
@@ -1135,9 +1164,11 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
 // row k - 1 for a mirrored block) -- sixteen lines x 80 B are contiguous in the scratch, so the idle
 // producer waves fetch them as wide coalesced loads and the chain quads need neither a register ring
 // nor four scattered 16-byte loads per step for them.
-template <class T>
+template <class T, int DIR>
 __device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n0, int n0p, int line0, int nl, int lpw,
-                                                 T *buf, int R, int chunk, int pt, int np)
+                                                 T *buf, int R, int chunk, int pt, int np,
+                                                 const emg::Axes<T, DIR> *A = nullptr, int colour = 0, int cntp = 0,
+                                                 int cntq = 0, double *lfo = nullptr)
 {
     const int mk = emg::line_mid(n0);
     const int items = 2 * R * lpw;
@@ -1152,16 +1183,26 @@ __device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n
         const T a0 = r0[0], a1 = rt[1], a2 = rt[2], a3 = rt[3], a4 = rt[4];
         T *o = buf + ((size_t)(half * R + row) * lpw + ll) * 5;
         o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+        if (lfo) {
+            // the coupling entries of block k from four zeta values (32 B) instead of its lfac record (64 B)
+            int i1, i2, l2;
+            emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+            double c[8];
+            emg::line_coupling<T, DIR>(*A, k, i1, i2, half != 0, c);
+            double *lo = lfo + ((size_t)(half * R + row) * lpw + ll) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lo[r] = c[r];
+        }
     }
 }
 
 // backward substitution of one half for B right-hand sides (quad_backward, MIDFIRST form, per source);
 // the w records come from the LDS ring (stream_produce_w)
-template <class T, int DIR, int HALF, int RD, int B, bool PAIR>
+template <class T, int DIR, int HALF, int RD, int B, bool PAIR, bool LFR>
 __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p, int qline,
                                                 int qend, int line0, int j, const T *fac, const double *lfac, T *vec,
                                                 size_t vstride, size_t boff0, const T *ringbase, int lpw, int R,
-                                                int nchunks)
+                                                int nchunks, const double *lfring)
 {
     const emg::Axes<T, DIR> A(L, boff0);
     const int n0 = A.n0();
@@ -1189,7 +1230,7 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
     QuadRow<T> ring[RD];
     const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
     auto fetch = [&](QuadRow<T> &q, int i) {
-        q.template load<LaneAddr<T, HALF, false>, false>(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));
+        q.template load<LaneAddr<T, HALF, false>, false, !LFR>(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));
     };
     // coupling to the middle: B_m (top) / U_{m+1} (bottom)
     QuadRow<T> qm;
@@ -1235,8 +1276,11 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
 #pragma unroll
             for (int d = 0; d < RD; ++d) {
                 const int k = W.bwd(i0 + d);
-                const QuadRow<T> &q = ring[d];
+                QuadRow<T> &q = ring[d];
                 const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
+                if constexpr (LFR)
+                    q.take_b(lfring + (size_t)(c & 1) * ((size_t)2 * R * lpw * 8) +
+                             ((size_t)(HALF * R + (i0 + d - c * R)) * lpw + ll) * 8, j);
                 const bool real_block = HALF ? k <= n0 - 1 : true;      // uniform over the wave
                 T *const oj = real_block ? pej : dj;
                 T *const o4 = real_block ? pe4 : d4;
@@ -1277,7 +1321,10 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
 
 // NPROD: producer threads (four waves for a single source; six for groups -- with the kernel held to 256
 // registers by its six waves anyway, two more producer waves cost nothing and keep more loads in flight)
-template <class T, int DIR, int B, int RD, int NPROD, bool PAIR>
+// LFR: the coupling entries (the 8 reals of a block's lfac record) are recomputed by the producers and handed
+// over through a second ring [2 buffers][2 halves][R][lpw][8] behind the first: 64 B per block less to fetch in
+// the forward pass (the producers hold the zeta values already), 32 B less in the backward pass.
+template <class T, int DIR, int B, int RD, int NPROD, bool PAIR, bool LFR>
 __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                                     int lpw, int R, const T *fac, const double *lfac,
                                                                     T *vec, size_t vstride, size_t boff0)
@@ -1290,6 +1337,8 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
     const int nl = min(lpw, nlines - line0);
     T *const ringbase = reinterpret_cast<T *>(ls_smem);
     const size_t srcelems = (size_t)2 * R * lpw * 5, bufelems = (size_t)B * srcelems;
+    double *const lfring = LFR ? reinterpret_cast<double *>(ringbase + 2 * bufelems) : nullptr;
+    const size_t lfelems = (size_t)2 * R * lpw * 8;
     const int n0 = DIR == 0 ? L.nx : DIR == 1 ? L.ny : L.nz;
     const int mk = emg::line_mid(n0);
     const int smax = max(mk, n0p - 2 - mk);
@@ -1313,7 +1362,8 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
                 *V.p4(mk, lid) = rhs[4];
                 *V.p(mk + 1, lid, 0) = emg::line_rhs_e0<T, DIR>(A, min(mk + 1, n0 - 1), i1, i2);
             }
-            stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD);
+            stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD,
+                                   (LFR && b == 0) ? lfring : nullptr);
         }
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
@@ -1322,22 +1372,27 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
                 for (int b = 0; b < B; ++b) {
                     const emg::Axes<T, DIR> A(L, boff0 + b * L.bstride);
                     stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw,
-                                           ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD);
+                                           ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD,
+                                           (LFR && b == 0) ? lfring + (size_t)((c + 1) & 1) * lfelems : nullptr);
                 }
             }
             lds_barrier();
         }
         __syncthreads();                                      // the forward chains are done: all w records are written
+        const emg::Axes<T, DIR> A0(L, boff0);
 #pragma unroll 1
         for (int b = 0; b < B; ++b)
-            stream_produce_w<T>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD);
+            stream_produce_w<T, DIR>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD,
+                                     &A0, colour, cntp, cntq, (LFR && b == 0) ? lfring : nullptr);
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
             if (c + 1 < nchunks) {
 #pragma unroll 1
                 for (int b = 0; b < B; ++b)
-                    stream_produce_w<T>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
-                                        ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD);
+                    stream_produce_w<T, DIR>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
+                                             ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD,
+                                             &A0, colour, cntp, cntq,
+                                             (LFR && b == 0) ? lfring + (size_t)((c + 1) & 1) * lfelems : nullptr);
             }
             lds_barrier();
         }
@@ -1347,13 +1402,13 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
 #ifndef LSB_NO_FWD
-    if (half == 0) quad_forward_stream<T, 0, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
-    else quad_forward_stream<T, 1, RD, B>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks);
+    if (half == 0) quad_forward_stream<T, 0, RD, B, LFR>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks, lfring);
+    else quad_forward_stream<T, 1, RD, B, LFR>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks, lfring);
 #endif
     __syncthreads();
 #ifndef LSB_NO_BWD
-    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
-    else quad_backward_stream<T, DIR, 1, RD, B, PAIR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks);
+    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR, LFR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks, lfring);
+    else quad_backward_stream<T, DIR, 1, RD, B, PAIR, LFR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks, lfring);
 #endif
 }
 
@@ -1489,10 +1544,10 @@ struct LinePlan {
 constexpr int LSB_MAX = 4;
 // rows per chunk of the ring of a group of g right-hand sides: 2 buffers x g x 2 halves x R x 16 lines x
 // 5 entries must fit the 160 KB of a CU
-inline int stream_rows(int g, size_t elem)
+inline int stream_rows(int g, size_t elem, bool lfr = false)
 {
     int R = g_line_stream_r > 0 ? g_line_stream_r : 16;
-    while (R > 4 && (size_t)2 * g * 2 * R * 16 * 5 * elem > (size_t)160 * 1024) R -= 4;
+    while (R > 4 && (size_t)2 * 2 * R * 16 * (g * 5 * elem + (lfr ? 64 : 0)) > (size_t)160 * 1024) R -= 4;
     return R;
 }
 template <class T> LinePlan line_plan(const emg::LineClass &lc, int batch)
@@ -1563,13 +1618,16 @@ template <class T, int DIR, int B>
 void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const T *f, const double *lf, T *vec,
                          size_t vstride, int b0, int lpw, hipStream_t st)
 {
-    int R = stream_rows(B, sizeof(T));
-    const size_t smem = (size_t)2 * B * 2 * R * lpw * 5 * sizeof(T);
+    // one source: the coupling entries through a second ring (option line_stream_lf, default 1)
+    const bool lfr = B == 1 && g_line_stream_lf != 0;
+    int R = stream_rows(B, sizeof(T), lfr);
+    const size_t smem = (size_t)2 * B * 2 * R * lpw * 5 * sizeof(T) + (lfr ? (size_t)2 * 2 * R * lpw * 8 * sizeof(double) : 0);
     // one source: four producer waves and unpaired stores (in a config-3 cycle six waves / paired x-line stores
     // measure the same to 0.5 %: tools/ab_cycle.py); groups: six producer waves, x-line stores in pairs
     constexpr int RD = B >= 2 ? 2 : emg::LINE_PAD;
     constexpr int NPROD = B >= 2 ? LS_PROD : 256;
-    const void *kern = (const void *)&k_line_stream<T, DIR, B, RD, NPROD, (B >= 2)>;
+    const void *kern = lfr ? (const void *)&k_line_stream<T, DIR, B, RD, NPROD, (B >= 2), (B == 1)>
+                           : (const void *)&k_line_stream<T, DIR, B, RD, NPROD, (B >= 2), false>;
     (void)allow_lds(kern, 160 * 1024);
     T *v0 = vec + (size_t)b0 * vstride;
     size_t boff0 = (size_t)b0 * L.bstride;
@@ -1949,7 +2007,7 @@ static const OptionEntry g_options[] = {
     {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
-    {"line_stream_bmin", &g_line_stream_bmin},
+    {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value

@@ -761,6 +761,40 @@ EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
 }
 
 
+// The eight coupling entries of record k of a line's `lfac` (line_setup: put_B), recomputed from zeta and the
+// widths: c[m-1] = first row, c[3+m] = diagonal, m = 1..4. Records 1 .. m of the top half hold B_k (left0 /
+// leftd of line_matrix(k)), records >= m + 1 of the bottom half U_k of the mirrored block (mid[.][0] / leftd of
+// line_matrix(k); zero for the last block n0 - 1), record 0 and the identity padding blocks behind n0 - 1
+// zeros. Products only, evaluated as line_matrix evaluates them: the same bits as the stored records.
+template <class T, int DIR>
+EMG_HD void line_coupling(const Axes<T, DIR> &A, int k, int i1, int i2, bool mirrored, double (&c)[8])
+{
+    const int n0 = A.n0();
+    const int kk = k < 0 ? 0 : (k > n0 - 1 ? n0 - 1 : k);
+    const int i1m = i1 - 1, i2m = i2 - 1;
+    const double h00 = A.ih0()[kk];
+    const double h10 = A.ih1()[i1m], h11 = A.ih1()[i1];
+    const double h20 = A.ih2()[i2m], h21 = A.ih2()[i2];
+    const double k00 = 0.5 * h00, k10 = 0.5 * h10, k11 = 0.5 * h11, k20 = 0.5 * h20, k21 = 0.5 * h21;
+    const double z000 = A.zeta(kk, i1m, i2m), z010 = A.zeta(kk, i1, i2m);
+    const double z001 = A.zeta(kk, i1m, i2), z011 = A.zeta(kk, i1, i2);
+    const double mzyLxm = k10 * (z001 + z000), mzyRxm = k11 * (z011 + z010);
+    const double myzLxm = k20 * (z010 + z000), myzRxm = k21 * (z011 + z001);
+    const double mzxLym = k00 * (z001 + z000), mzxLyp = k00 * (z011 + z010);
+    const double myxLzm = k00 * (z010 + z000), myxLzp = k00 * (z011 + z001);
+    const bool any = mirrored ? (k >= 1 && k < n0 - 1) : (k >= 1 && k <= n0 - 1);
+    const double a0 = mzyLxm * h00, a1 = mzyRxm * h00, a2 = myzLxm * h00, a3 = myzRxm * h00;
+    // top: B_k(0, m) = (+, -, +, -); mirrored: U_k(0, m) = M_k(m, 0) = the negatives
+    c[0] = any ? (mirrored ? -a0 : a0) : 0.0;
+    c[1] = any ? (mirrored ? a1 : -a1) : 0.0;
+    c[2] = any ? (mirrored ? -a2 : a2) : 0.0;
+    c[3] = any ? (mirrored ? a3 : -a3) : 0.0;
+    c[4] = any ? -(mzxLym * h00) : 0.0;
+    c[5] = any ? -(mzxLyp * h00) : 0.0;
+    c[6] = any ? -(myxLzm * h00) : 0.0;
+    c[7] = any ? -(myxLzp * h00) : 0.0;
+}
+
 // In-register LDL^T of a symmetric 5x5 block given by its lower triangle S (S[r][m], m<=r):
 // C[tri(r,m)] (m<r) and dinv[r]. nrows < 5 factorises the leading nrows x nrows part.
 template <class T> EMG_HD void ldlt5(const T (&S)[5][5], int nrows, T (&C)[10], T (&dinv)[5])
