@@ -94,11 +94,13 @@ int g_line_occ2 = 0;
 int g_point_small = 512;
 // fused line kernel: lines per workgroup (0 = automatic: 4, 8 or 16)
 int g_line_lpw = 0;
-// the largest levels (records of 16 lines do not fit in LDS even without their fifth slot: lines of
-// ~160 blocks and more): k_line_stream -- right-hand sides and w records staged through an LDS ring by
-// producer waves while the chain waves substitute (1, default); 0: k_line_colour everywhere; 2: k_line_stream
-// also where slots 0..3 would fit (~128-block lines: measured equal)
-int g_line_stream = 1;
+// the levels whose records do not fit the LDS of a CU: k_line_stream -- right-hand sides, coupling entries and
+// w records staged through LDS rings by producer waves while the chain waves substitute. 2 (default): wherever
+// the full records of the workgroup's lines do not fit (lines of ~128 blocks and more with 16 lines per
+// workgroup; since round 4, when the producers took over the coupling entries: 128-block lines -6 % per launch
+// against k_line_colour with slots 0..3 in LDS); 1: only where not even slots 0..3 fit (~160 blocks and more);
+// 0: k_line_colour everywhere
+int g_line_stream = 2;
 // sequence of the colour passes of the LINE smoothers (launch.h: line_sweep_colour): 1 (default) cyclic
 // 1,2,3,0,1,...; 0 mirrored sweeps (0,2,3,1 forward / its reverse backward: rounds 1-2); 2 the classes
 // 1,2,3,0 in every sweep (eight launches per two sweeps). Like
@@ -1581,6 +1583,8 @@ template <class T> LinePlan line_plan(const emg::LineClass &lc, int batch)
     const size_t smem1 = rec_bytes(lpw, 5);
     const size_t smem2 = rec_bytes(lpw, 4);
     P.batchk = batch > 1 || g_line_occ2;
+    // (streaming also the levels whose whole records fit -- 64-block lines and shorter -- measured slower: 84.5
+    // against 83.8 ms per config-3 cycle)
     const bool streamable = g_line_stream && !P.shortl && !g_line_occ2 && !(g_line_debug & 1) && lpw <= 16 && !fits(smem1) &&
                             (!fits(smem2) || g_line_stream >= 2);
     // the largest levels of a single-source solve: right-hand sides streamed through LDS

@@ -114,11 +114,13 @@ int emg3d_device_count(void);
  * sweep of the same call (it reproduces the same values bit by bit); 0 launches every pass.
  * "tile_fuse": 1 (default) lets the tiles of the tiled point smoother where two consecutive
  * sweeps meet run both sweeps on one LDS copy (same operations, one load / store less).
- * "line_stream": 1 (default) runs the colour passes of lines too long for LDS records (more than
- * ~128 blocks with 16 lines per workgroup) with the right-hand sides (forward pass) and the w records
- * (backward pass) staged through an LDS ring by producer waves while the chain waves substitute
- * (k_line_stream: no round trip of the right-hand sides through the scratch, bit-identical results); 0 the
- * three-phase kernel everywhere; 2 also where part of the records fit in LDS. "line_stream_r": rows per
+ * "line_stream": 2 (default) runs the colour passes of lines whose records do not fit the LDS of a CU (~128
+ * blocks and more with 16 lines per workgroup) with the right-hand sides and coupling entries (forward pass)
+ * and the w records (backward pass) staged through LDS rings by producer waves while the chain waves substitute
+ * (k_line_stream: no round trip of the right-hand sides through the scratch, bit-identical results); 1 only
+ * where not even slots 0..3 of the records fit (~160 blocks and more); 0 the
+ * three-phase kernel everywhere. "line_stream_lf": 1 (default) one source's coupling entries are recomputed by the
+ * producers instead of fetched (bit-equal values). "line_stream_r": rows per
  * half of that ring (0 = 16; a multiple of 4 in 4..32, anything else is refused; fewer where several
  * right-hand sides share the LDS). "line_stream_bmin": with several right-hand sides
  * (emg3d_level::batch > 1) such passes on lines of at least this many blocks (default 64; <= 0: never)

@@ -385,7 +385,8 @@ def test_bench_helpers_without_a_gpu():
     # the label is the library's own dispatch decision (emg3d_line_kernel_name), per direction and batch
     for lr in (1, 2, 3):
         assert bench.line_kernel_name(lr, (256, 256, 256)) == 'k_line_stream'
-        assert bench.line_kernel_name(lr, (128, 128, 128)) == 'k_line_colour'
+        assert bench.line_kernel_name(lr, (128, 128, 128)) == 'k_line_stream'
+        assert bench.line_kernel_name(lr, (64, 64, 64)) == 'k_line_colour'
         assert bench.line_kernel_name(lr, (256, 256, 256), batch=4) == 'k_line_stream'
         assert bench.line_kernel_name(lr, (64, 64, 64), batch=4) == 'k_line_colour'
     assert bench.line_kernel_name(1, (384, 256, 256)) == 'k_line_stream' and bench.line_kernel_name(2, (256, 16, 16)) == 'k_line_colour'
