@@ -86,6 +86,8 @@ int g_line_lds = 1;
 int g_point_prefetch = 0;
 // residual kernel: planes a workgroup walks on large levels (1 = one plane per workgroup)
 int g_residual_zb = 8;
+// ... and carries the operands a cell shares with the cell below it in registers (1, default; 0: every cell loads all of its own)
+int g_residual_roll = 1;
 // fused line kernel with the records in the global scratch (the largest levels): the instantiation
 // that is held to 256 registers, so that two workgroups share a CU and overlap their phases
 int g_line_occ2 = 0;
@@ -1421,7 +1423,7 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
 // the CU's cache then -- with one plane per workgroup the three workgroups that need a plane run on
 // different XCDs at different times and each fetches it from HBM (PMC, 256^3: 399 B read per cell
 // against 144).
-template <class T>
+template <class T, bool ROLL>
 __global__ __launch_bounds__(256) void k_residual(emg::Level<T> L0, T *rx, T *ry, T *rz, double *partial, int nzb, int zb)
 {
     // grid.z = plane blocks x right-hand sides; the residual buffers are stacked like the fields, and
@@ -1433,8 +1435,10 @@ __global__ __launch_bounds__(256) void k_residual(emg::Level<T> L0, T *rx, T *ry
     const int iy = blockIdx.y * blockDim.y + threadIdx.y;
     const int z0 = (blockIdx.z - b * nzb) * zb, z1 = min(z0 + zb, L.nz + 1);
     double acc = 0.0;
-    if (ix <= L.nx && iy <= L.ny)
-        for (int iz = z0; iz < z1; ++iz) acc += emg::residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
+    if (ix <= L.nx && iy <= L.ny) {
+        if constexpr (ROLL) acc = emg::residual_column<T>(L, rx, ry, rz, ix, iy, z0, z1);
+        else for (int iz = z0; iz < z1; ++iz) acc += emg::residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
+    }
     if (partial) {
         // wave reduction (64 lanes), then across the 4 waves through LDS
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -1879,8 +1883,12 @@ int launch_residual(const emg3d_level *lv, void *rx, void *ry, void *rz, double 
     grid.z = cdiv((int)grid.z, zb);
     const size_t nblk = (size_t)grid.x * grid.y * grid.z;       // per right-hand side
     if (sumsq && (ws == nullptr || ws_len < nblk * L.batch)) return fail(EMG3D_ERR_SCRATCH, "residual: workspace too small");
-    hipLaunchKernelGGL(k_residual<T>, dim3(grid.x, grid.y, grid.z * L.batch), block, 0, st, L, (T *)rx, (T *)ry, (T *)rz,
-                       sumsq ? ws : nullptr, (int)grid.z, zb);
+    if (zb > 1 && g_residual_roll)
+        hipLaunchKernelGGL((k_residual<T, true>), dim3(grid.x, grid.y, grid.z * L.batch), block, 0, st, L, (T *)rx, (T *)ry,
+                           (T *)rz, sumsq ? ws : nullptr, (int)grid.z, zb);
+    else
+        hipLaunchKernelGGL((k_residual<T, false>), dim3(grid.x, grid.y, grid.z * L.batch), block, 0, st, L, (T *)rx, (T *)ry,
+                           (T *)rz, sumsq ? ws : nullptr, (int)grid.z, zb);
     if (sumsq) hipLaunchKernelGGL(k_reduce_sum, dim3(L.batch), dim3(256), 0, st, ws, (int)nblk, sumsq);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2011,7 +2019,7 @@ static const OptionEntry g_options[] = {
     {"line_occ2", &g_line_occ2},         {"point_small", &g_point_small},       {"line_lpw", &g_line_lpw},
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
-    {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf},
+    {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value

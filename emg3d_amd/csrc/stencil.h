@@ -114,6 +114,147 @@ template <class T, int DIR> struct Axes {
     }
 };
 
+// The operands of the residual of extended cell (ix,iy,iz): 24 field values, 8 zeta, 12 eta. Split from the
+// arithmetic (residual_compute) so that a thread that walks a column of cells upwards can CARRY the values it
+// will need again one plane higher (residual_load_roll) instead of loading them a second time: 28 instead of 53
+// loads per cell, the same operands, the same arithmetic, the same bits.
+template <class T> struct ResIn {
+    T ex_c, ey_c, ez_c;
+    T ex_zp, exm_zp, exm_c, ex_zm, ex_yp, exm_yp, ex_ym;        // EX(ix,iy,izp) (ixm,iy,izp) (ixm,iy,iz) (ix,iy,izm) (ix,iyp,iz) (ixm,iyp,iz) (ix,iym,iz)
+    T ey_zp, eym_zp, eym_c, ey_zm, ey_xp, ey_xm, eym_xp;        // EY(ix,iy,izp) (ix,iym,izp) (ix,iym,iz) (ix,iy,izm) (ixp,iy,iz) (ixm,iy,iz) (ixp,iym,iz)
+    T ez_yp, ez_ym, ez_xp, ez_xm, ez_yp_zm, ez_zm, ez_xp_zm;    // EZ(ix,iyp,iz) (ix,iym,iz) (ixp,iy,iz) (ixm,iy,iz) (ix,iyp,izm) (ix,iy,izm) (ixp,iy,izm)
+    double z000, z100, z010, z110, z001, z101, z011, z111;
+    T etx[4], ety[4], etz[4];                                   // in the order of the sums of core.py:181-186
+    double hx1, hx0, hy1, hy0, hz1, hz0;
+};
+
+// all operands from memory
+template <class T> EMG_HD void residual_load(const Level<T> &L, int ix, int iy, int iz, ResIn<T> &in)
+{
+    const Axes<T, 0> A(L);
+    const int ixm = ix > 0 ? ix - 1 : 0, iym = iy > 0 ? iy - 1 : 0, izm = iz > 0 ? iz - 1 : 0;
+    const int ixp = ix + 1, iyp = iy + 1, izp = iz + 1;
+    in.hx1 = L.ihx[ix]; in.hx0 = L.ihx[ixm];
+    in.hy1 = L.ihy[iy]; in.hy0 = L.ihy[iym];
+    in.hz1 = L.ihz[iz]; in.hz0 = L.ihz[izm];
+#define EXv(i, j, k) L.ex[A.iex(i, j, k)]
+#define EYv(i, j, k) L.ey[A.iey(i, j, k)]
+#define EZv(i, j, k) L.ez[A.iez(i, j, k)]
+#define ZT(i, j, k) L.zeta[A.icc(i, j, k)]
+#define ETv(p, i, j, k) (p)[A.icc(i, j, k)]
+    in.ex_c = EXv(ix, iy, iz); in.ey_c = EYv(ix, iy, iz); in.ez_c = EZv(ix, iy, iz);
+    in.ex_zp = EXv(ix, iy, izp); in.exm_zp = EXv(ixm, iy, izp); in.exm_c = EXv(ixm, iy, iz); in.ex_zm = EXv(ix, iy, izm);
+    in.ex_yp = EXv(ix, iyp, iz); in.exm_yp = EXv(ixm, iyp, iz); in.ex_ym = EXv(ix, iym, iz);
+    in.ey_zp = EYv(ix, iy, izp); in.eym_zp = EYv(ix, iym, izp); in.eym_c = EYv(ix, iym, iz); in.ey_zm = EYv(ix, iy, izm);
+    in.ey_xp = EYv(ixp, iy, iz); in.ey_xm = EYv(ixm, iy, iz); in.eym_xp = EYv(ixp, iym, iz);
+    in.ez_yp = EZv(ix, iyp, iz); in.ez_ym = EZv(ix, iym, iz); in.ez_xp = EZv(ixp, iy, iz); in.ez_xm = EZv(ixm, iy, iz);
+    in.ez_yp_zm = EZv(ix, iyp, izm); in.ez_zm = EZv(ix, iy, izm); in.ez_xp_zm = EZv(ixp, iy, izm);
+    in.z000 = ZT(ixm, iym, izm); in.z100 = ZT(ix, iym, izm); in.z010 = ZT(ixm, iy, izm); in.z110 = ZT(ix, iy, izm);
+    in.z001 = ZT(ixm, iym, iz); in.z101 = ZT(ix, iym, iz); in.z011 = ZT(ixm, iy, iz); in.z111 = ZT(ix, iy, iz);
+    in.etx[0] = ETv(L.eta_x, ix, iym, izm); in.etx[1] = ETv(L.eta_x, ix, iym, iz);
+    in.etx[2] = ETv(L.eta_x, ix, iy, izm); in.etx[3] = ETv(L.eta_x, ix, iy, iz);
+    in.ety[0] = ETv(L.eta_y, ixm, iy, izm); in.ety[1] = ETv(L.eta_y, ix, iy, izm);
+    in.ety[2] = ETv(L.eta_y, ixm, iy, iz); in.ety[3] = ETv(L.eta_y, ix, iy, iz);
+    in.etz[0] = ETv(L.eta_z, ixm, iym, iz); in.etz[1] = ETv(L.eta_z, ix, iym, iz);
+    in.etz[2] = ETv(L.eta_z, ixm, iy, iz); in.etz[3] = ETv(L.eta_z, ix, iy, iz);
+}
+
+// the operands of cell (ix,iy,iz), iz >= 1, when `in` still holds those of cell (ix,iy,iz-1): what lay in plane
+// iz (izp of the cell below) moves to this cell's own plane, what lay in the cell's plane moves to izm; only the
+// rest is loaded
+template <class T> EMG_HD void residual_load_roll(const Level<T> &L, int ix, int iy, int iz, ResIn<T> &in)
+{
+    const Axes<T, 0> A(L);
+    const int ixm = ix > 0 ? ix - 1 : 0, iym = iy > 0 ? iy - 1 : 0;
+    const int ixp = ix + 1, iyp = iy + 1, izp = iz + 1;
+    in.hz0 = in.hz1;
+    in.hz1 = L.ihz[iz];
+    // plane iz -> izm
+    in.ex_zm = in.ex_c; in.ey_zm = in.ey_c;
+    in.ez_zm = in.ez_c; in.ez_xp_zm = in.ez_xp; in.ez_yp_zm = in.ez_yp;
+    in.z000 = in.z001; in.z100 = in.z101; in.z010 = in.z011; in.z110 = in.z111;
+    in.etx[0] = in.etx[1]; in.etx[2] = in.etx[3];
+    in.ety[0] = in.ety[2]; in.ety[1] = in.ety[3];
+    // plane izp -> iz
+    in.ex_c = in.ex_zp; in.exm_c = in.exm_zp; in.ey_c = in.ey_zp; in.eym_c = in.eym_zp;
+    // loaded
+    in.ez_c = EZv(ix, iy, iz);
+    in.ex_zp = EXv(ix, iy, izp); in.exm_zp = EXv(ixm, iy, izp);
+    in.ex_yp = EXv(ix, iyp, iz); in.exm_yp = EXv(ixm, iyp, iz); in.ex_ym = EXv(ix, iym, iz);
+    in.ey_zp = EYv(ix, iy, izp); in.eym_zp = EYv(ix, iym, izp);
+    in.ey_xp = EYv(ixp, iy, iz); in.ey_xm = EYv(ixm, iy, iz); in.eym_xp = EYv(ixp, iym, iz);
+    in.ez_yp = EZv(ix, iyp, iz); in.ez_ym = EZv(ix, iym, iz); in.ez_xp = EZv(ixp, iy, iz); in.ez_xm = EZv(ixm, iy, iz);
+    in.z001 = ZT(ixm, iym, iz); in.z101 = ZT(ix, iym, iz); in.z011 = ZT(ixm, iy, iz); in.z111 = ZT(ix, iy, iz);
+    in.etx[1] = ETv(L.eta_x, ix, iym, iz); in.etx[3] = ETv(L.eta_x, ix, iy, iz);
+    in.ety[2] = ETv(L.eta_y, ixm, iy, iz); in.ety[3] = ETv(L.eta_y, ix, iy, iz);
+    in.etz[0] = ETv(L.eta_z, ixm, iym, iz); in.etz[1] = ETv(L.eta_z, ix, iym, iz);
+    in.etz[2] = ETv(L.eta_z, ixm, iy, iz); in.etz[3] = ETv(L.eta_z, ix, iy, iz);
+#undef EXv
+#undef EYv
+#undef EZv
+#undef ZT
+#undef ETv
+}
+
+// The three values of extended cell (ix,iy,iz), ix < nx etc. (the entries core.amat_x touches), from its operands:
+//   SRC:  r = s - A e   (solver.residual)            !SRC:  r = -A e   (the Krylov operator)
+template <class T, bool SRC>
+EMG_HD void residual_compute(const Level<T> &L, const ResIn<T> &in, int ix, int iy, int iz, T &ox, T &oy, T &oz)
+{
+    const Axes<T, 0> A(L);
+    const double hx1 = in.hx1, hx0 = in.hx0, hy1 = in.hy1, hy0 = in.hy0, hz1 = in.hz1, hz0 = in.hz0;
+    const T ex_c = in.ex_c, ey_c = in.ey_c, ez_c = in.ez_c;
+    // 1. curl on the faces around the three edges (core.py:136-155)
+    T v1pp = (in.ez_yp - ez_c) * hy1 - (in.ey_zp - ey_c) * hz1;
+    T v1mp = (ez_c - in.ez_ym) * hy0 - (in.eym_zp - in.eym_c) * hz1;
+    T v1pm = (in.ez_yp_zm - in.ez_zm) * hy1 - (ey_c - in.ey_zm) * hz0;
+
+    T v2pp = (in.ex_zp - ex_c) * hz1 - (in.ez_xp - ez_c) * hx1;
+    T v2mp = (in.exm_zp - in.exm_c) * hz1 - (ez_c - in.ez_xm) * hx0;
+    T v2pm = (ex_c - in.ex_zm) * hz0 - (in.ez_xp_zm - in.ez_zm) * hx1;
+
+    T v3pp = (in.ey_xp - ey_c) * hx1 - (in.ex_yp - ex_c) * hy1;
+    T v3mp = (ey_c - in.ey_xm) * hx0 - (in.exm_yp - in.exm_c) * hy1;
+    T v3pm = (in.eym_xp - in.eym_c) * hx1 - (ex_c - in.ex_ym) * hy0;
+
+    // 2. face averages of zeta (core.py:160-170)
+    v1pp *= in.z011 + in.z111;
+    v1mp *= in.z001 + in.z101;
+    v1pm *= in.z010 + in.z110;
+    v2pp *= in.z101 + in.z111;
+    v2mp *= in.z001 + in.z011;
+    v2pm *= in.z100 + in.z110;
+    v3pp *= in.z110 + in.z111;
+    v3mp *= in.z010 + in.z011;
+    v3pm *= in.z100 + in.z101;
+
+    // 3. second curl (core.py:174-176)
+    T rrx = v3pp * hy1 - v3pm * hy0 - v2pp * hz1 + v2pm * hz0;
+    T rry = v1pp * hz1 - v1pm * hz0 - v3pp * hx1 + v3mp * hx0;
+    T rrz = v2pp * hx1 - v2mp * hx0 - v1pp * hy1 + v1mp * hy0;
+
+    // 4. eta edge sums (core.py:181-186)
+    const T stx = in.etx[0] + in.etx[1] + in.etx[2] + in.etx[3];
+    const T sty = in.ety[0] + in.ety[1] + in.ety[2] + in.ety[3];
+    const T stz = in.etz[0] + in.etz[1] + in.etz[2] + in.etz[3];
+    // PEC rows (core.py:193-198)
+    if (iy == 0 || iz == 0) rrx = zero<T>();
+    if (ix == 0 || iz == 0) rry = zero<T>();
+    if (ix == 0 || iy == 0) rrz = zero<T>();
+
+    // 5. r = s - (0.5 rr - 0.25 st e)   (core.py:204-206)
+    const T ax = 0.5 * rrx - 0.25 * (stx * ex_c), ay = 0.5 * rry - 0.25 * (sty * ey_c), az = 0.5 * rrz - 0.25 * (stz * ez_c);
+    if (SRC) {
+        ox = L.sx[A.iex(ix, iy, iz)] - ax;
+        oy = L.sy[A.iey(ix, iy, iz)] - ay;
+        oz = L.sz[A.iez(ix, iy, iz)] - az;
+    } else {
+        ox = -ax; oy = -ay; oz = -az;
+    }
+}
+
+// (one cell on its own: the compiler interleaves loads and arithmetic -- 92 registers against 170 with the
+// operands gathered first; the rolled column above trades registers for half of the loads)
 // The three values of extended cell (ix,iy,iz), ix < nx etc. (the entries core.amat_x touches):
 //   SRC:  r = s - A e   (solver.residual)            !SRC:  r = -A e   (the Krylov operator)
 template <class T, bool SRC>
@@ -237,6 +378,41 @@ EMG_HD double residual_cell(const Level<T> &L, T *rx, T *ry, T *rz, int ix, int 
             acc += abs2(v);
             if (rz) rz[A.iez(ix, iy, iz)] = v;
         }
+    }
+    return acc;
+}
+
+// The cells (ix, iy, z0 .. z1-1) of one column by one thread, bottom to top: the operands a cell shares with the
+// cell below it (half of the field values, zeta and eta of the plane between them) are carried in registers
+// (residual_load_roll). Same operands, same arithmetic (ONE call site of residual_compute), same order of the
+// sum of squares as a loop over residual_cell.
+template <class T>
+EMG_HD double residual_column(const Level<T> &L, T *rx, T *ry, T *rz, int ix, int iy, int z0, int z1)
+{
+    const Axes<T, 0> A(L);
+    double acc = 0.0;
+    if (ix < L.nx && iy < L.ny) {
+        ResIn<T> in;
+        bool have = false;
+        for (int iz = z0; iz < z1; ++iz) {
+            if (iz < L.nz) {
+                if (have) residual_load_roll<T>(L, ix, iy, iz, in);
+                else residual_load<T>(L, ix, iy, iz, in);
+                have = true;
+                T ox, oy, oz;
+                residual_compute<T, true>(L, in, ix, iy, iz, ox, oy, oz);
+                acc += abs2(ox) + abs2(oy) + abs2(oz);
+                if (rx) {
+                    rx[A.iex(ix, iy, iz)] = ox;
+                    ry[A.iey(ix, iy, iz)] = oy;
+                    rz[A.iez(ix, iy, iz)] = oz;
+                }
+            } else {
+                acc += residual_cell<T>(L, rx, ry, rz, ix, iy, iz);      // the top plane: r = s on ex / ey
+            }
+        }
+    } else {
+        for (int iz = z0; iz < z1; ++iz) acc += residual_cell<T>(L, rx, ry, rz, ix, iy, iz);
     }
     return acc;
 }
