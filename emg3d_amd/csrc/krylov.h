@@ -134,28 +134,38 @@ __global__ __launch_bounds__(KRY_BLOCK) void k_kry_finish(const double *partial,
 
 // out = A x for a vector x laid out like a field (the Krylov operator of emg3d/solver.py:686-702:
 // core.amat_x into a zero field, negated): the residual kernel with the source switched off.
+// A workgroup walks `zb` consecutive planes (like k_residual): a thread carries the operands a cell shares with
+// the cell below it in registers (stencil.h: residual_load_roll) -- 28 instead of 53 loads per cell, same values.
 template <class T>
-__global__ __launch_bounds__(256) void k_apply_operator(emg::Level<T> L0, T *ox, T *oy, T *oz, int nzp)
+__global__ __launch_bounds__(256) void k_apply_operator(emg::Level<T> L0, T *ox, T *oy, T *oz, int nzb, int zb)
 {
-    const int b = blockIdx.z / nzp;
+    const int b = blockIdx.z / nzb;
     emg::Level<T> L = emg::source_level(L0, b);
     ox += b * L0.bstride; oy += b * L0.bstride; oz += b * L0.bstride;
     const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y * blockDim.y + threadIdx.y;
-    const int iz = blockIdx.z - b * nzp;
+    const int z0 = (blockIdx.z - b * nzb) * zb, z1 = min(z0 + zb, L.nz + 1);
     if (ix > L.nx || iy > L.ny) return;
     const emg::Axes<T, 0> A(L);
     // r = 0 - A e on the entries core.amat_x touches, 0 elsewhere; A e = -r
-    const bool inx = ix < L.nx, iny = iy < L.ny, inz = iz < L.nz;
-    if (inx && iny && inz) {
-        T rx, ry, rz;
-        emg::residual_values<T, false>(L, ix, iy, iz, rx, ry, rz);
-        ox[A.iex(ix, iy, iz)] = -rx;
-        oy[A.iey(ix, iy, iz)] = -ry;
-        oz[A.iez(ix, iy, iz)] = -rz;
-    } else {
-        if (inx) ox[A.iex(ix, iy, iz)] = emg::zero<T>();
-        if (iny) oy[A.iey(ix, iy, iz)] = emg::zero<T>();
-        if (inz) oz[A.iez(ix, iy, iz)] = emg::zero<T>();
+    const bool inx = ix < L.nx, iny = iy < L.ny;
+    emg::ResIn<T> in;
+    bool have = false;
+    for (int iz = z0; iz < z1; ++iz) {
+        const bool inz = iz < L.nz;
+        if (inx && iny && inz) {
+            T rx, ry, rz;
+            if (have) emg::residual_load_roll<T>(L, ix, iy, iz, in);
+            else emg::residual_load<T>(L, ix, iy, iz, in);
+            have = true;
+            emg::residual_compute<T, false>(L, in, ix, iy, iz, rx, ry, rz);
+            ox[A.iex(ix, iy, iz)] = -rx;
+            oy[A.iey(ix, iy, iz)] = -ry;
+            oz[A.iez(ix, iy, iz)] = -rz;
+        } else {
+            if (inx) ox[A.iex(ix, iy, iz)] = emg::zero<T>();
+            if (iny) oy[A.iey(ix, iy, iz)] = emg::zero<T>();
+            if (inz) oz[A.iez(ix, iy, iz)] = emg::zero<T>();
+        }
     }
 }
 
@@ -206,14 +216,18 @@ int emg3d_dev_apply_operator(const emg3d_level *lv, void *ox, void *oy, void *oz
 {
     if (!lv || !ox || !oy || !oz) return fail(EMG3D_ERR_BADARG, "apply_operator: bad argument");
     const dim3 block = d3(emg::cell_block());
-    const dim3 grid = d3(emg::cell_grid(lv->nx + 1, lv->ny + 1, lv->nz + 1));
+    dim3 grid = d3(emg::cell_grid(lv->nx + 1, lv->ny + 1, lv->nz + 1));
     const int batch = lv->batch > 1 ? lv->batch : 1;
+    // planes per workgroup: as in the residual kernel (8 where that still leaves every CU several workgroups)
+    const int zb = (g_residual_roll && (size_t)grid.x * grid.y * (grid.z / g_residual_zb) >= 8u * (unsigned)compute_units())
+                       ? g_residual_zb : 1;
+    grid.z = cdiv((int)grid.z, zb);
     if (lv->is_complex)
         hipLaunchKernelGGL(k_apply_operator<cplx>, dim3(grid.x, grid.y, grid.z * batch), block, 0, (hipStream_t)stream,
-                           to_level<cplx>(lv), (cplx *)ox, (cplx *)oy, (cplx *)oz, (int)grid.z);
+                           to_level<cplx>(lv), (cplx *)ox, (cplx *)oy, (cplx *)oz, (int)grid.z, zb);
     else
         hipLaunchKernelGGL(k_apply_operator<double>, dim3(grid.x, grid.y, grid.z * batch), block, 0, (hipStream_t)stream,
-                           to_level<double>(lv), (double *)ox, (double *)oy, (double *)oz, (int)grid.z);
+                           to_level<double>(lv), (double *)ox, (double *)oy, (double *)oz, (int)grid.z, zb);
     HIP_TRY(hipGetLastError());
     return 0;
 }
