@@ -1627,6 +1627,8 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
                          size_t vstride, int b0, int lpw, hipStream_t st)
 {
     // one source: the coupling entries through a second ring (option line_stream_lf, default 1)
+    // (for groups of two the second ring leaves room for 8 rows per chunk only: y / z lines 0.83 -> 0.79-0.82 x per
+    // source, x-lines 0.82 -> 0.93 x -- measured, not adopted)
     const bool lfr = B == 1 && g_line_stream_lf != 0;
     int R = stream_rows(B, sizeof(T), lfr);
     const size_t smem = (size_t)2 * B * 2 * R * lpw * 5 * sizeof(T) + (lfr ? (size_t)2 * 2 * R * lpw * 8 * sizeof(double) : 0);
