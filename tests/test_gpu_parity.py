@@ -1751,7 +1751,7 @@ def test_line_factor_policy_rebuild_equals_resident(kw):
 def test_512_cubed_w_cycle_with_rebuilt_line_factors():
     """512^3 (134 M cells, 403 M unknowns) on ONE GPU: the tri-axial workload of config 3 at twice its edge length,
     W-cycle with semicoarsening and line relaxation, hierarchy policy 'rebuild' (two line-factor buffers per level:
-    with all three directions resident the hierarchy would need ~315 GB). One cycle reduces the error
+    233 GB for the whole hierarchy against 274 GB with every direction resident). One cycle reduces the error
     by more than an order of magnitude (tools/big_cube.py compared this very cycle with the oracle in the same
     ordering: 1.1e-12 rel-L2, profiles/r04_big_cube.txt), and the operator on the finest level keeps the
     size-independent properties of test_full_size_operator_properties: linear, complex symmetric, residual(0) = s."""
