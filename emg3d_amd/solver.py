@@ -534,11 +534,11 @@ class Hierarchy:
 
     def __init__(self, vmodel, device=None, batch=1, line_factors=None):
         """line_factors: 'resident' (default; or the environment's EMG3D_AMD_LINE_FACTORS) keeps the line
-        factorisation of every direction a level has used in HBM -- 304 B per cell and direction, ~1.5 kB per
-        cell of the finest level for the whole hierarchy with three directions; 'rebuild' keeps two directions
-        per level and re-factorises on change (``DeviceLevel._line_factor_slots``): ~1.1 kB per cell, one
-        more factorisation per level and cycle when the line-relaxation code cycles; 'single' keeps one
-        direction per level and re-factorises at every change of direction."""
+        factorisation of every direction a level has used in HBM -- 304 B per cell and direction, ~2.0 kB per
+        finest-level cell for a whole semicoarsened hierarchy with three directions; 'rebuild' keeps two directions
+        per level and re-factorises on change (``DeviceLevel._line_factor_slots``): ~1.7 kB per cell, one more
+        factorisation per level and cycle when the line-relaxation code cycles (+8 % per cycle); 'single' keeps one
+        direction per level and re-factorises at every change of direction: ~1.1 kB per cell, +47 %."""
         self.device = device or _device()
         line_factors = line_factors or os.environ.get('EMG3D_AMD_LINE_FACTORS', 'resident')
         self.line_factors = line_factors
