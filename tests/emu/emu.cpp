@@ -8,6 +8,8 @@
 // package never loads it, and nothing here is reachable from emg3d_amd/.
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -306,6 +308,49 @@ void emu_line_blocks(const LevelArgs *lv, int dir, int i1, int i2, void *dg_, do
         }
     };
     if (dir == 0) run(emg::Axes<cplx, 0>(L)); else if (dir == 1) run(emg::Axes<cplx, 1>(L)); else run(emg::Axes<cplx, 2>(L));
+}
+
+// Residual through the column walk of the HIP kernels (stencil.h: residual_column -- operands shared by vertically
+// adjacent cells carried from cell to cell), `zb` planes per walk; returns sum |r|^2.
+double emu_residual_column(const LevelArgs *lv, void *rx, void *ry, void *rz, int zb)
+{
+    double acc = 0.0;
+    auto run = [&](auto L, auto *px, auto *py, auto *pz) {
+        using T = std::remove_pointer_t<decltype(px)>;
+        for (int z0 = 0; z0 <= L.nz; z0 += zb)
+            for (int iy = 0; iy <= L.ny; ++iy)
+                for (int ix = 0; ix <= L.nx; ++ix)
+                    acc += emg::residual_column<T>(L, px, py, pz, ix, iy, z0, std::min(z0 + zb, L.nz + 1));
+    };
+    if (lv->is_complex) run(to_level<cplx>(lv), (cplx *)rx, (cplx *)ry, (cplx *)rz);
+    else run(to_level<double>(lv), (double *)rx, (double *)ry, (double *)rz);
+    return acc;
+}
+
+// The coupling entries k_line_stream's producers recompute (stencil.h: line_coupling) against the lfac records the
+// set-up stores for one line: number of the 8 x (records the half-chains read) doubles that differ (bitwise).
+int emu_line_coupling_mismatches(const LevelArgs *lv, int dir, int i1, int i2)
+{
+    const emg::Level<cplx> L = to_level<cplx>(lv);
+    int bad = 0;
+    auto run = [&](auto A, auto dirtag) {
+        constexpr int DIR = decltype(dirtag)::value;
+        const int n0 = A.n0(), n0p = emg::line_padded(n0), mk = emg::line_mid(n0);
+        std::vector<cplx> fac((size_t)15 * n0p);
+        std::vector<double> lfac((size_t)8 * n0p);
+        emg::line_setup<cplx, DIR>(L, i1, i2, fac.data(), lfac.data(), 1, 0, n0p);
+        for (int k = 0; k < n0p; ++k) {
+            if (k == mk || k == mk + 1) continue;          // the middle records are read from lfac by the kernels
+            double c[8];
+            emg::line_coupling<cplx, DIR>(A, k, i1, i2, k >= mk + 2, c);
+            for (int r = 0; r < 8; ++r)
+                if (std::memcmp(&c[r], &lfac[(size_t)k * 8 + r], sizeof(double)) != 0 && !(c[r] == 0.0 && lfac[(size_t)k * 8 + r] == 0.0)) ++bad;
+        }
+    };
+    if (dir == 0) run(emg::Axes<cplx, 0>(L), std::integral_constant<int, 0>());
+    else if (dir == 1) run(emg::Axes<cplx, 1>(L), std::integral_constant<int, 1>());
+    else run(emg::Axes<cplx, 2>(L), std::integral_constant<int, 2>());
+    return bad;
 }
 
 void emu_solve(void *amat, void *bvec, int n, int is_complex)

@@ -28,6 +28,7 @@ def lib():
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.emu_residual.restype = ctypes.c_double
+        _lib.emu_residual_column.restype = ctypes.c_double
     return _lib
 
 
@@ -76,6 +77,21 @@ def residual(e, s, vm, r=None):
     if r is None:
         return lib().emu_residual(ctypes.byref(lv), None, None, None)
     return lib().emu_residual(ctypes.byref(lv), _ptr(r.fx), _ptr(r.fy), _ptr(r.fz))
+
+
+def residual_column(e, s, vm, r, zb):
+    """The residual through the HIP kernels' column walk (operands carried from cell to cell), zb planes per walk."""
+    keep = []
+    lv = make_level(e, s, vm, keep)
+    return lib().emu_residual_column(ctypes.byref(lv), _ptr(r.fx), _ptr(r.fy), _ptr(r.fz), int(zb))
+
+
+def line_coupling_mismatches(e, s, vm, direction, i1, i2):
+    """Number of recomputed coupling entries (stencil.h: line_coupling) that differ bitwise from the stored lfac
+    records of line (i1, i2) of the direction."""
+    keep = []
+    lv = make_level(e, s, vm, keep)
+    return lib().emu_line_coupling_mismatches(ctypes.byref(lv), int(direction), int(i1), int(i2))
 
 
 def line_blocks(e, s, vm, direction, i1, i2):

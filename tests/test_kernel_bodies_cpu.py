@@ -328,3 +328,43 @@ def test_bench_workloads_build():
             for d in range(3):
                 assert wl['origin'][d] < wl['source'][d] < wl['origin'][d] + wl['h'][d].sum()
     assert {workload('salt96', i)['frequency'] for i in range(8)} == {0.25, 0.5, 1.0, 2.0}
+
+
+@pytest.mark.parametrize('shape', [(9, 12, 7), (24, 6, 10), (5, 5, 40)])
+def test_recomputed_coupling_entries_equal_the_stored_records(shape):
+    """k_line_stream's producers recompute the eight coupling entries of a block from zeta and the widths
+    (stencil.h: line_coupling) instead of fetching the lfac record: for every line direction, several lines and
+    every record the half-chains read (top blocks, mirrored blocks, the last block, the identity padding) the
+    recomputed values must equal the set-up's stored ones bit for bit."""
+    rng = np.random.default_rng(sum(shape))
+    h = [rng.uniform(5., 15., n) * 1.1 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    vm = mg_ref.volume_model(grid, 0.7, *[10 ** rng.uniform(-1, 1, shape) for _ in range(3)],
+                             mu_r=rng.uniform(0.8, 2.0, shape))
+    e, s = mg_ref.Field(grid), mg_ref.Field(grid)
+    for direction in (0, 1, 2):
+        n1 = shape[(direction + 1) % 3]
+        n2 = shape[(direction + 2) % 3]
+        for i1, i2 in ((1, 1), (n1 - 1, n2 - 1), (max(n1 // 2, 1), 1), (1, max(n2 // 2, 1))):
+            assert emu.line_coupling_mismatches(e, s, vm, direction, i1, i2) == 0, (direction, i1, i2)
+
+
+@pytest.mark.parametrize('dtype', [complex, float])
+@pytest.mark.parametrize('zb', [1, 3, 8])
+def test_residual_column_walk_equals_cell_by_cell(dtype, zb):
+    """The residual kernels walk a column of cells and carry the operands a cell shares with the cell below it
+    (stencil.h: residual_load_roll): same values, same norm as cell by cell, bit for bit, for any number of planes
+    per walk (also when the walk ends on the top boundary plane)."""
+    shape = (7, 9, 11)
+    rng = np.random.default_rng(zb)
+    h = [rng.uniform(5., 15., n) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    vm = mg_ref.volume_model(grid, 0.7 if dtype is complex else -0.7, *[10 ** rng.uniform(-1, 1, shape) for _ in range(3)])
+    e, s = mg_ref.Field(grid, dtype=dtype), mg_ref.Field(grid, dtype=dtype)
+    for f in (e, s):
+        f.field[:] = rng.standard_normal(f.field.size) + (1j * rng.standard_normal(f.field.size) if dtype is complex else 0)
+    r1, r2 = mg_ref.Field(grid, dtype=dtype), mg_ref.Field(grid, dtype=dtype)
+    n1 = emu.residual(e, s, vm, r1)
+    n2 = emu.residual_column(e, s, vm, r2, zb)
+    assert np.array_equal(r1.field, r2.field)
+    assert n2 == pytest.approx(n1, rel=1e-13)

@@ -2,7 +2,11 @@
 differ by up to 8 % with one binary, so a change is only visible when both builds run on ONE box, interleaved.
     python tools/ab_cycle.py emg3d_amd/lib/libemg3d_amd_r03.so [workload] [rounds]
 The other build is loaded in a child process with the entry points it lacks stubbed (older builds have no
-emg3d_options_generation / emg3d_line_kernel_name)."""
+emg3d_options_generation / emg3d_line_kernel_name). Built libraries are not in the history; an older one is made from
+its commit, e.g. the library of the end of round 3:
+    mkdir /tmp/r03 && git archive 57cc31a emg3d_amd/csrc include | tar x -C /tmp/r03 && \
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared /tmp/r03/emg3d_amd/csrc/kernels.hip -o emg3d_amd/lib/libemg3d_amd_r03.so
+AB_VARIANTS="opt=value;opt2=value ..." adds runs of the current build under library options."""
 import json, os, subprocess, sys
 root = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
