@@ -1405,15 +1405,11 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
     const int half = wave & 1;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
-#ifndef LSB_NO_FWD
     if (half == 0) quad_forward_stream<T, 0, RD, B, LFR>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks, lfring);
     else quad_forward_stream<T, 1, RD, B, LFR>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks, lfring);
-#endif
     __syncthreads();
-#ifndef LSB_NO_BWD
     if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR, LFR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks, lfring);
     else quad_backward_stream<T, DIR, 1, RD, B, PAIR, LFR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks, lfring);
-#endif
 }
 
 #pragma clang fp contract(fast)      // (end of the spelled-out section: the compiler's default again)
