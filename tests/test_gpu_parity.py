@@ -624,6 +624,27 @@ def test_streamed_line_kernel_is_bit_identical(shape, lr, dtype):
     assert np.array_equal(out[2], out[0])
 
 
+SHORT_SHAPES = [((2, 37, 11), 1), ((3, 36, 12), 1), ((4, 150, 5), 1), ((5, 33, 9), 1), ((6, 40, 40), 1),
+                ((8, 70, 9), 1), ((9, 34, 35), 1), ((10, 20, 90), 1), ((130, 4, 4), 2), ((70, 5, 8), 2),
+                ((41, 6, 4), 2), ((35, 8, 37), 2), ((12, 10, 300), 2), ((256, 4, 4), 3), ((9, 70, 3), 3),
+                ((20, 21, 6), 3), ((66, 8, 8), 3), ((8, 8, 9), 3), ((5, 4, 10), 3)]
+
+
+@pytest.mark.parametrize('shape,lr', SHORT_SHAPES)
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_short_lines_vs_oracle(shape, lr, dtype):
+    """Every short line length (2, 3, 4, 5, 6 blocks: padding granule 2; 8, 9, 10: halves of exactly one register ring,
+    with and without identity padding) on rod-, slab- and cube-shaped levels (1 ... 75 lines per colour class,
+    workgroups of 4, 8 and 16 lines, surplus quads): nu = 3 sweeps against the oracle in the same ordering."""
+    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + 7 * lr)
+    a, b = e0.copy(), e0.copy()
+    args = (s0.fx, s0.fy, s0.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
+    getattr(ocore, SMOOTHERS[lr])(a.fx, a.fy, a.fz, *args, order=1)
+    getattr(core, SMOOTHERS[lr])(b.fx, b.fy, b.fz, *args)
+    assert np.any(b.field != e0.field)
+    assert relerr(b.field, a.field) < 1e-11
+
+
 def _random_level_fields(shape, dtype, seed, freq=0.7, extras=False):
     """Stretched random tri-axial model on `shape` (oracle volume model) with random source / start fields
     (PEC faces of the start field zero); extras: with epsilon_r and mu_r (eta gets a real part)."""
