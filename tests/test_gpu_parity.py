@@ -627,15 +627,19 @@ def test_streamed_line_kernel_is_bit_identical(shape, lr, dtype):
 SHORT_SHAPES = [((2, 37, 11), 1), ((3, 36, 12), 1), ((4, 150, 5), 1), ((5, 33, 9), 1), ((6, 40, 40), 1),
                 ((8, 70, 9), 1), ((9, 34, 35), 1), ((10, 20, 90), 1), ((130, 4, 4), 2), ((70, 5, 8), 2),
                 ((41, 6, 4), 2), ((35, 8, 37), 2), ((12, 10, 300), 2), ((256, 4, 4), 3), ((9, 70, 3), 3),
-                ((20, 21, 6), 3), ((66, 8, 8), 3), ((8, 8, 9), 3), ((5, 4, 10), 3)]
+                ((20, 21, 6), 3), ((66, 8, 8), 3), ((8, 8, 9), 3), ((5, 4, 10), 3),
+                ((7, 30, 31), 1), ((11, 40, 9), 1), ((16, 33, 34), 1), ((33, 70, 6), 1), ((64, 40, 40), 1),
+                ((50, 12, 9), 2), ((9, 24, 70), 2), ((40, 63, 40), 2), ((30, 31, 17), 3), ((70, 5, 32), 3),
+                ((36, 36, 66), 3)]
 
 
 @pytest.mark.parametrize('shape,lr', SHORT_SHAPES)
 @pytest.mark.parametrize('dtype', [complex, float])
 def test_short_lines_vs_oracle(shape, lr, dtype):
-    """Every short line length (2, 3, 4, 5, 6 blocks: padding granule 2; 8, 9, 10: halves of exactly one register ring,
-    with and without identity padding) on rod-, slab- and cube-shaped levels (1 ... 75 lines per colour class,
-    workgroups of 4, 8 and 16 lines, surplus quads): nu = 3 sweeps against the oracle in the same ordering."""
+    """Every short line length (2, 3, 4, 5, 6 blocks: padding granule 2; 7 ... 11: halves of one register ring or
+    none, with and without identity padding) and lines of 12 ... 66 blocks whose records live in LDS, on rod-, slab-
+    and cube-shaped levels (1 ... 400 lines per colour class, workgroups of 4, 8 and 16 lines, surplus quads):
+    nu = 3 sweeps against the oracle in the same ordering."""
     grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + 7 * lr)
     a, b = e0.copy(), e0.copy()
     args = (s0.fx, s0.fy, s0.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
