@@ -992,24 +992,39 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
         V = VecRef<T>::global(vec, (!BATCH && vstride == ~(size_t)0) ? 0 : nlines);
         dum = dum4 = dummy;
     }
-    // (1) right-hand sides of the workgroup's lines; x-lines run the lanes along the line
-    for (int i = threadIdx.x; i < nl * n0p; i += LC_THREADS) {
-        const int ll = DIR == 0 ? i / n0p : i % nl;
-        const int k = DIR == 0 ? i % n0p : i / nl;
+    // (1) right-hand sides of the workgroup's lines; x-lines run the lanes along the line. Only the n0 real blocks
+    // are computed: with the identity padding rows (n0p - n0 = 2 ... 5 of them, rhs = 0) among the items, 16 lines of
+    // 64 blocks were 1 056 items = five rounds of 256 threads instead of four, 8 lines of 32 blocks two instead of one
+    // -- and a round is 3 000 (L2) to 8 500 (HBM) cycles of the launch (profiles/r04_line_phase_stamps.txt)
+    const int n0r = A.n0();
+    for (int i = threadIdx.x; i < nl * n0r; i += LC_THREADS) {
+        const int ll = DIR == 0 ? i / n0r : i % nl;
+        const int k = DIR == 0 ? i % n0r : i / nl;
         const int lid = line0 + ll;
         int i1, i2, l2;
         emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
         T rhs[5];
-        emg::line_rhs<T, DIR>(A, min(k, A.n0() - 1), i1, i2, rhs);
-        const double keep = k < A.n0() ? 1.0 : 0.0;            // identity padding blocks: rhs = 0
+        emg::line_rhs<T, DIR>(A, k, i1, i2, rhs);
         if (VMODE == 3 && (k < V.klo || k >= V.khi)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *V.pg(k, lid, r) = keep * rhs[r];
+            for (int r = 0; r < 4; ++r) *V.pg(k, lid, r) = rhs[r];
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *V.p(k, lid, r) = keep * rhs[r];
+            for (int r = 0; r < 4; ++r) *V.p(k, lid, r) = rhs[r];
         }
-        *V.p4(k, lid) = keep * rhs[4];
+        *V.p4(k, lid) = rhs[4];
+    }
+    // identity padding blocks behind block n0 - 1: rhs = 0 (dealt from the last thread downwards: the helper waves)
+    for (int i = LC_THREADS - 1 - (int)threadIdx.x; i < nl * (n0p - n0r); i += LC_THREADS) {
+        const int k = n0r + i / nl, lid = line0 + i % nl;
+        if (VMODE == 3 && (k < V.klo || k >= V.khi)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *V.pg(k, lid, r) = emg::zero<T>();
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *V.p(k, lid, r) = emg::zero<T>();
+        }
+        *V.p4(k, lid) = emg::zero<T>();
     }
     __syncthreads();
     // chain waves: waves 0 / 1 walk the top / bottom halves of the workgroup's first 16 lines; with
