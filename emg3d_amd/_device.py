@@ -149,8 +149,15 @@ class DeviceLevel:
         memory policy of the whole hierarchy (``line_factors`` / ``_line_factor_slots``)."""
         if line_factors not in ('resident', 'rebuild', 'single'):
             raise ValueError(f"`line_factors` must be 'resident', 'rebuild' or 'single'. Provided: {line_factors!r}.")
-        work = work or Workspace(device)
+        if work is None:
+            work = Workspace(device)
+        elif getattr(work, '_policy_owner', False) and work.factor_policy != line_factors:
+            # a shared workspace carries ONE policy: a second hierarchy with another one would switch the first
+            # hierarchy's levels between the `_factors` and `_slots` schemes under its captured graphs
+            raise ValueError(f"`work` already serves a hierarchy with line_factors={work.factor_policy!r}; "
+                             f"provided: {line_factors!r}.")
         work.factor_policy = line_factors
+        work._policy_owner = True
         if hasattr(vmodel, 'device_arrays'):
             # emg3d_amd.models.VolumeModel: form eta / zeta in HBM from the conductivities
             ex, ey, ez, zeta = vmodel.device_arrays(device)
@@ -232,7 +239,14 @@ class DeviceLevel:
                 return sl['fac'], sl['lfac']
         keep = self.__dict__.get('_factor_keep', ())
         free = [sl for sl in slots if sl['dir'] is None] or [sl for sl in slots if sl['dir'] not in keep]
-        victim = min(free or slots, key=lambda sl: sl['used'])
+        if free:
+            victim = min(free, key=lambda sl: sl['used'])
+        else:
+            # more directions in use than buffers (line-relaxation code 7 = x, y, z with two buffers; any code with
+            # one): under the cyclic access x, y, z, x, ... evicting the LEAST recently used buffer would miss on
+            # every call (three factorisations per smoothing call, what 'single' does with half the memory) --
+            # evict the MOST recently used one: the other buffer stays resident and hits once per round
+            victim = max(slots, key=lambda sl: sl['used'])
         _lib.check(lib.emg3d_dev_line_setup(self._cref, lr, _ptr(victim['fac']), _ptr(victim['lfac']), _stream()),
                    'emg3d_dev_line_setup')
         victim['dir'], victim['used'] = lr, self._slot_clock

@@ -7,6 +7,7 @@
 // no dense contraction and therefore no MFMA use.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,6 +118,11 @@ int g_line_stream_bmin = 64;
 // one source: the coupling entries of a block (8 reals) recomputed by the producer waves from zeta / h and handed
 // to the chain waves through a second LDS ring instead of being fetched from the lfac records (1, default; 0: fetched)
 int g_line_stream_lf = 1;
+// the wide form of the line pass (k_line_wide: four-unknown chains on sixteen lanes per half-line, one thread per
+// block for everything else) on lines of at most this many blocks, where the level holds the N records (launch.h:
+// line_wide_capable -- a function of the level's shape alone, so that buffers sized once stay valid whatever the
+// option says); 0: never
+int g_line_wide = 0;
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
@@ -1045,6 +1051,265 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
     else quad_backward<T, DIR, 1, QD, BATCH, SPLIT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
+// ---- the colour pass of SMALL levels with short dependent chains: k_line_wide ----------------------------
+// (stencil.h, "wide" form.) On the levels where a colour class has fewer lines than the chip has SIMDs a launch of
+// k_line_colour costs what one wave needs to issue its chain: ~130 instructions per block step at one instruction
+// per ~5 cycles, 64 dependent steps for a 64-block line, and as much again for the right-hand sides, the middle
+// block and the set-up of the walks on the shortest lines (profiles/r04_line_phase_stamps.txt). Here the
+// recurrences run in four unknowns with the model-only matrices N_k = (T_k C_k)[1..4, 1..4] (k_line_wide_setup:
+// one more record of 16 entries per block, behind the T records of the direction):
+//   * SIXTEEN lanes per half-line, lane (a, b) holding N_k(a, b): a step is one complex multiply-add per lane and a
+//     two-stage sum -- inside the quads (DPP quad_perm) in even steps, across the quads (DPP row_ror) in odd steps
+//     with the matrix fetched transposed, so that the result lies where the next step wants it: ~25 instructions;
+//   * everything that is not a recurrence -- right-hand sides, g = (T r)[1..4], c = r - C w, w_0, g' = C^T w,
+//     x = T (c - h), the scatter -- by ONE THREAD PER BLOCK (waves 0..2) which keeps r / c, T_k and C_k in registers
+//     from the first phase to the last; the middle blocks (6 x 6) by the threads of wave 3;
+//   * the 4-vectors pass between the block threads and the chain lanes through LDS rows of six entries (four values,
+//     a zero that the lanes without a right-hand-side entry add, a dummy that they store to): no select, no branch
+//     inside the chains.
+// Five phases, four workgroup barriers (LDS only). Same factors T_k as the other line kernels; N_k is one more
+// rounding of T_k C_k, so results agree with them to rounding, not bit for bit -- a level runs ONE of the kernels
+// for every right-hand side (single source and batch alike), whatever the batch size.
+constexpr int LW_THREADS = 256;
+constexpr int LW_BLOCK_THREADS = 192;      // waves 0..2: one thread per top / bottom block; wave 3: the middle blocks
+constexpr int LW_ROW = 6;                  // entries of an LDS row: values 1..4, a zero, a dummy
+// lines per workgroup: at most 8 (two chain waves per half), and every block of them needs a thread
+inline int wide_lpw(int n0) { return std::max(1, std::min(8, LW_BLOCK_THREADS / std::max(n0 - 2, 1))); }
+
+template <class T> __global__ __launch_bounds__(256) void k_line_wide_setup(const T *fac, const double *lfac, T *nfac, size_t nrec)
+{
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    T Tk[15], N[16];
+    double lf[8];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) Tk[j] = fac[r * 15 + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lf[j] = lfac[r * 8 + j];
+    emg::wide_n_record<T>(Tk, lf, N);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) nfac[r * 16 + j] = N[j];
+}
+
+// phase stamps of workgroup 0 (threads 0 and 192), only in the -DEMG_WIDE_STAMPS build of tools/wide_stamps.py
+#ifdef EMG_WIDE_STAMPS
+__device__ unsigned long long g_wide_stamps[32];
+#define WSTAMP(i)                                                                                       \
+    do {                                                                                                \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == LW_BLOCK_THREADS))                   \
+            g_wide_stamps[(threadIdx.x ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime();                 \
+    } while (0)
+#else
+#define WSTAMP(i)
+#endif
+
+// One chain of a 16-lane group: nst steps v <- acc_i - M_i v, M = N (forward) or N^T (BWD), acc_i from / result to
+// the LDS row krow0 + i dk, N from record kmat0 + i dk. v enters (and leaves an even number of steps) with lane
+// (a, b) holding entry b.
+template <class T, bool BWD>
+__device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow, unsigned loff, int krow0, int kmat0,
+                                           int dk, int nst, int l16, T v)
+{
+    const int a = l16 >> 2, b = l16 & 3;
+    const unsigned e1 = 4 * a + b, e2 = 4 * b + a;
+    const unsigned eI = loff + (BWD ? e2 : e1), eII = loff + (BWD ? e1 : e2);
+    const int rdI = b == 0 ? a : 4, wrI = b == 0 ? a : 5;
+    const int rdII = a == 0 ? b : 4, wrII = a == 0 ? b : 5;
+    T nr[4], ac[4];
+    auto fetch = [&](int d, int i) {
+        const int ic = min(i, nst - 1);
+        nr[d] = nbase[(size_t)(kmat0 + ic * dk) * nrow + ((d & 1) ? eII : eI)];
+        ac[d] = rows[(krow0 + ic * dk) * LW_ROW + ((d & 1) ? rdII : rdI)];
+    };
+#pragma unroll
+    for (int d = 0; d < 4; ++d) fetch(d, d);
+    auto step = [&](int d, int i) {
+        T p = emg::nmad(nr[d], v, ac[d]);
+        if (!(d & 1)) {
+            p = xop::add(p, dpp_move<0x4E>(p));    // quad_perm:[2,3,0,1]
+            p = xop::add(p, dpp_move<0xB1>(p));    // quad_perm:[1,0,3,2]
+        } else {
+            p = xop::add(p, dpp_move<0x128>(p));   // row_ror:8
+            p = xop::add(p, dpp_move<0x124>(p));   // row_ror:4
+        }
+        rows[(krow0 + i * dk) * LW_ROW + ((d & 1) ? wrII : wrI)] = p;
+        v = p;
+    };
+    int i = 0;
+    for (; i + 4 <= nst; i += 4) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            step(d, i + d);
+            fetch(d, i + d + 4);
+        }
+    }
+    if (i < nst) {
+        step(0, i);
+        if (i + 1 < nst) {
+            step(1, i + 1);
+            if (i + 2 < nst) step(2, i + 2);
+        }
+    }
+}
+
+template <class T, int DIR, bool BATCH>
+__global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int colour, int cntp, int cntq, int lpw,
+                                                         const T *fac, const double *lfac, const T *nfac)
+{
+    extern __shared__ double2 lw_smem[];
+    WSTAMP(0);
+    const size_t boff = BATCH ? blockIdx.y * L.bstride : 0;
+    const emg::Axes<T, DIR> A(L, boff);
+    const int n0 = A.n0(), mk = emg::line_mid(n0);
+    const int nbt = mk, nbb = n0 - mk - 2, nblk = n0 - 2;
+    const int nlines = cntp * cntq, line0 = blockIdx.x * lpw, nl = min(lpw, nlines - line0);
+    const int rows = n0 + 1;                               // (row n0 of a line: the dummy row)
+    T *const GY = reinterpret_cast<T *>(lw_smem);          // [lpw][rows][LW_ROW]: g, then y
+    T *const GH = GY + (size_t)lpw * rows * LW_ROW;        //                      g', then h
+    const int t = threadIdx.x;
+    const bool isq = t >= LW_BLOCK_THREADS;
+    const int tq = t - LW_BLOCK_THREADS;
+    const bool has = isq ? tq < nl : t < nl * nblk;
+    int ll = 0, j = 0;
+    if (isq) ll = tq;
+    else if (has) {
+        if (DIR == 0) { ll = t / nblk; j = t - ll * nblk; }      // x-lines: the field is contiguous along the line
+        else { j = t / nl; ll = t - j * nl; }
+    }
+    int i1 = 0, i2 = 0, k = 0, mir = 0;
+    T Tk[21], r[6];                                         // block thread: T_k (15), r -> c (5); middle: T_Q (21), r_Q (6)
+    double lf[8], lf2[8];                                   // C_k; middle: B_m, U_{m+1}
+    // ---- (A) right-hand sides, factor records, g --------------------------------------------------
+    if (has) {
+        const int lid = line0 + ll;
+        int l2;
+        emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+        if (!isq) {
+            const emg::WideBlock wb = emg::wide_block(j, mk);
+            k = wb.k; mir = wb.mir;
+            T rb[5];
+            emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
+            const size_t rec = (size_t)k * nlines + lid;
+#pragma unroll
+            for (int q = 0; q < 15; ++q) Tk[q] = fac[rec * 15 + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lf[q] = lfac[rec * 8 + q];
+            T g[4];
+            emg::wide_g<T, 21>(Tk, rb, g);
+            T *const row = GY + ((size_t)ll * rows + k) * LW_ROW;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) row[q] = g[q];
+            row[4] = emg::zero<T>();
+            GH[((size_t)ll * rows + k) * LW_ROW + 4] = emg::zero<T>();
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = rb[q];
+        } else {
+            T rm[5];
+            emg::line_rhs<T, DIR>(A, mk, i1, i2, rm);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = rm[q];
+            r[5] = emg::line_rhs_e0<T, DIR>(A, mk + 1, i1, i2);
+            const size_t rm0 = (size_t)mk * nlines + lid, rm1 = rm0 + nlines;
+#pragma unroll
+            for (int q = 0; q < 15; ++q) Tk[q] = fac[rm0 * 15 + q];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Tk[15 + q] = fac[rm1 * 15 + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { lf[q] = lfac[rm0 * 8 + q]; lf2[q] = lfac[rm1 * 8 + q]; }
+        }
+    }
+    WSTAMP(1);
+    __syncthreads();
+    WSTAMP(2);
+    // the chain groups: waves 0 / 1 the top halves of lines 0..3 / 4..7, waves 2 / 3 their bottom halves -- a wave's
+    // groups all walk the same number of steps; groups beyond the last line repeat it (identical stores)
+    const int wave = t >> 6, lane = t & 63, half = wave >> 1;
+    const int cl = min((wave & 1) * 4 + (lane >> 4), nl - 1);
+    const bool chain_wave = (wave & 1) * 4 < nl;
+    const T *const nbase = nfac + (size_t)line0 * 16;
+    const size_t nrow = (size_t)nlines * 16;
+    // ---- (F) forward chains: y_k = g_k - N_k y_kn ---------------------------------------------------
+    {
+        const int nst = half ? nbb : nbt;
+        if (chain_wave && nst > 0)
+            wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, nbase, nrow, (unsigned)cl * 16, half ? n0 - 1 : 0,
+                                 half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>());
+    }
+    WSTAMP(3);
+    __syncthreads();
+    WSTAMP(4);
+    // ---- (C) per block: c = r - C w_kn, w_0, g' = C^T w; the middle blocks -----------------------------
+    if (has) {
+        if (!isq) {
+            const int kn = mir ? k + 1 : k - 1;
+            const bool first = mir ? k == n0 - 1 : k == 0;
+            const T *const yr = GY + ((size_t)ll * rows + (first ? k : kn)) * LW_ROW;
+            const T *const yo = GY + ((size_t)ll * rows + k) * LW_ROW;
+            T yp[4], y[4], c[5], rb[5], gp[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { yp[q] = yr[q]; y[q] = yo[q]; }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) rb[q] = r[q];
+            emg::wide_c<T>(lf, rb, yp, c);
+            const T w0 = emg::wide_row5<T, 21>(Tk, 0, c);
+            emg::wide_gp<T>(lf, w0, y, gp);
+            T *const o = GH + ((size_t)ll * rows + (first ? n0 : kn)) * LW_ROW;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = gp[q];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = c[q];
+        } else {
+            const T *const yt = GY + ((size_t)ll * rows + max(mk - 1, 0)) * LW_ROW;
+            const T *const yb = GY + ((size_t)ll * rows + min(mk + 2, n0 - 1)) * LW_ROW;
+            T yT[4], yB[4], xq[6], hT[4], hB[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const T vt = yt[q], vb = yb[q];
+                yT[q] = nbt > 0 ? vt : emg::zero<T>();
+                yB[q] = nbb > 0 ? vb : emg::zero<T>();
+            }
+            emg::wide_middle<T>(Tk, lf, lf2, r, yT, yB, xq, hT, hB);
+            T *const ot = GH + ((size_t)ll * rows + (nbt > 0 ? mk - 1 : n0)) * LW_ROW;
+            T *const ob = GH + ((size_t)ll * rows + (nbb > 0 ? mk + 2 : n0)) * LW_ROW;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ot[q] = hT[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ob[q] = hB[q];
+            const T xs[5] = {xq[0], xq[1], xq[2], xq[3], xq[4]};
+            emg::wide_block_scatter<T, DIR>(A, mk, 0, i1, i2, xs);
+            A.E(0)[A.idx(0, mk + 1, i1, i2)] = xq[5];
+        }
+    }
+    WSTAMP(5);
+    __syncthreads();
+    WSTAMP(6);
+    // ---- (B) backward chains: h_k = g'_k - N_kp^T h_kp, outwards from the block next to the middle ------------
+    {
+        const int nst = (half ? nbb : nbt) - 1;
+        if (chain_wave && nst > 0) {
+            const int kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
+            T *const rw = GH + (size_t)cl * rows * LW_ROW;
+            const T v0 = rw[kb0 * LW_ROW + (lane & 3)];
+            wide_chain<T, true>(rw, nbase, nrow, (unsigned)cl * 16, kb0 + dk, kb0, dk, nst, lane & 15, v0);
+        }
+    }
+    WSTAMP(7);
+    __syncthreads();
+    WSTAMP(8);
+    // ---- (E) per block: x = T (c - h), scatter ------------------------------------------------------
+    if (has && !isq) {
+        const T *const hr = GH + ((size_t)ll * rows + k) * LW_ROW;
+        T h[4], c[5], x[5];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = hr[q];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) c[q] = r[q];
+        emg::wide_x<T, 21>(Tk, c, h, x);
+        emg::wide_block_scatter<T, DIR>(A, k, mir, i1, i2, x);
+    }
+    WSTAMP(9);
+}
+
 // ---- fused colour pass with STREAMED records (the largest levels): k_line_stream -----------------
 // k_line_colour runs right-hand sides, forward and backward substitution one after the other, and
 // on the levels whose records do not fit the LDS of a CU the right-hand sides make a round trip
@@ -1633,6 +1898,12 @@ template <class T> LinePlan line_plan(const emg::LineClass &lc, int batch)
     return P;
 }
 
+// does the direction run k_line_wide on this level? (option line_wide = longest line; the level must hold N records)
+inline bool line_wide_used(int dir, int nx, int ny, int nz)
+{
+    return g_line_wide > 0 && emg::line_n0(dir, nx, ny, nz) <= g_line_wide && emg::line_nfac_elems(dir, nx, ny, nz) > 0;
+}
+
 template <class T, int DIR, int B>
 void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const T *f, const double *lf, T *vec,
                          size_t vstride, int b0, int lpw, hipStream_t st)
@@ -1672,6 +1943,17 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
     const size_t vstride = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz);    // scratch of one right-hand side
     const size_t dummy_off = vstride - emg::LINE_DUMMY;
+    if (line_wide_used(DIR, L.nx, L.ny, L.nz)) {
+        const int lpw = wide_lpw(lc.n0);
+        const size_t smem = (size_t)2 * lpw * (lc.n0 + 1) * LW_ROW * sizeof(T);
+        const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + lc.fac_off / 15 * 16;
+        const dim3 grid(cdiv(lc.lines, lpw), L.batch);
+        if (L.batch > 1)
+            hipLaunchKernelGGL((k_line_wide<T, DIR, true>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
+        else
+            hipLaunchKernelGGL((k_line_wide<T, DIR, false>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
+        return;
+    }
     const LinePlan P = line_plan<T>(lc, L.batch);
     if (P.kind == LK_STREAM) {
         // groups of at most LSB_MAX right-hand sides, as even as possible (8 -> 4 + 4, 6 -> 3 + 3, 5 -> 3 + 2)
@@ -1868,6 +2150,11 @@ void launch_line_setup_dir(const emg::Level<T> &L, T *fac, double *lfac, hipStre
         }
     }
     if (gx > 0 && gy > 0) hipLaunchKernelGGL((k_line_setup<T, DIR>), dim3(gx, gy, 4), dim3(128), 0, st, L, S, fac, lfac);
+    // the N records of the wide form, behind the T records (one per block record, from its T and coupling entries)
+    const size_t nrec = emg::line_records(DIR, L.nx, L.ny, L.nz);
+    if (gx > 0 && gy > 0 && emg::line_nfac_elems(DIR, L.nx, L.ny, L.nz) > 0)
+        hipLaunchKernelGGL(k_line_wide_setup<T>, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, (const T *)fac,
+                           (const double *)lfac, fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz), nrec);
 }
 
 template <class T>
@@ -2033,6 +2320,7 @@ static const OptionEntry g_options[] = {
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
+    {"line_wide", &g_line_wide},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value
@@ -2066,12 +2354,20 @@ int emg3d_set_option(const char *name, int value)
 
 int emg3d_options_generation(void) { return g_options_generation; }
 
+#ifdef EMG_WIDE_STAMPS
+int emg3d_debug_wide_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
+
 const char *emg3d_line_kernel_name(int lr, int nx, int ny, int nz, int is_complex, int batch)
 {
     if (lr < 1 || lr > 3 || nx < 2 || ny < 2 || nz < 2) return "";
     // the largest colour class (odd, odd) decides, as it does for the scratch size
     const emg::LineClass lc = emg::line_class(lr - 1, nx, ny, nz, 3);
     if (lc.lines <= 0) return "";
+    if (line_wide_used(lr - 1, nx, ny, nz)) return "k_line_wide";
     const LinePlan P = is_complex ? line_plan<cplx>(lc, batch > 1 ? batch : 1) : line_plan<double>(lc, batch > 1 ? batch : 1);
     switch (P.kind) {
     case LK_STREAM: return "k_line_stream";
@@ -2104,7 +2400,7 @@ size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex)
 size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex)
 {
     if (lr < 1 || lr > 3) return 0;
-    return emg::line_fac_elems(lr - 1, nx, ny, nz) * (is_complex ? 16 : 8);
+    return (emg::line_fac_elems(lr - 1, nx, ny, nz) + emg::line_nfac_elems(lr - 1, nx, ny, nz)) * (is_complex ? 16 : 8);
 }
 
 size_t emg3d_line_lfac_bytes(int lr, int nx, int ny, int nz)

@@ -585,6 +585,17 @@ inline size_t line_fac_elems(int dir, int nx, int ny, int nz)
 {
     return (size_t)15 * line_padded(line_n0(dir, nx, ny, nz)) * line_total(dir, nx, ny, nz);
 }
+// block records of a direction (all classes), and the elements of the N records of the wide form (kernels.hip:
+// k_line_wide) that follow the T records in the factor buffer of a level that can take it
+inline size_t line_records(int dir, int nx, int ny, int nz)
+{
+    return (size_t)line_padded(line_n0(dir, nx, ny, nz)) * line_total(dir, nx, ny, nz);
+}
+inline size_t line_nfac_elems(int dir, int nx, int ny, int nz)
+{
+    const size_t rec = line_records(dir, nx, ny, nz);
+    return line_wide_capable(line_n0(dir, nx, ny, nz), rec) ? 16 * rec : 0;
+}
 inline size_t line_lfac_elems(int dir, int nx, int ny, int nz)
 {
     return (size_t)8 * line_padded(line_n0(dir, nx, ny, nz)) * line_total(dir, nx, ny, nz);

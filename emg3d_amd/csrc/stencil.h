@@ -1493,6 +1493,246 @@ EMG_HD void line_scatter(const Axes<T, DIR> &A, int k, int i1, int i2, const T *
     }
 }
 
+// ---- the same line solve with SHORT dependent chains ("wide" form; kernels.hip: k_line_wide) ----------
+// On the small levels of a hierarchy a colour class has fewer lines than the chip has SIMDs, and a launch
+// costs what ONE wave needs to issue the instructions of its chain (a lone wave issues one instruction per
+// ~5 cycles whatever its kind; the step above is ~130 of them). The coupling blocks C_k (B_k / U_k) have the
+// shape e0 l0^T + diag(0, d): of the previous block's w only entries 1..4 enter the next one. So the
+// recurrences can be restated in FOUR unknowns with a model-only 4 x 4 matrix, and everything else of the
+// solve becomes independent per block:
+//
+//   forward   y_k = g_k - N_k y_kn            y_k = w_k[1..4],  g_k = (T_k r_k)[1..4],  N_k = (T_k C_k)[1..4, 1..4]
+//                                             (kn = the block before k in forward order; C of the first block is 0)
+//   per block c_k = r_k - C_k w_kn  (needs y_kn only),   w_k[0] = (T_k c_k)[0],   g'_kn = C_k^T w_k
+//   middle    x_Q as in line_middle (needs y of the two blocks next to it), h of the two blocks next to it
+//   backward  h_k = g'_k - N_kp^T h_kp        h_k = C_kp^T x_kp (entry 0 is zero),  kp = the block before k in
+//                                             backward order;  (C^T T)[1..4, 1..4] = N^T because T is symmetric
+//   per block x_k = T_k (c_k - h_k)
+//
+// The 16 entries of N_k sit in 16 lanes: one complex multiply-add per lane and a two-stage sum per step --
+// within the quads (DPP quad_perm) in even steps, across the quads (DPP row_ror) in odd steps, with the
+// matrix fetched transposed in odd steps, so that the result of one step already lies where the next step needs
+// it. ~25 instructions per step instead of ~130. It is the same direct solve of the line system as
+// core.solve (emg3d/core.py:1481-1616), with the same factors T_k; N_k is one more rounding of T_k C_k.
+// The functions below are the per-block arithmetic shared by the kernel and by line_wide_ref (the CPU walk of
+// the unit tests); the sums of a chain step are associated (p0 + p2) + (p1 + p3) everywhere. Every product that
+// feeds a sum is an explicit fused multiply-add (cplx.h: mad / nmad), so that the compiler's contraction cannot
+// round an expression differently in the single-source and the batched instantiation of the kernel.
+constexpr int WIDE_N0_MAX = 64;                 // longest lines that can take the wide form
+constexpr size_t WIDE_RECORDS_MAX = (size_t)1 << 19;   // ... on levels with at most this many block records per direction
+EMG_HD bool line_wide_capable(int n0, size_t records) { return n0 >= 2 && n0 <= WIDE_N0_MAX && records <= WIDE_RECORDS_MAX; }
+
+// N = (T C)[1..4, 1..4]: N[4 (a-1) + (b-1)] = T(a,0) l0[b] + T(a,b) d[b]
+template <class T> EMG_HD void wide_n_record(const T (&Tk)[15], const double (&lf)[8], T (&N)[16])
+{
+#pragma unroll
+    for (int a = 1; a < 5; ++a)
+#pragma unroll
+        for (int b = 1; b < 5; ++b) {
+            const T first = lf[b - 1] * Tk[sym(a, 0)];
+            N[4 * (a - 1) + (b - 1)] = mad(lf[3 + b], Tk[sym(a, b)], first);
+        }
+}
+// row `row` of T z for a packed symmetric 5 x 5 (two accumulators, like the chain steps of kernels.hip)
+template <class T, int NT> EMG_HD T wide_row5(const T (&Tk)[NT], int row, const T (&z)[5])
+{
+    const T lo = mad(Tk[sym(row, 4)], z[4], mad(Tk[sym(row, 1)], z[1], mad(Tk[sym(row, 0)], z[0], zero<T>())));
+    const T hi = mad(Tk[sym(row, 3)], z[3], mad(Tk[sym(row, 2)], z[2], zero<T>()));
+    return lo + hi;
+}
+// g = (T r)[1..4]
+template <class T, int NT> EMG_HD void wide_g(const T (&Tk)[NT], const T (&r)[5], T (&g)[4])
+{
+#pragma unroll
+    for (int a = 1; a < 5; ++a) g[a - 1] = wide_row5<T, NT>(Tk, a, r);
+}
+// c = r - C yp  (yp = entries 1..4 of the previous block's w)
+template <class T> EMG_HD void wide_c(const double (&lf)[8], const T (&r)[5], const T (&yp)[4], T (&c)[5])
+{
+    T q0 = lf[0] * yp[0];
+#pragma unroll
+    for (int b = 1; b < 4; ++b) q0 = mad(lf[b], yp[b], q0);
+    c[0] = r[0] - q0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) c[b + 1] = nmad(lf[4 + b], yp[b], r[b + 1]);
+}
+// g' = C^T w  (entries 1..4; w = (w0, y))
+template <class T> EMG_HD void wide_gp(const double (&lf)[8], const T w0, const T (&y)[4], T (&gp)[4])
+{
+#pragma unroll
+    for (int b = 0; b < 4; ++b) gp[b] = mad(lf[b], w0, lf[4 + b] * y[b]);
+}
+// x = T (c - (0, h))
+template <class T, int NT> EMG_HD void wide_x(const T (&Tk)[NT], const T (&c)[5], const T (&h)[4], T (&x)[5])
+{
+    T z[5];
+    z[0] = c[0];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) z[b + 1] = c[b + 1] - h[b];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) x[r] = wide_row5<T, NT>(Tk, r, z);
+}
+// middle block: x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}]) and the h of the two neighbouring blocks,
+// hT = B_m^T x_Q(standard part), hB = U_{m+1}^T x_Q(mirrored part). yT / yB: entries 1..4 of w_{m-1} / w_{m+2}
+// (zeros where that half has no blocks).
+template <class T>
+EMG_HD void wide_middle(const T (&Tq)[21], const double (&lfB)[8], const double (&lfU)[8], const T (&rq)[6],
+                        const T (&yT)[4], const T (&yB)[4], T (&xq)[6], T (&hT)[4], T (&hB)[4])
+{
+    T z[6];
+    T q0 = lfB[0] * yT[0], q5 = lfU[0] * yB[0];
+#pragma unroll
+    for (int b = 1; b < 4; ++b) { q0 = mad(lfB[b], yT[b], q0); q5 = mad(lfU[b], yB[b], q5); }
+    z[0] = rq[0] - q0;
+    z[5] = rq[5] - q5;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) z[b + 1] = nmad(lfU[4 + b], yB[b], nmad(lfB[4 + b], yT[b], rq[b + 1]));
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const T lo = mad(Tq[sym(r, 4)], z[4], mad(Tq[sym(r, 2)], z[2], mad(Tq[sym(r, 0)], z[0], zero<T>())));
+        const T hi = mad(Tq[sym(r, 5)], z[5], mad(Tq[sym(r, 3)], z[3], mad(Tq[sym(r, 1)], z[1], zero<T>())));
+        xq[r] = lo + hi;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        hT[b] = mad(lfB[b], xq[0], lfB[4 + b] * xq[b + 1]);
+        hB[b] = mad(lfU[b], xq[5], lfU[4 + b] * xq[b + 1]);
+    }
+}
+// one chain step on a 4-vector: v <- acc - M v with M = N (transposed = false) or N^T; every entry is summed
+// as (p0 + p2) + (p1 + p3), p_j = (j == 0 ? acc : 0) - M(.,j) v_j -- what the 16 lanes of the kernel compute
+template <class T> EMG_HD void wide_chain_step(const T (&N)[16], bool transposed, const T (&acc)[4], T (&v)[4])
+{
+    T o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        T p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = nmad(transposed ? N[4 * j + r] : N[4 * r + j], v[j], j == 0 ? acc[r] : zero<T>());
+        o[r] = (p[0] + p[2]) + (p[1] + p[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = o[r];
+}
+
+// The blocks of a line in the wide form: item j = 0 .. n0-3 is top block j (j < m) or bottom block j + 2.
+struct WideBlock { int k, mir; };
+EMG_HD WideBlock wide_block(int j, int mk) { return j < mk ? WideBlock{j, 0} : WideBlock{j + 2, 1}; }
+
+// Right-hand side of a block in its own grouping: standard block k = {E0(k), t(k+1)} (record row k), mirrored
+// block k = {E0(k), t(k)} (entry 0 of row k, entries 1..4 of row k - 1).
+template <class T, int DIR>
+EMG_HD void wide_block_rhs(const Axes<T, DIR> &A, int k, int mir, int i1, int i2, T (&r)[5])
+{
+    line_rhs_t<T, DIR>(A, k - mir, i1, i2, r);
+    r[0] = line_rhs_e0<T, DIR>(A, k, i1, i2);
+}
+// scatter of a block's solution (line_scatter, core.py:775-783, in the block's grouping)
+template <class T, int DIR>
+EMG_HD void wide_block_scatter(const Axes<T, DIR> &A, int k, int mir, int i1, int i2, const T (&x)[5])
+{
+    const int node = k - mir + 1;
+    A.E(0)[A.idx(0, k, i1, i2)] = x[0];
+    A.E(1)[A.idx(1, node, i1 - 1, i2)] = x[1];
+    A.E(1)[A.idx(1, node, i1, i2)] = x[2];
+    A.E(2)[A.idx(2, node, i1, i2 - 1)] = x[3];
+    A.E(2)[A.idx(2, node, i1, i2)] = x[4];
+}
+
+// CPU walk of one line in the wide form (unit tests; the specification of k_line_wide): right-hand sides,
+// solve and scatter, in place on the field. nrec: the line's N records (record k at nrec[k * nlines * 16]).
+template <class T, int DIR>
+EMG_HD void line_wide_ref(const Axes<T, DIR> &A, int i1, int i2, int nlines, int lid, const T *fac,
+                          const double *lfac, const T *nfac)
+{
+    const int n0 = A.n0(), mk = line_mid(n0);
+    const int nbt = mk, nbb = n0 - mk - 2;
+    auto rec = [&](int k) { return (size_t)k * nlines + lid; };
+    auto getT = [&](int k, T (&Tk)[15]) { for (int j = 0; j < 15; ++j) Tk[j] = fac[rec(k) * 15 + j]; };
+    auto getC = [&](int k, double (&lf)[8]) { for (int j = 0; j < 8; ++j) lf[j] = lfac[rec(k) * 8 + j]; };
+    auto getN = [&](int k, T (&N)[16]) { for (int j = 0; j < 16; ++j) N[j] = nfac[rec(k) * 16 + j]; };
+    // per-block state (indexed by block k)
+    T r[WIDE_N0_MAX][5], c[WIDE_N0_MAX][5], gy[WIDE_N0_MAX][4], gh[WIDE_N0_MAX][4];
+    for (int j = 0; j < n0 - 2; ++j) {                     // phase A
+        const WideBlock b = wide_block(j, mk);
+        T Tk[15];
+        wide_block_rhs<T, DIR>(A, b.k, b.mir, i1, i2, r[b.k]);
+        getT(b.k, Tk);
+        wide_g<T, 15>(Tk, r[b.k], gy[b.k]);
+    }
+    T rq[6];
+    {
+        T rm[5];
+        line_rhs<T, DIR>(A, mk, i1, i2, rm);
+        for (int j = 0; j < 5; ++j) rq[j] = rm[j];
+        rq[5] = line_rhs_e0<T, DIR>(A, mk + 1, i1, i2);
+    }
+    for (int half = 0; half < 2; ++half) {                 // forward chains
+        const int nb = half ? nbb : nbt, k0 = half ? n0 - 1 : 0, dk = half ? -1 : 1;
+        T v[4] = {zero<T>(), zero<T>(), zero<T>(), zero<T>()};
+        for (int i = 0; i < nb; ++i) {
+            const int k = k0 + i * dk;
+            T N[16];
+            getN(k, N);
+            wide_chain_step<T>(N, false, gy[k], v);
+            for (int e = 0; e < 4; ++e) gy[k][e] = v[e];
+        }
+    }
+    for (int j = 0; j < n0 - 2; ++j) {                     // per block: c, w0, g'
+        const WideBlock b = wide_block(j, mk);
+        const int k = b.k, kn = b.mir ? k + 1 : k - 1;
+        const bool first = b.mir ? k == n0 - 1 : k == 0;
+        T Tk[15];
+        double lf[8];
+        getT(k, Tk); getC(k, lf);
+        wide_c<T>(lf, r[k], gy[first ? k : kn], c[k]);
+        const T w0 = wide_row5<T, 15>(Tk, 0, c[k]);
+        if (!first) wide_gp<T>(lf, w0, gy[k], gh[kn]);
+    }
+    T xq[6];
+    {                                                      // middle block
+        T Tq[21], yT[4], yB[4], hT[4], hB[4];
+        double lfB[8], lfU[8];
+        for (int j = 0; j < 15; ++j) Tq[j] = fac[rec(mk) * 15 + j];
+        for (int j = 0; j < 6; ++j) Tq[15 + j] = fac[rec(mk + 1) * 15 + j];
+        getC(mk, lfB); getC(mk + 1, lfU);
+        for (int e = 0; e < 4; ++e) {
+            yT[e] = nbt > 0 ? gy[mk - 1][e] : zero<T>();
+            yB[e] = nbb > 0 ? gy[mk + 2][e] : zero<T>();
+        }
+        wide_middle<T>(Tq, lfB, lfU, rq, yT, yB, xq, hT, hB);
+        for (int e = 0; e < 4; ++e) {
+            if (nbt > 0) gh[mk - 1][e] = hT[e];
+            if (nbb > 0) gh[mk + 2][e] = hB[e];
+        }
+    }
+    for (int half = 0; half < 2; ++half) {                 // backward chains
+        const int nb = half ? nbb : nbt, kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
+        if (nb < 1) continue;
+        T v[4];
+        for (int e = 0; e < 4; ++e) v[e] = gh[kb0][e];
+        for (int i = 0; i + 1 < nb; ++i) {
+            const int k = kb0 + (i + 1) * dk;
+            T N[16];
+            getN(kb0 + i * dk, N);
+            wide_chain_step<T>(N, true, gh[k], v);
+            for (int e = 0; e < 4; ++e) gh[k][e] = v[e];
+        }
+    }
+    for (int j = 0; j < n0 - 2; ++j) {                     // per block: x, scatter
+        const WideBlock b = wide_block(j, mk);
+        T Tk[15], x[5];
+        getT(b.k, Tk);
+        wide_x<T, 15>(Tk, c[b.k], gh[b.k], x);
+        wide_block_scatter<T, DIR>(A, b.k, b.mir, i1, i2, x);
+    }
+    {
+        const T xs[5] = {xq[0], xq[1], xq[2], xq[3], xq[4]};
+        wide_block_scatter<T, DIR>(A, mk, 0, i1, i2, xs);
+        A.E(0)[A.idx(0, mk + 1, i1, i2)] = xq[5];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Restriction of the residual, core.restrict (reference emg3d/core.py:1620-2001).
 // One body for the seven sc_dir variants: c{x,y,z} say whether a direction is coarsened.

@@ -31,6 +31,7 @@ struct LevelArgs {
 int g_point_slab = 0;
 int g_point_tile_min = 1 << 20;
 int g_line_order = 1;
+int g_line_wide = 0;          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
 // kernels.hip (k_gs_point_tile), each workgroup's phases separated like its barriers
@@ -122,6 +123,21 @@ void line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac
     });
 }
 
+// one colour pass in the wide form (kernels.hip: k_line_wide): one walk per line, in place on the field
+template <class T, int DIR>
+void line_colour_wide(const emg::Level<T> &L, int c, const T *fac, const double *lfac, const T *nfac)
+{
+    const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
+    if (lc.lines <= 0) return;
+    const emg::Axes<T, DIR> A(L);
+    for (int lid = 0; lid < lc.lines; ++lid) {
+        int i1, i2, l2;
+        emg::line_of_thread<DIR>(c, lc.cntp, lc.cntq, lid % lc.cntp, lid / lc.cntp, i1, i2, l2);
+        emg::line_wide_ref<T, DIR>(A, i1, i2, lc.lines, lid, fac + lc.fac_off, lfac + lc.lfac_off,
+                                   nfac + lc.fac_off / 15 * 16);
+    }
+}
+
 template <class T, int DIR> void line_setup_all(const emg::Level<T> &L, T *fac, double *lfac)
 {
     for (int c = 0; c < 4; ++c) {
@@ -143,6 +159,19 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
     if (lr == 1) line_setup_all<T, 0>(L, fac.data(), lfac.data());
     if (lr == 2) line_setup_all<T, 1>(L, fac.data(), lfac.data());
     if (lr == 3) line_setup_all<T, 2>(L, fac.data(), lfac.data());
+    // the N records of the wide form (k_line_wide_setup): one per block record, from its T and coupling entries
+    const size_t nrec = lr ? fac.size() / 15 : 0;
+    const bool wide = lr && g_line_wide && emg::line_wide_capable(emg::line_n0(lr - 1, nx, ny, nz), nrec);
+    std::vector<T> nfac(wide ? nrec * 16 : 1);
+    if (wide)
+        for (size_t r = 0; r < nrec; ++r) {
+            T Tk[15], N[16];
+            double lf[8];
+            for (int j = 0; j < 15; ++j) Tk[j] = fac[r * 15 + j];
+            for (int j = 0; j < 8; ++j) lf[j] = lfac[r * 8 + j];
+            emg::wide_n_record<T>(Tk, lf, N);
+            for (int j = 0; j < 16; ++j) nfac[r * 16 + j] = N[j];
+        }
     // point smoother: odd nu runs with the precomputed eta edge sums (k_point_setup), even
     // nu forms them on the fly -- both forms of point_load get exercised
     std::vector<T> pstv;
@@ -190,6 +219,12 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
         }
         for (int cc = 0; cc < 4; ++cc) {
             const int c = emg::line_sweep_colour(g_line_order, it, cc);
+            if (wide) {
+                if (lr == 1) line_colour_wide<T, 0>(L, c, fac.data(), lfac.data(), nfac.data());
+                else if (lr == 2) line_colour_wide<T, 1>(L, c, fac.data(), lfac.data(), nfac.data());
+                else line_colour_wide<T, 2>(L, c, fac.data(), lfac.data(), nfac.data());
+                continue;
+            }
             if (lr == 1) line_colour<T, 0>(L, c, fac.data(), lfac.data(), vec.data());
             else if (lr == 2) line_colour<T, 1>(L, c, fac.data(), lfac.data(), vec.data());
             else line_colour<T, 2>(L, c, fac.data(), lfac.data(), vec.data());
@@ -214,6 +249,7 @@ extern "C" {
 void emu_set_point_slab(int t) { g_point_slab = t; }
 void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
 void emu_set_line_order(int o) { g_line_order = o; }
+void emu_set_line_wide(int w) { g_line_wide = w; }
 void emu_set_point_order(int o) { emg::point_order_ref() = o; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)

@@ -649,6 +649,76 @@ def test_short_lines_vs_oracle(shape, lr, dtype):
     assert relerr(b.field, a.field) < 1e-11
 
 
+class _option:
+    """Set a run-time option of the library for the duration of a with-block."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        lib = _lib.lib()
+        self.old = lib.emg3d_get_option(self.name)
+        assert lib.emg3d_set_option(self.name, self.value) == 0
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().emg3d_set_option(self.name, self.old)
+
+
+WIDE_SHAPES = [(sh, lr) for sh, lr in SHORT_SHAPES if sh[lr - 1] <= 64]
+
+
+@pytest.mark.parametrize('shape,lr', WIDE_SHAPES)
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_wide_line_kernel_vs_oracle(shape, lr, dtype):
+    """k_line_wide (option line_wide: four-unknown chains on sixteen lanes per half-line, one thread per block for the
+    rest) on every short line length -- 2 ... 64 blocks: no top half, no bottom half, halves of unequal length, one
+    to eight lines per workgroup, surplus chain groups -- nu = 3 sweeps against the oracle in the same ordering,
+    and against the kernel the level runs otherwise (same factors, N = T C rounded once more: equal to rounding)."""
+    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + 7 * lr)
+    a, b, c = e0.copy(), e0.copy(), e0.copy()
+    args = (s0.fx, s0.fy, s0.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
+    getattr(ocore, SMOOTHERS[lr])(a.fx, a.fy, a.fz, *args, order=1)
+    with _option('line_wide', 0):
+        getattr(core, SMOOTHERS[lr])(c.fx, c.fy, c.fz, *args)
+    with _option('line_wide', 64):
+        assert _lib.lib().emg3d_line_kernel_name(lr, *shape, int(dtype is complex), 1) == b'k_line_wide'
+        getattr(core, SMOOTHERS[lr])(b.fx, b.fy, b.fz, *args)
+    assert np.any(b.field != e0.field)
+    assert relerr(b.field, a.field) < 1e-11
+    assert relerr(b.field, c.field) < 1e-11
+
+
+@pytest.mark.parametrize('shape,lr', [((4, 40, 9), 1), ((34, 16, 30), 2), ((20, 21, 64), 3)])
+@pytest.mark.parametrize('batch,dtype', [(2, complex), (5, complex), (3, float)])
+def test_wide_line_kernel_batch_equals_single_source(shape, lr, batch, dtype):
+    """k_line_wide with several right-hand sides (grid.y = right-hand side) gives every source the bits it gets alone."""
+    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + lr + batch)
+    dev = torch.device('cuda')
+    rng = np.random.default_rng(batch)
+    n = e0.field.size
+    srcs = [s0.field * (1 + b) + (0.3 * b) * rng.standard_normal(n) for b in range(batch)]
+    starts = [e0.field * (1.0 - 0.2 * b) for b in range(batch)]
+    with _option('line_wide', 64):
+        assert _lib.lib().emg3d_line_kernel_name(lr, *shape, int(dtype is complex), batch) == b'k_line_wide'
+        single = DeviceLevel.from_host(vm, dev)
+        want = []
+        for b in range(batch):
+            single.s.copy_(torch.from_numpy(srcs[b]))
+            single.e.copy_(torch.from_numpy(starts[b]))
+            single.smooth(lr, 3)
+            want.append(single.e.cpu().numpy())
+        many = DeviceLevel.from_host(vm, dev, batch=batch)
+        many._factors = single._factors              # the same factor buffers (they depend on the model only)
+        many.s.copy_(torch.from_numpy(np.concatenate(srcs)))
+        many.e.copy_(torch.from_numpy(np.concatenate(starts)))
+        many.smooth(lr, 3)
+        got = many.e.cpu().numpy().reshape(batch, n)
+    for b in range(batch):
+        assert np.any(want[b] != starts[b])
+        assert np.array_equal(got[b], want[b]), (b, relerr(got[b], want[b]))
+
+
 def _random_level_fields(shape, dtype, seed, freq=0.7, extras=False):
     """Stretched random tri-axial model on `shape` (oracle volume model) with random source / start fields
     (PEC faces of the start field zero); extras: with epsilon_r and mu_r (eta gets a real part)."""
@@ -672,13 +742,16 @@ def _random_level_fields(shape, dtype, seed, freq=0.7, extras=False):
     return grid, vm, fields[0], e0
 
 
-@pytest.mark.parametrize('shape,lr', [((130, 72, 72), 1), ((72, 130, 72), 2), ((72, 72, 258), 3)])
+@pytest.mark.parametrize('shape,lr', [((130, 72, 72), 1), ((72, 130, 72), 2), ((72, 72, 258), 3), ((384, 66, 66), 1),
+                                      ((66, 384, 66), 2)])
 @pytest.mark.parametrize('batch,dtype', [(2, complex), (3, complex), (4, complex), (5, complex), (4, float), (8, complex)])
 def test_batched_streamed_line_kernel_equals_single_source(shape, lr, batch, dtype):
     """k_line_stream with B > 1 -- one workgroup serves its 16 lines for a group of up to four right-hand sides,
     every factor row fetched once per group -- against the single-source launches on the same level: source by source the fields after nu = 3 sweeps must agree BIT
     FOR BIT (batches of 5 and 8 run as groups of 3 + 2 and 4 + 4). Lines of 130 and 258 blocks (R = 16 / 8
-    rows per chunk, several chunks, a ragged last one), > 1000 lines per colour class (16 per workgroup)."""
+    rows per chunk, several chunks, a ragged last one), > 1000 lines per colour class (16 per workgroup); lines of
+    384 blocks -- config 5's own line length (384 x 256 x 256): three ring chunks per half at R = 16 with a ragged
+    last one, six at R = 8 -- in groups of two, three and four (x-lines) and as 3 + 2 / 4 + 4 (y-lines)."""
     lib = _lib.lib()
     if batch >= 5 and lr != 2:
         pytest.skip('group splitting is direction-independent: one direction is enough')
@@ -1670,6 +1743,15 @@ def test_salt384_one_cycle_vs_oracle_same_order():
     _one_cycle_vs_oracle('salt384', source_index=7)
 
 
+@pytest.mark.slow
+def test_salt384_pair0_one_cycle_vs_oracle_same_order():
+    """Config 5's longest pair at full size -- pair 0 (0.25 Hz, the source at x = -2000 m: 9 cycles to 1e-6, 22 to
+    1e-10) --: one F-cycle against the oracle in the same ordering, next to pair 7 above. (The pair converged to
+    1e-10 against the oracle costs 5.5 min of oracle time on 16 threads, which the suite's time limit does not
+    hold beside the converged configs 2 and 3; builder-run: tools/full_size_converged.py, profiles/.)"""
+    _one_cycle_vs_oracle('salt384', source_index=0)
+
+
 @pytest.mark.parametrize('pair', [3, 5, 6])
 def test_salt96_other_pairs_converged_vs_oracle(pair):
     """Config 5's other (source, frequency) pairs on the quarter-size copy (pair 0 is in
@@ -2064,6 +2146,33 @@ def test_bench_two_ranks_through_its_own_launcher(backend):
     # two independent sources: twice the cell-sweeps of one rank per step
     assert out['config']['cell_sweeps_per_step'] > 0
     assert out['value'] == pytest.approx(2 * out['config']['cell_sweeps_per_step'] * 3 / (out['ms_per_step'] * 3e-3) / 1e6, rel=0.02)
+
+
+@pytest.mark.slow
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """`python bench.py --gpus 8 --workload marine128` -- BASELINE.json config 4 at its real rank count -- as the
+    driver's scaling run calls it, with the eight ranks sharing this box's one GPU and their collectives over gloo
+    (EMG3D_BENCH_BACKEND): process-group setup, the model broadcast to seven receiving ranks, one source per rank,
+    barrier, MAX / SUM reductions, the rank-0 JSON line. So that the first 8-GPU run is not the first execution of
+    this path. (Eight 128^3 hierarchies are 8 x 4.2 GB of the one GPU's HBM.)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, EMG3D_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--workload', 'marine128',
+                        '--steps', '2', '--warmup', '1', '--no-256', '--no-survey', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['steps'] == 2 and out['scaling'] == 'weak'
+    assert out['config']['workload'] == 'marine128' and out['value'] > 0
+    assert out['config']['broadcast_ms'] > 0 and 'gloo' in out['config']['model_distribution']
+    # eight independent sources: the aggregate is the sum over the ranks
+    assert out['value'] == pytest.approx(8 * out['config']['cell_sweeps_per_step'] * 2 / (out['ms_per_step'] * 2e-3) / 1e6, rel=0.02)
 
 
 @pytest.mark.parametrize('name,cycles', [('uni32_F', 10), ('marine32_W', 8)])

@@ -13,6 +13,13 @@ from oracle import core as ocore
 from helpers import relerr, widths
 
 
+def emg3d_line_records(n0, lines):
+    """Block records of a direction (stencil.h: line_padded): middle m = (n0 // 2) // 4 * 4, m + 2 records up to
+    the middle pair, the rest padded to a multiple of four."""
+    m = (n0 // 2) // 4 * 4
+    return (m + 2 + (n0 - 2 - m + 3) // 4 * 4) * lines
+
+
 def test_library_loads_and_exports_all_declared_symbols():
     lib = _lib.lib()
     assert lib.emg3d_version() == 100
@@ -27,7 +34,10 @@ def test_library_loads_and_exports_all_declared_symbols():
     # records per line of the two-sided factorisation (stencil.h: line_padded):
     # n0 = 8 -> 4 top + 2 middle + 2 bottom padded to 4 = 10;  n0 = 5 (granule 2) -> 2 + 2 + 1 -> 2 = 6
     assert lib.emg3d_gs_scratch_bytes(1, 8, 6, 4, 1) == (5 * 10 * 3 * 2 + 80) * 16
-    assert lib.emg3d_line_fac_bytes(1, 8, 6, 4, 1) == 15 * 10 * 5 * 3 * 16
+    # T records (15 entries) + the N records of the wide form (16 entries) on levels small enough to hold them
+    assert lib.emg3d_line_fac_bytes(1, 8, 6, 4, 1) == (15 + 16) * 10 * 5 * 3 * 16
+    assert lib.emg3d_line_fac_bytes(1, 128, 6, 4, 1) == 15 * emg3d_line_records(128, 5 * 3) * 16      # lines too long
+    assert lib.emg3d_line_fac_bytes(3, 300, 300, 64, 1) == 15 * 66 * 299 * 299 * 16                   # too many records
     assert lib.emg3d_line_lfac_bytes(3, 8, 6, 5) == 8 * 6 * 7 * 5 * 8
     assert lib.emg3d_point_fac_bytes(8, 6, 4, 1) == (8 * 7 * 5 + 9 * 6 * 5 + 9 * 7 * 4) * 16
     assert lib.emg3d_residual_ws_len(64, 8, 4) == 2 * 3 * 5

@@ -368,3 +368,47 @@ def test_residual_column_walk_equals_cell_by_cell(dtype, zb):
     n2 = emu.residual_column(e, s, vm, r2, zb)
     assert np.array_equal(r1.field, r2.field)
     assert n2 == pytest.approx(n1, rel=1e-13)
+
+
+def _random_case(shape, freq, seed, stretch=True):
+    rng = np.random.default_rng(seed)
+    h = [rng.uniform(10, 30, n) if stretch else np.ones(n) * 20. for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, freq, *sig)
+    dtype = complex if freq > 0 else float
+    s = mg_ref.Field(grid, dtype=dtype)
+    e0 = mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    return grid, vm, s, e0
+
+
+@pytest.mark.parametrize('shape,freq', [((16, 8, 12), 1.3), ((5, 7, 9), 1.3), ((3, 3, 3), 1.3), ((2, 9, 4), 1.3),
+                                        ((14, 4, 6), 1.3), ((32, 6, 10), -2.0), ((64, 6, 10), 1.0),
+                                        ((64, 6, 10), 0.01)])
+def test_wide_line_form_matches_oracle(shape, freq):
+    """stencil.h: line_wide_ref -- the line solve restated with 4 x 4 chains (what k_line_wide computes per line:
+    N records, g / y chains, per-block c / w0 / g', middle block, h chains, x) against the oracle's four-colour
+    order, per call; ragged line lengths (2 ... 64 blocks: middle positions 0 ... 32, halves of unequal length),
+    complex and real, and at a low frequency (nearly singular blocks) with the tolerance the two-sided
+    factorisation itself is held to."""
+    grid, vm, s, e0 = _random_case(shape, freq, 7)
+    tol = 2e-10 if freq == 0.01 else 2e-12
+    try:
+        emu.lib().emu_set_line_wide(1)
+        for fn, lr in LR.items():
+            if lr == 0:
+                continue
+            a, b = e0.copy(), e0.copy()
+            getattr(ocore, fn)(a.fx, a.fy, a.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z,
+                               vm.zeta, *grid.h, 2, order=1)
+            emu.gauss_seidel(b, s, vm, lr, 2)
+            assert relerr(b.field, a.field) < tol, (shape, fn)
+    finally:
+        emu.lib().emu_set_line_wide(0)

@@ -103,6 +103,68 @@ def test_two_process_gloo_sharding_and_broadcast():
     assert abs(sum(costs[i] for i in lpt0) - sum(costs[i] for i in lpt1)) <= 1
 
 
+def _worker8(rank, world, port, q):
+    """One rank of the real rank count of BASELINE.json configs 4 and 5 (8 GPUs of one node): the product's
+    process-group setup, the model broadcast, and the pair each rank takes."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    import emg3d_amd as emg3d
+    from emg3d_amd import parallel
+    from bench import PAIR_COSTS
+    try:
+        r, w, device = parallel.init('gloo')
+        assert (r, w) == (rank, world)
+        model = None
+        if rank == 0:
+            grid = emg3d.TensorMesh([np.full(6, 10.), np.full(4, 20.), np.full(4, 5.)], (0, 0, 0))
+            model = emg3d.Model(grid, np.random.default_rng(1).uniform(1, 2, grid.shape_cells))
+        m2 = parallel.broadcast_model(model, 0)
+        costs = PAIR_COSTS['salt384']
+        sources = {f'S{i}': (12. + i, 10., 20., 0., 0.) for i in range(8)}
+
+        def fake_solve(inp):
+            sf = emg3d.get_source_field(inp['grid'], inp['source'], inp['frequency'])
+            return sf, {'exit': 0, 'it_mg': 1, 'chk': float(np.linalg.norm(sf.field)), 'log': ''}
+        out = parallel.compute(model, None, sources, {'f': 1.0}, {'sslsolver': False}, solve_fn=fake_solve)
+        q.put({'rank': rank, 'sum': float(m2.property_x.sum()), 'case': m2.case,
+               'config5': parallel.shard(len(costs), rank, world, costs),      # LPT: cycles to tolerance by frequency
+               'config4': parallel.shard(8, rank, world),                      # round-robin: one source per GPU
+               'mine': sorted(k for k in out if k != '_all_info'),
+               'all': sorted(out['_all_info']) if rank == 0 else None})
+        parallel.finalize()
+    except Exception as e:   # pragma: no cover
+        q.put({'rank': rank, 'error': repr(e)})
+        raise
+
+
+@pytest.mark.timeout(600)
+def test_eight_process_gloo_one_pair_per_rank():
+    """The multi-rank path at the REAL rank count (world size 8, gloo on CPU): the model reaches all eight ranks,
+    config 5's eight (source, frequency) pairs go one to a rank under the longest-processing-time sharding with
+    bench.PAIR_COSTS (ranks 0 / 1 take the two 0.25 Hz pairs, ...), config 4's eight sources one to a rank
+    round-robin, `parallel.compute` solves every pair exactly once and rank 0 gathers all eight infos."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all('error' not in r for r in results), results
+    res = {r['rank']: r for r in results}
+    assert len({res[r]['sum'] for r in range(world)}) == 1 and all(res[r]['case'] == 'isotropic' for r in range(world))
+    assert [res[r]['config5'] for r in range(world)] == [[i] for i in range(world)]    # costs are sorted: pair r -> rank r
+    assert [res[r]['config4'] for r in range(world)] == [[i] for i in range(world)]
+    assert all(len(res[r]['mine']) == 1 for r in range(world))
+    assert sorted(sum((res[r]['mine'] for r in range(world)), [])) == sorted((f'S{i}', 'f') for i in range(8))
+    assert res[0]['all'] == sorted((f'S{i}', 'f') for i in range(8))
+
+
 def test_shard_round_robin_and_pairs_order():
     from emg3d_amd import parallel
     assert parallel.srcfreq_pairs(['a', 'b'], [1, 2]) == [('a', 1), ('a', 2), ('b', 1), ('b', 2)]
