@@ -123,6 +123,12 @@ int g_line_stream_lf = 1;
 // line_wide_capable -- a function of the level's shape alone, so that buffers sized once stay valid whatever the
 // option says); 0: never
 int g_line_wide = 0;
+// ALL colour passes of a smoothing call in one launch (k_line_fused + k_line_fused_back) on the slab / rod levels whose
+// lines have at most this many blocks (launch.h: fused_capable; <= FUSED_N0_CAP); 0: never. line_fused_w: node planes
+// a workgroup owns (4 .. 64; fewer = more workgroups, each with the same halo)
+int g_line_fused = 0;
+int g_line_fused_w = 8;
+constexpr int FUSED_N0_CAP = 17, FUSED_W_MIN = 4, FUSED_W_MAX = 64;
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
@@ -1106,19 +1112,21 @@ __device__ unsigned long long g_wide_stamps[32];
 // One chain of a 16-lane group: nst steps v <- acc_i - M_i v, M = N (forward) or N^T (BWD), acc_i from / result to
 // the LDS row krow0 + i dk, N from record kmat0 + i dk. v enters (and leaves an even number of steps) with lane
 // (a, b) holding entry b.
+// (es: distance between the sixteen entries of a record -- 1 in the factor buffer; the LDS copy of k_line_fused keeps
+//  entry q of all its records in one plane)
 template <class T, bool BWD>
-__device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow, unsigned loff, int krow0, int kmat0,
-                                           int dk, int nst, int l16, T v)
+__device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow, int loff, int krow0, int kmat0,
+                                           int dk, int nst, int l16, T v, int es = 1)
 {
     const int a = l16 >> 2, b = l16 & 3;
-    const unsigned e1 = 4 * a + b, e2 = 4 * b + a;
-    const unsigned eI = loff + (BWD ? e2 : e1), eII = loff + (BWD ? e1 : e2);
+    const int e1 = 4 * a + b, e2 = 4 * b + a;
+    const int eI = loff + es * (BWD ? e2 : e1), eII = loff + es * (BWD ? e1 : e2);
     const int rdI = b == 0 ? a : 4, wrI = b == 0 ? a : 5;
     const int rdII = a == 0 ? b : 4, wrII = a == 0 ? b : 5;
     T nr[4], ac[4];
     auto fetch = [&](int d, int i) {
         const int ic = min(i, nst - 1);
-        nr[d] = nbase[(size_t)(kmat0 + ic * dk) * nrow + ((d & 1) ? eII : eI)];
+        nr[d] = nbase[(ptrdiff_t)((size_t)(kmat0 + ic * dk) * nrow) + ((d & 1) ? eII : eI)];
         ac[d] = rows[(krow0 + ic * dk) * LW_ROW + ((d & 1) ? rdII : rdI)];
     };
 #pragma unroll
@@ -1232,7 +1240,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     {
         const int nst = half ? nbb : nbt;
         if (chain_wave && nst > 0)
-            wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, nbase, nrow, (unsigned)cl * 16, half ? n0 - 1 : 0,
+            wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, nbase, nrow, cl * 16, half ? n0 - 1 : 0,
                                  half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>());
     }
     WSTAMP(3);
@@ -1290,7 +1298,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
             const int kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
             T *const rw = GH + (size_t)cl * rows * LW_ROW;
             const T v0 = rw[kb0 * LW_ROW + (lane & 3)];
-            wide_chain<T, true>(rw, nbase, nrow, (unsigned)cl * 16, kb0 + dk, kb0, dk, nst, lane & 15, v0);
+            wide_chain<T, true>(rw, nbase, nrow, cl * 16, kb0 + dk, kb0, dk, nst, lane & 15, v0);
         }
     }
     WSTAMP(7);
@@ -1308,6 +1316,301 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
         emg::wide_block_scatter<T, DIR>(A, k, mir, i1, i2, x);
     }
     WSTAMP(9);
+}
+
+// ---- ALL colour passes of a smoothing call in one launch, on the slab / rod levels: k_line_fused ------------
+// (launch.h, "several colour passes of one line direction in ONE launch".) A level like 256 x 4 x 4 has ~190 lines of
+// four blocks per colour class: a pass is a launch of 6 us -- kernel boundary, first touch of memory, a chain of two
+// steps --, and a W-cycle on a 256^3 problem launches 1 800 of them per level. Here a workgroup owns `w` node planes
+// across the long axis, copies them and a halo into a private level IN LDS (field, source, zeta, widths), runs every
+// pass of the call there with workgroup barriers only -- the halo lines are solved redundantly instead of being
+// exchanged --, leaves its owned planes in the global scratch, and k_line_fused_back writes them back (a second
+// launch: a workgroup may only overwrite the level when every other workgroup has read its halo from it).
+// A pass is k_line_wide's five phases on the lines the patch needs in that pass (fused_lines), a thread per block
+// (middle blocks: from the next wave on, so that no wave runs both roles) and sixteen lanes per half-line chain. The
+// only global accesses of a pass are the factor records of its blocks, fetched at its start by LDS-direct loads
+// (no register holds them: entry q of the record of thread t lands at plane q, slot t) -- T, C and N records are
+// read from LDS where they are used, and only the right-hand sides r / c stay in registers between the phases.
+constexpr int LF_THREADS = 512;
+// phase stamps of workgroup 1 (thread 0), only in the -DEMG_FUSED_STAMPS build of tools/fused_stamps.py
+#ifdef EMG_FUSED_STAMPS
+__device__ unsigned long long g_fused_stamps[128];
+#define FSTAMP(i)                                                                                            \
+    do {                                                                                                     \
+        if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0 && (i) < 128) g_fused_stamps[(i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define FSTAMP(i)
+#endif
+// LDS of a launch, in elements of the field type: rows (g / y and g' / h of `chunk` lines), the staged records of a
+// round (blocks: 15 T + FC_PLANES C + 16 N planes of chunk * nblk slots; middle blocks: 21 T_Q + 2 FC_PLANES planes of
+// chunk slots), the private level
+template <class T> struct FusedLds {
+    static constexpr int FC = sizeof(T) == 16 ? 4 : 8;      // planes of a coupling record (8 doubles)
+    static constexpr int BLK = 15 + FC + 16, MID = 21 + 2 * FC;
+    static __host__ __device__ size_t rows(int chunk, int n0) { return (size_t)2 * chunk * (n0 + 1) * LW_ROW; }
+    static __host__ __device__ size_t staged(int chunk, int n0) { return (size_t)BLK * chunk * (n0 - 2) + (size_t)MID * chunk; }
+};
+// lines per round of a pass: the block threads fill whole waves, the middle-block threads follow
+inline int fused_chunk_threads(int n0)
+{
+    int c = LF_THREADS / (n0 - 1);
+    while (c > 1 && ((c * (n0 - 2) + 63) & ~63) + c > LF_THREADS) --c;
+    return std::max(1, c);
+}
+
+// entry q of the record at `src` into plane q (`stride` slots apart) of the staging area, slot of this thread:
+// complex: LDS-direct loads (a wave's lanes land side by side behind the wave-uniform base `wbase` = plane 0, slot
+// of the wave's first lane); real: through a register
+template <class T, int N> __device__ __forceinline__ void fused_stage(const T *src, T *wbase, int stride, int lane)
+{
+    if constexpr (sizeof(T) == 16) {
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + q), (lptr_t)(wbase + (size_t)q * stride), 16, 0, 0);
+    } else {
+        T v[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = src[q];
+#pragma unroll
+        for (int q = 0; q < N; ++q) wbase[(size_t)q * stride + lane] = v[q];
+    }
+}
+// the eight doubles of a staged coupling record (planes of 16 bytes for complex fields, of 8 for real ones)
+template <class T> __device__ __forceinline__ void fused_get_c(const T *plane0, int stride, int slot, double (&lf)[8])
+{
+    if constexpr (sizeof(T) == 16) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const double2 v = *reinterpret_cast<const double2 *>(plane0 + (size_t)p * stride + slot);
+            lf[2 * p] = v.x; lf[2 * p + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) lf[p] = plane0[(size_t)p * stride + slot];
+    }
+}
+
+template <class T, int DIR, bool BATCH>
+__global__ __launch_bounds__(LF_THREADS) void k_line_fused(emg::Level<T> L, emg::FusedPlan P, int chunk, const T *fac,
+                                                          const double *lfac, const T *nfac, T *priv, size_t priv_stride)
+{
+    extern __shared__ double2 lf_smem[];
+    using LD = FusedLds<T>;
+    constexpr int FC = LD::FC;
+    // (the patch in LDS: its plane ranges are indexed by the pass at run time)
+    __shared__ emg::FusedPatch sF;
+    const int t = threadIdx.x;
+    const size_t boff = BATCH ? blockIdx.y * L.bstride : 0;
+    FSTAMP(0);
+    if (t == 0) emg::fused_patch(P, blockIdx.x, sF);
+    __syncthreads();
+    FSTAMP(1);
+    const emg::FusedPatch &F = sF;
+    const int n0 = P.n0, mk = emg::line_mid(n0);
+    const int nbt = mk, nbb = n0 - mk - 2, nblk = n0 - 2, rows = n0 + 1;
+    T *const GY = reinterpret_cast<T *>(lf_smem);          // [chunk][rows][LW_ROW]: g, then y
+    T *const GH = GY + (size_t)chunk * rows * LW_ROW;      //                        g', then h
+    T *const ST = GH + (size_t)chunk * rows * LW_ROW;      // the staged records of the round
+    T *const gpriv = priv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * priv_stride;
+    const emg::Level<T> Q = emg::fused_private_level(L, P, F, ST + LD::staged(chunk, n0));
+    emg::fused_copy_in(L, Q, P, F, boff, t, LF_THREADS);
+    __syncthreads();
+    FSTAMP(2);
+    const emg::Axes<T, DIR> A(Q);
+    const int wave = t >> 6, lane = t & 63, half = wave >> 2, gq = (wave & 3) * 4 + (lane >> 4);
+    for (int pass = 1; pass <= P.npass; ++pass) {
+        const emg::FusedLines S = emg::fused_lines(P, F, pass);
+        const int c = S.colour, nlines = S.cp * emg::fused_sel(P.cntq, c);
+        const long long rec0 = emg::fused_sel(P.rec0, c);
+        const T *const f = fac + rec0 * 15;
+        const double *const lfc = lfac + rec0 * 8;
+        const T *const nf = nfac + rec0 * 16;
+        for (int l0 = 0; l0 < S.n; l0 += chunk) {
+            const int nl = min(chunk, S.n - l0);
+            // the block threads first, the middle-block threads from the next wave on (no wave runs both roles)
+            const int nbs = nl * nblk, tq0 = (nbs + 63) & ~63;
+            const bool isq = t >= tq0;
+            const bool has = isq ? t - tq0 < nl : t < nbs;
+            int ll = 0, j = 0;
+            if (isq) ll = t - tq0;
+            else if (DIR == 0) { ll = emg::fused_div(t, nblk); j = t - ll * nblk; }      // x-lines: the field is contiguous along the line
+            else { j = emg::fused_div(t, nl); ll = t - j * nl; }
+            // staging planes of the round: blocks [T 15 | C | N 16] x nbs slots, then middle blocks [T_Q 21 | B | U] x nl slots
+            T *const FT = ST, *const FCb = ST + (size_t)15 * nbs, *const FN = ST + (size_t)(15 + FC) * nbs;
+            T *const MT = ST + (size_t)LD::BLK * nbs, *const MB = MT + (size_t)21 * nl, *const MU = MB + (size_t)FC * nl;
+            int i1 = 1, i2 = 1, lid = 0, k = 0, mir = 0;
+            T r[6];
+            // ---- (A) the records on their way into LDS; right-hand sides; g ----
+            if (has) {
+                if (pass == 2) FSTAMP(64);
+                emg::fused_line<DIR>(P, F, S, l0 + ll, i1, i2, lid);
+                const int w0 = __builtin_amdgcn_readfirstlane(t & ~63);
+                if (pass == 2) FSTAMP(65);
+                if (!isq) {
+                    const emg::WideBlock wb = emg::wide_block(j, mk);
+                    k = wb.k; mir = wb.mir;
+                    const size_t rec = (size_t)k * nlines + lid;
+                    fused_stage<T, 15>(f + rec * 15, FT + w0, nbs, lane);
+                    fused_stage<T, FC>(reinterpret_cast<const T *>(lfc + rec * 8), FCb + w0, nbs, lane);
+                    fused_stage<T, 16>(nf + rec * 16, FN + w0, nbs, lane);
+                    if (pass == 2) FSTAMP(66);
+                    T rb[5];
+                    emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
+                    if (pass == 2) FSTAMP(67);
+                    // (the records of this thread have landed: the compiler does not count LDS-direct loads)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (pass == 2) FSTAMP(68);
+                    T Tk[15], g[4];
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) Tk[q] = FT[(size_t)q * nbs + t];
+                    emg::wide_g<T, 15>(Tk, rb, g);
+                    if (pass == 2) FSTAMP(69);
+                    T *const row = GY + ((size_t)ll * rows + k) * LW_ROW;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) row[q] = g[q];
+                    row[4] = emg::zero<T>();
+                    GH[((size_t)ll * rows + k) * LW_ROW + 4] = emg::zero<T>();
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) r[q] = rb[q];
+                } else {
+                    const size_t rm0 = (size_t)mk * nlines + lid, rm1 = rm0 + nlines;
+                    const int wq = w0 - tq0;
+                    fused_stage<T, 15>(f + rm0 * 15, MT + wq, nl, lane);
+                    fused_stage<T, 6>(f + rm1 * 15, MT + (size_t)15 * nl + wq, nl, lane);
+                    fused_stage<T, FC>(reinterpret_cast<const T *>(lfc + rm0 * 8), MB + wq, nl, lane);
+                    fused_stage<T, FC>(reinterpret_cast<const T *>(lfc + rm1 * 8), MU + wq, nl, lane);
+                    T rm[5];
+                    emg::line_rhs<T, DIR>(A, mk, i1, i2, rm);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) r[q] = rm[q];
+                    r[5] = emg::line_rhs_e0<T, DIR>(A, mk + 1, i1, i2);
+                }
+            }
+            // (every record of the round has landed before any thread reads one: LDS-direct loads are not part of
+            //  what __syncthreads waits for)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pass == 2) FSTAMP(70);
+            __syncthreads();
+            FSTAMP(3 + (pass - 1) * 5 + 0);
+            // ---- (F) forward chains: waves 0..3 the top halves, waves 4..7 the bottom halves, sixteen lines a round;
+            //      the N record of line cl, block record k belongs to thread cl nblk + j (x-lines) / j nl + cl, j = k or k - 2 ----
+            const int ks = DIR == 0 ? 1 : nl;
+            {
+                const int nst = half ? nbb : nbt;
+                if (nst > 0)
+                    for (int base = 0; base + (wave & 3) * 4 < nl; base += 16) {
+                        const int cl = min(base + gq, nl - 1);
+                        wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, FN, (size_t)ks, (DIR == 0 ? cl * nblk : cl) - (half ? 2 * ks : 0),
+                                             half ? n0 - 1 : 0, half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>(), nbs);
+                    }
+            }
+            __syncthreads();
+            FSTAMP(3 + (pass - 1) * 5 + 1);
+            // ---- (C) per block: c = r - C w_kn, w_0, g' = C^T w; the middle blocks ----
+            if (has) {
+                if (!isq) {
+                    const int kn = mir ? k + 1 : k - 1;
+                    const bool first = mir ? k == n0 - 1 : k == 0;
+                    const T *const yr = GY + ((size_t)ll * rows + (first ? k : kn)) * LW_ROW;
+                    const T *const yo = GY + ((size_t)ll * rows + k) * LW_ROW;
+                    T yp[4], y[4], cc[5], rb[5], gp[4], T0[15];
+                    double lf[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { yp[q] = yr[q]; y[q] = yo[q]; }
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) rb[q] = r[q];
+                    fused_get_c<T>(FCb, nbs, t, lf);
+                    // row 0 of T: packed entries sym(0, m) = m (m + 1) / 2
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) T0[emg::sym(0, m)] = FT[(size_t)emg::sym(0, m) * nbs + t];
+                    emg::wide_c<T>(lf, rb, yp, cc);
+                    const T w0 = emg::wide_row5<T, 15>(T0, 0, cc);
+                    emg::wide_gp<T>(lf, w0, y, gp);
+                    T *const o = GH + ((size_t)ll * rows + (first ? n0 : kn)) * LW_ROW;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = gp[q];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) r[q] = cc[q];
+                } else {
+                    const T *const yt = GY + ((size_t)ll * rows + max(mk - 1, 0)) * LW_ROW;
+                    const T *const yb = GY + ((size_t)ll * rows + min(mk + 2, n0 - 1)) * LW_ROW;
+                    T yT[4], yB[4], xq[6], hT[4], hB[4], Tq[21];
+                    double lf[8], lf2[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const T vt = yt[q], vb = yb[q];
+                        yT[q] = nbt > 0 ? vt : emg::zero<T>();
+                        yB[q] = nbb > 0 ? vb : emg::zero<T>();
+                    }
+#pragma unroll
+                    for (int q = 0; q < 21; ++q) Tq[q] = MT[(size_t)q * nl + ll];
+                    fused_get_c<T>(MB, nl, ll, lf);
+                    fused_get_c<T>(MU, nl, ll, lf2);
+                    emg::wide_middle<T>(Tq, lf, lf2, r, yT, yB, xq, hT, hB);
+                    T *const ot = GH + ((size_t)ll * rows + (nbt > 0 ? mk - 1 : n0)) * LW_ROW;
+                    T *const ob = GH + ((size_t)ll * rows + (nbb > 0 ? mk + 2 : n0)) * LW_ROW;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ot[q] = hT[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ob[q] = hB[q];
+                    const T xs[5] = {xq[0], xq[1], xq[2], xq[3], xq[4]};
+                    emg::wide_block_scatter<T, DIR>(A, mk, 0, i1, i2, xs);
+                    A.E(0)[A.idx(0, mk + 1, i1, i2)] = xq[5];
+                }
+            }
+            __syncthreads();
+            FSTAMP(3 + (pass - 1) * 5 + 2);
+            // ---- (B) backward chains: outwards from the block next to the middle ----
+            {
+                const int nst = (half ? nbb : nbt) - 1;
+                if (nst > 0) {
+                    const int kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
+                    for (int base = 0; base + (wave & 3) * 4 < nl; base += 16) {
+                        const int cl = min(base + gq, nl - 1);
+                        T *const rw = GH + (size_t)cl * rows * LW_ROW;
+                        const T v0 = rw[kb0 * LW_ROW + (lane & 3)];
+                        wide_chain<T, true>(rw, FN, (size_t)ks, (DIR == 0 ? cl * nblk : cl) - (half ? 2 * ks : 0), kb0 + dk, kb0, dk, nst,
+                                            lane & 15, v0, nbs);
+                    }
+                }
+            }
+            __syncthreads();
+            FSTAMP(3 + (pass - 1) * 5 + 3);
+            // ---- (E) per block: x = T (c - h), scatter into the private field ----
+            if (has && !isq) {
+                const T *const hr = GH + ((size_t)ll * rows + k) * LW_ROW;
+                T h[4], cc[5], x[5], Tk[15];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = hr[q];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) cc[q] = r[q];
+#pragma unroll
+                for (int q = 0; q < 15; ++q) Tk[q] = FT[(size_t)q * nbs + t];
+                emg::wide_x<T, 15>(Tk, cc, h, x);
+                emg::wide_block_scatter<T, DIR>(A, k, mir, i1, i2, x);
+            }
+            __syncthreads();           // (the rows and staged records are reused; the next pass reads what this one scattered)
+            FSTAMP(3 + (pass - 1) * 5 + 4);
+        }
+    }
+    // the owned planes into the scratch copy of the private level, where k_line_fused_back finds them
+    emg::fused_copy_owned(Q, emg::fused_private_level(L, P, F, gpriv), P, F, t, LF_THREADS);
+    FSTAMP(3 + P.npass * 5);
+}
+
+// the owned planes of every patch back into the level (after ALL workgroups of k_line_fused have read their halos)
+template <class T, bool BATCH>
+__global__ __launch_bounds__(256) void k_line_fused_back(emg::Level<T> L, emg::FusedPlan P, T *priv, size_t priv_stride)
+{
+    __shared__ emg::FusedPatch sF;
+    const size_t boff = BATCH ? blockIdx.y * L.bstride : 0;
+    if (threadIdx.x == 0) emg::fused_patch(P, blockIdx.x, sF);
+    __syncthreads();
+    const emg::Level<T> Q = emg::fused_private_level(L, P, sF, priv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * priv_stride);
+    emg::fused_copy_out(L, Q, P, sF, boff, threadIdx.x, 256);
 }
 
 // ---- fused colour pass with STREAMED records (the largest levels): k_line_stream -----------------
@@ -1904,6 +2207,57 @@ inline bool line_wide_used(int dir, int nx, int ny, int nz)
     return g_line_wide > 0 && emg::line_n0(dir, nx, ny, nz) <= g_line_wide && emg::line_nfac_elems(dir, nx, ny, nz) > 0;
 }
 
+// does the direction run the fused passes on this level? (option line_fused = longest line)
+inline bool line_fused_used(int dir, int nx, int ny, int nz)
+{
+    return g_line_fused > 0 && emg::fused_capable(dir, nx, ny, nz, std::min(g_line_fused, FUSED_N0_CAP));
+}
+// scratch elements (per right-hand side) the fused passes may need on a level, whatever the options say
+inline size_t fused_scratch_elems(int dir, int nx, int ny, int nz)
+{
+    if (!emg::fused_capable(dir, nx, ny, nz, FUSED_N0_CAP)) return 0;
+    const emg::FusedPlan P = emg::fused_plan(dir, nx, ny, nz, emg::FUSED_MAXPASS / 4, 2, false, FUSED_W_MIN);
+    return (size_t)P.nwg * emg::fused_private_elems(P.dl, P.nmax, nx, ny, nz);
+}
+
+// LDS plan of a fused launch: lines per round (0: the private level does not fit beside the rows and staged records of
+// a round of at least `min(8, most lines of a pass)` lines -- the call is then launched pass by pass)
+template <class T> int fused_chunk(const emg::FusedPlan &P, int nx, int ny, int nz, size_t &smem)
+{
+    const size_t stride = emg::fused_private_elems(P.dl, P.nmax, nx, ny, nz);
+    // no more lines than a pass can have (planes of one parity x lines of the class per plane)
+    const int other = P.dl_is_p ? std::max(P.cntq[1], P.cntq[2]) : std::max(P.cntp[1], P.cntp[2]);
+    const int most = std::max(1, (P.nmax / 2 + 1) * std::max(other, 1));
+    int chunk = std::min(fused_chunk_threads(P.n0), most);
+    const size_t lds_cu = 160 * 1024 - 1024;
+    auto bytes = [&](int ch) { return (FusedLds<T>::rows(ch, P.n0) + FusedLds<T>::staged(ch, P.n0) + stride) * sizeof(T); };
+    const int least = std::min(8, most);
+    while (chunk > least && bytes(chunk) > lds_cu) --chunk;
+    smem = bytes(chunk);
+    return smem <= lds_cu ? chunk : 0;
+}
+
+template <class T, int DIR>
+bool launch_line_fused(const emg::Level<T> &L, const emg::FusedPlan &P, const T *fac, const double *lfac, T *priv, hipStream_t st)
+{
+    size_t smem = 0;
+    const int chunk = fused_chunk<T>(P, L.nx, L.ny, L.nz, smem);
+    if (chunk <= 0) return false;
+    const size_t stride = emg::fused_private_elems(P.dl, P.nmax, L.nx, L.ny, L.nz);
+    const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz);
+    const dim3 grid(P.nwg, L.batch);
+#define LF_LAUNCH(B)                                                                                                      \
+    do {                                                                                                                  \
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_fused<T, DIR, B>), smem);                                   \
+        hipLaunchKernelGGL((k_line_fused<T, DIR, B>), grid, dim3(LF_THREADS), smem, st, L, P, chunk, fac, lfac, nf, priv, stride); \
+        hipLaunchKernelGGL((k_line_fused_back<T, B>), grid, dim3(256), 0, st, L, P, priv, stride);                          \
+    } while (0)
+    if (L.batch > 1) LF_LAUNCH(true);
+    else LF_LAUNCH(false);
+#undef LF_LAUNCH
+    return true;
+}
+
 template <class T, int DIR, int B>
 void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const T *f, const double *lf, T *vec,
                          size_t vstride, int b0, int lpw, hipStream_t st)
@@ -2041,6 +2395,19 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
     // for the tiled one
     const T *pst = (lr == 0 && !tiled) ? (const T *)fac : nullptr;
     const hipStream_t st_ = st;
+    if (lr != 0 && line_fused_used(lr - 1, nx, ny, nz)) {
+        const int w = std::max(FUSED_W_MIN, std::min(FUSED_W_MAX, g_line_fused_w));
+        const emg::FusedPlan P = emg::fused_plan(lr - 1, nx, ny, nz, nu, g_line_order, g_skip_repeat != 0, w);
+        if (P.npass <= emg::FUSED_MAXPASS) {
+            const bool done = lr == 1   ? launch_line_fused<T, 0>(L, P, (const T *)fac, lfac, (T *)scratch, st)
+                              : lr == 2 ? launch_line_fused<T, 1>(L, P, (const T *)fac, lfac, (T *)scratch, st)
+                                        : launch_line_fused<T, 2>(L, P, (const T *)fac, lfac, (T *)scratch, st);
+            if (done) {
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
+    }
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;   // first sweep backward (reference emg3d/core.py:301,311)
@@ -2320,7 +2687,7 @@ static const OptionEntry g_options[] = {
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
-    {"line_wide", &g_line_wide},
+    {"line_wide", &g_line_wide},         {"line_fused", &g_line_fused},         {"line_fused_w", &g_line_fused_w},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value
@@ -2343,6 +2710,10 @@ int emg3d_set_option(const char *name, int value)
         return fail(EMG3D_ERR_BADARG, "line_stream_r: 0 (= 16) or a multiple of 4 in 4..32");
     if (!std::strcmp(name, "line_order") && (value < 0 || value > 2)) return fail(EMG3D_ERR_BADARG, "line_order: 0, 1 or 2");
     if (!std::strcmp(name, "point_order") && (value < 0 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_order: 0 or 1");
+    if (!std::strcmp(name, "line_fused") && (value < 0 || value > FUSED_N0_CAP))
+        return fail(EMG3D_ERR_BADARG, "line_fused: 0 (never) or the longest fused line in blocks, at most 17");
+    if (!std::strcmp(name, "line_fused_w") && (value < FUSED_W_MIN || value > FUSED_W_MAX))
+        return fail(EMG3D_ERR_BADARG, "line_fused_w: 4 .. 64 node planes per workgroup");
     for (const OptionEntry &o : g_options)
         if (!std::strcmp(name, o.name)) {
             if (*o.value != value) ++g_options_generation;
@@ -2353,6 +2724,13 @@ int emg3d_set_option(const char *name, int value)
 }
 
 int emg3d_options_generation(void) { return g_options_generation; }
+
+#ifdef EMG_FUSED_STAMPS
+int emg3d_debug_fused_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
 
 #ifdef EMG_WIDE_STAMPS
 int emg3d_debug_wide_stamps(unsigned long long *out)
@@ -2367,6 +2745,12 @@ const char *emg3d_line_kernel_name(int lr, int nx, int ny, int nz, int is_comple
     // the largest colour class (odd, odd) decides, as it does for the scratch size
     const emg::LineClass lc = emg::line_class(lr - 1, nx, ny, nz, 3);
     if (lc.lines <= 0) return "";
+    if (line_fused_used(lr - 1, nx, ny, nz)) {      // (decided for a call of two sweeps, the cycles' smoothing calls)
+        const emg::FusedPlan P = emg::fused_plan(lr - 1, nx, ny, nz, 2, g_line_order, g_skip_repeat != 0,
+                                                 std::max(FUSED_W_MIN, std::min(FUSED_W_MAX, g_line_fused_w)));
+        size_t smem = 0;
+        if ((is_complex ? fused_chunk<cplx>(P, nx, ny, nz, smem) : fused_chunk<double>(P, nx, ny, nz, smem)) > 0) return "k_line_fused";
+    }
     if (line_wide_used(lr - 1, nx, ny, nz)) return "k_line_wide";
     const LinePlan P = is_complex ? line_plan<cplx>(lc, batch > 1 ? batch : 1) : line_plan<double>(lc, batch > 1 ? batch : 1);
     switch (P.kind) {
@@ -2394,7 +2778,8 @@ int emg3d_device_count(void)
 size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex)
 {
     if (lr < 1 || lr > 3) return 0;
-    return emg::line_vec_elems(lr - 1, nx, ny, nz) * (is_complex ? 16 : 8);
+    // (the private levels of the fused passes, where the level can take them: a function of the shape alone)
+    return std::max(emg::line_vec_elems(lr - 1, nx, ny, nz), fused_scratch_elems(lr - 1, nx, ny, nz)) * (is_complex ? 16 : 8);
 }
 
 size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex)

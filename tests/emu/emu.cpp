@@ -31,6 +31,7 @@ struct LevelArgs {
 int g_point_slab = 0;
 int g_point_tile_min = 1 << 20;
 int g_line_order = 1;
+int g_line_fused = 0, g_line_fused_w = 8;   // the fused form of launch.h (k_line_fused): longest lines, planes per patch
 int g_line_wide = 0;          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
@@ -138,6 +139,37 @@ void line_colour_wide(const emg::Level<T> &L, int c, const T *fac, const double 
     }
 }
 
+// all colour passes of a call on the private levels of the patches (kernels.hip: k_line_fused + k_line_fused_back):
+// every patch is loaded from the level as it was before the call, the owned planes are written back at the end
+template <class T, int DIR>
+void line_fused(const emg::Level<T> &L, const emg::FusedPlan &P, const T *fac, const double *lfac, const T *nfac)
+{
+    std::vector<std::vector<T>> bufs(P.nwg);
+    for (int wg = 0; wg < P.nwg; ++wg) {
+        emg::FusedPatch F;
+        emg::fused_patch(P, wg, F);
+        bufs[wg].assign(emg::fused_private_elems(P.dl, P.nmax, L.nx, L.ny, L.nz), T(1e300));
+        const emg::Level<T> Q = emg::fused_private_level(L, P, F, bufs[wg].data());
+        emg::fused_copy_in(L, Q, P, F, 0, 0, 1);
+        const emg::Axes<T, DIR> A(Q);
+        for (int t = 1; t <= P.npass; ++t) {
+            const emg::FusedLines S = emg::fused_lines(P, F, t);
+            const int c = S.colour, lines = P.cntp[c] * P.cntq[c];   // (host: plain indexing)
+            for (int ll = 0; ll < S.n; ++ll) {
+                int i1, i2, lid;
+                emg::fused_line<DIR>(P, F, S, ll, i1, i2, lid);
+                emg::line_wide_ref<T, DIR>(A, i1, i2, lines, lid, fac + P.rec0[c] * 15, lfac + P.rec0[c] * 8, nfac + P.rec0[c] * 16);
+            }
+        }
+    }
+    for (int wg = 0; wg < P.nwg; ++wg) {
+        emg::FusedPatch F;
+        emg::fused_patch(P, wg, F);
+        const emg::Level<T> Q = emg::fused_private_level(L, P, F, bufs[wg].data());
+        emg::fused_copy_out(L, Q, P, F, 0, 0, 1);
+    }
+}
+
 template <class T, int DIR> void line_setup_all(const emg::Level<T> &L, T *fac, double *lfac)
 {
     for (int c = 0; c < 4; ++c) {
@@ -203,6 +235,15 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
                         else emg::tile_pst_setup<T, TB, false>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
                     }
     }
+    if (wide && emg::fused_capable(lr - 1, nx, ny, nz, g_line_fused)) {
+        const emg::FusedPlan P = emg::fused_plan(lr - 1, nx, ny, nz, nu, g_line_order, false, g_line_fused_w);
+        if (P.npass <= emg::FUSED_MAXPASS) {
+            if (lr == 1) line_fused<T, 0>(L, P, fac.data(), lfac.data(), nfac.data());
+            else if (lr == 2) line_fused<T, 1>(L, P, fac.data(), lfac.data(), nfac.data());
+            else line_fused<T, 2>(L, P, fac.data(), lfac.data(), nfac.data());
+            return;
+        }
+    }
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;
@@ -250,6 +291,7 @@ void emu_set_point_slab(int t) { g_point_slab = t; }
 void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
 void emu_set_line_order(int o) { g_line_order = o; }
 void emu_set_line_wide(int w) { g_line_wide = w; }
+void emu_set_line_fused(int n0max, int w) { g_line_fused = n0max; g_line_fused_w = w; }
 void emu_set_point_order(int o) { emg::point_order_ref() = o; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
