@@ -291,8 +291,7 @@ def smoothers_256(device, n=256, nu=2, reps=5):
                           'achieved': gbs_exec, 'unit': 'GB/s', 'frac': gbs_exec / HBM_PEAK_GBS,
                           'achieved_delivered': gbs_deliv, 'frac_delivered': gbs_deliv / HBM_PEAK_GBS,
                           'gcell_sweeps_per_s_delivered': grid.n_cells * nu / (ms_call * 1e-3) / 1e9}
-        lv._factors.pop(lr, None)               # 5 GB of line factors per direction: free them
-        torch.cuda.empty_cache()
+        lv._factors.pop(lr, None)               # 5 GB of line factors per direction: back to the caching allocator
     return {'level': f'{n}^3 tri-axial, complex fp64, {nu} sweeps per call',
             'bytes_per_cell_sweep': BYTES_PER_CELL_SWEEP['triaxial'], 'peak': HBM_PEAK_GBS, 'smoothers': out}
 
@@ -330,12 +329,24 @@ def survey_8(device):
     return out
 
 
-def survey_config5(device, name='salt384'):
+def survey_config5(device, name='salt384', repeats=2):
     """BASELINE.json config 5 on ONE GPU: 4 frequencies x 2 sources on the 384 x 256 x 256 salt-like model as whole
     solves to tol 1e-6. Sources of one frequency share the model, hence every level's line factorisation: the two
     sources of a frequency are solved TOGETHER (solver.solve_batch; on the levels with long lines one workgroup
     serves its lines for both right-hand sides per factor fetch, k_line_stream) -- against one after the other
-    on a hierarchy they share (what `parallel.compute(reuse=True)` does). Fields are bit-identical either way."""
+    on a hierarchy they share (what `parallel.compute(reuse=True)` does). Fields are bit-identical either way.
+
+    Every (mode, frequency) call is made `repeats` times and is taken apart: source vectors on the host, the device
+    hierarchy (allocations, model upload, finest-level buffers), the solve (coarse levels, factorisations and graph
+    captures happen inside its first cycles: the per-cycle wall times are reported), and what the caching
+    allocator held before and after. `ms_per_source` is computed from the FASTEST repeat of every frequency;
+    `first_repeat` gives the same sum over the first calls (what a process that solves every pair once pays).
+
+    The buffers of a finished call stay with torch's caching allocator, as they do in `parallel.compute` (round 4
+    returned them to the driver with torch.cuda.empty_cache() before every call: after ~50 GB have been handed
+    back, one of the next hipMalloc calls takes 1.7 - 2 s on this stack -- reproduced with torch.empty alone,
+    tools/config5_stall.py malloc, profiles/r05_config5_stall.txt; that was the 2.9 / 2.5 s of two of the four
+    batched pairs in BENCH_r04.json, not the kernels)."""
     import torch
     import emg3d_amd as emg3d
     from emg3d_amd import solver, models
@@ -345,31 +356,53 @@ def survey_config5(device, name='salt384'):
     opts = {k: v for k, v in wls[0]['opts'].items() if k != 'sslsolver'}
     opts.update(tol=1e-6, verb=0)
     out = {'workload': f'config 5: 4 frequencies x 2 sources, {grid.shape_cells} salt-like model, whole solves to '
-           'tol 1e-6 (setup of the hierarchy of each frequency included)'}
-    for tag, together in (('one_by_one', False), ('two_sources_of_a_frequency_together', True)):
+           'tol 1e-6 (setup of the hierarchy of each frequency included)', 'repeats': repeats}
+    gb = 1.0 / 2 ** 30
+
+    def one_call(pair, together):
         torch.cuda.synchronize(device)
+        rec = {'reserved_gb_before': torch.cuda.memory_reserved(device) * gb}
         t0 = time.perf_counter()
-        its, work, per_freq = [], 0.0, []
+        sfs = [emg3d.get_source_field(grid, w['source'], w['frequency']) for w in pair]
+        t1 = time.perf_counter()
+        hier = solver.Hierarchy(models.VolumeModel(model, sfs[0]), batch=2 if together else 1)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        if together:
+            res = emg3d.solve_batch(model, sfs, keep_fields=False, hierarchy=hier, **opts)
+        else:
+            res = [emg3d.solve(model, sf, sslsolver=False, return_info=True, hierarchy=hier, _download=False, **opts)
+                   for sf in sfs]
+        torch.cuda.synchronize(device)
+        t3 = time.perf_counter()
+        rec['reserved_gb_after'] = torch.cuda.memory_reserved(device) * gb
+        rec['allocated_gb_after'] = torch.cuda.memory_allocated(device) * gb
+        del hier
+        infos = [info for _, info in res]
+        # wall time of the cycles of every solve call (cycle 1 .. 3 hold level set-up, factorisations, graph captures)
+        cyc = [np.diff(np.asarray(info['runtime_at_cycle'], dtype=float)) for info in infos[:1 if together else 2]]
+        rec.update(seconds=t3 - t0, source_vectors_s=t1 - t0, hierarchy_s=t2 - t1, solve_s=t3 - t2,
+                   cycles=[int(info['it_mg']) for info in infos],
+                   cycle_wall_ms=[[round(1e3 * float(x), 1) for x in c] for c in cyc],
+                   work=float(sum(info['smoother_cell_sweeps'] for info in infos)))
+        return rec
+
+    for tag, together in (('one_by_one', False), ('two_sources_of_a_frequency_together', True)):
+        per_freq, best, first, its, work = [], 0.0, 0.0, [], 0.0
         for fi in range(4):
-            tf = time.perf_counter()
             pair = wls[2 * fi:2 * fi + 2]
-            sfs = [emg3d.get_source_field(grid, w['source'], w['frequency']) for w in pair]
-            if together:
-                res = emg3d.solve_batch(model, sfs, keep_fields=False, **opts)
-            else:
-                hier = solver.Hierarchy(models.VolumeModel(model, sfs[0]))
-                res = [emg3d.solve(model, sf, sslsolver=False, return_info=True, hierarchy=hier, _download=False, **opts)
-                       for sf in sfs]
-                del hier
-            for _, info in res:
-                its.append(int(info['it_mg']))
-                work += info['smoother_cell_sweeps']
-            torch.cuda.synchronize(device)
-            torch.cuda.empty_cache()
-            per_freq.append({'frequency': pair[0]['frequency'], 'seconds': time.perf_counter() - tf})
-        dt = time.perf_counter() - t0
-        out[tag] = {'seconds': dt, 'ms_per_source': dt / 8 * 1e3, 'Mcell_sweeps_per_s': work / dt / 1e6,
-                    'cycles': its, 'per_frequency': per_freq}
+            calls = [one_call(pair, together) for _ in range(repeats)]
+            secs = [c['seconds'] for c in calls]
+            best += min(secs)
+            first += secs[0]
+            its += calls[0]['cycles']
+            work += calls[0].pop('work')
+            for c in calls[1:]:
+                c.pop('work')
+            per_freq.append({'frequency': pair[0]['frequency'], 'seconds': min(secs), 'calls': calls})
+        out[tag] = {'seconds': best, 'ms_per_source': best / 8 * 1e3, 'Mcell_sweeps_per_s': work / best / 1e6,
+                    'cycles': its, 'first_repeat': {'seconds': first, 'ms_per_source': first / 8 * 1e3},
+                    'per_frequency': per_freq}
     return out
 
 
@@ -588,8 +621,8 @@ def run_gpu(args):
         except Exception as exc:        # informational block: never takes the bench line down
             out['time_to_tol'] = {'error': repr(exc)}
     if rank == 0 and world == 1 and not args.no_256:
-        del b
-        torch.cuda.empty_cache()
+        del b            # (its buffers stay with the caching allocator: handing tens of GB back to the driver makes a later
+                         #  hipMalloc take 1.7 - 2 s on this stack, profiles/r05_config5_stall.txt)
         out['smoothers_256'] = sm = smoothers_256(device)
         # the north-star kernel (gauss_seidel at 256^3) as a second roofline entry, per launch
         pt = sm['smoothers']['gauss_seidel (k_gs_point_tile)']
@@ -600,13 +633,11 @@ def run_gpu(args):
             'traffic': pmc_traffic('smoothers_256', 'k_gs_point_tile')[0],
             'traffic_source': pmc_traffic('smoothers_256', 'k_gs_point_tile')[1]}
     if rank == 0 and world == 1 and not args.no_survey:
-        torch.cuda.empty_cache()
         try:
             out['survey_8_sources'] = survey_8(device)
         except Exception as exc:        # informational block: never takes the bench line down
             out['survey_8_sources'] = {'error': repr(exc)}
     if rank == 0 and world == 1 and not args.no_survey:
-        torch.cuda.empty_cache()
         try:
             out['survey_config5'] = survey_config5(device)
         except Exception as exc:        # informational block: never takes the bench line down
@@ -804,6 +835,8 @@ def main():
     ap.add_argument('--no-ttt', action='store_true', help="skip the time-to-tolerance block")
     ap.add_argument('--no-256', action='store_true',
                     help="skip the separate 256^3 smoother measurement ('smoothers_256')")
+    ap.add_argument('--only-config5', action='store_true',
+                    help="only the informational block 'survey_config5' (config 5 on one GPU, taken apart per call)")
     ap.add_argument('--line-factors', default=None, choices=['resident', 'rebuild', 'single'],
                     help="factor-memory policy of the hierarchy (solver.Hierarchy; default: resident)")
     args = ap.parse_args()
@@ -817,6 +850,11 @@ def main():
             k, v = o.split('=')
             if _lib.lib().emg3d_set_option(k.encode(), int(v)) != 0:
                 raise SystemExit(f"unknown option {o}")
+    if args.only_config5:
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps({'survey_config5': survey_config5(torch.device('cuda', 0))}))
+        return
     out, wl, rank, world = run_gpu(args)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
