@@ -122,7 +122,11 @@ int g_line_stream_lf = 1;
 // block for everything else) on lines of at most this many blocks, where the level holds the N records (launch.h:
 // line_wide_capable -- a function of the level's shape alone, so that buffers sized once stay valid whatever the
 // option says); 0: never
-int g_line_wide = 0;
+int g_line_wide = 17;
+// ... with the N records formed in the kernel and kept in LDS (1); 0 (default): fetched from the stored records
+// (measured, tools/wide_times.py: equal on lines of 4 ... 16 and 64 blocks, 16 % slower on 32-block lines -- the
+//  block threads' phase is what a launch waits for, and it gets longer)
+int g_line_wide_n = 0;
 // ALL colour passes of a smoothing call in one launch (k_line_fused + k_line_fused_back) on the slab / rod levels whose
 // lines have at most this many blocks (launch.h: fused_capable; <= FUSED_N0_CAP); 0: never. line_fused_w: node planes
 // a workgroup owns (4 .. 64; fewer = more workgroups, each with the same halo)
@@ -145,7 +149,7 @@ template <> bool pst_stored_half<cplx>(int flags) { return (flags & emg::LEVEL_E
 // each of them.
 hipError_t allow_lds(const void *kernel, size_t bytes)
 {
-    constexpr int MAXDEV = 64, MAXK = 64;
+    constexpr int MAXDEV = 64, MAXK = 256;
     static const void *seen[MAXDEV][MAXK];
     static size_t seen_bytes[MAXDEV][MAXK];
     static int nseen[MAXDEV];
@@ -157,6 +161,10 @@ hipError_t allow_lds(const void *kernel, size_t bytes)
             if (seen[dev][i] == kernel && seen_bytes[dev][i] >= bytes) return hipSuccess;
     }
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < MAXDEV) {
+        for (int i = 0; i < nseen[dev]; ++i)
+            if (seen[dev][i] == kernel) { seen_bytes[dev][i] = bytes; return e; }      // (a larger request of a known kernel)
+    }
     if (e == hipSuccess && dev >= 0 && dev < MAXDEV && nseen[dev] < MAXK) {
         seen[dev][nseen[dev]] = kernel;
         seen_bytes[dev][nseen[dev]] = bytes;
@@ -1160,7 +1168,10 @@ __device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow,
     }
 }
 
-template <class T, int DIR, bool BATCH>
+// NLDS: the N records of the workgroup's blocks are formed by the block threads (which hold T_k and C_k anyway:
+// sixteen multiply-adds, wide_n_record -- the bits of the stored records) and kept in LDS for the chains, instead of
+// being fetched from memory by the chain lanes: 256 of ~1 100 B per block less, and no memory latency inside the chains.
+template <class T, int DIR, bool BATCH, bool NLDS>
 __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int colour, int cntp, int cntq, int lpw,
                                                          const T *fac, const double *lfac, const T *nfac)
 {
@@ -1174,6 +1185,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     const int rows = n0 + 1;                               // (row n0 of a line: the dummy row)
     T *const GY = reinterpret_cast<T *>(lw_smem);          // [lpw][rows][LW_ROW]: g, then y
     T *const GH = GY + (size_t)lpw * rows * LW_ROW;        //                      g', then h
+    T *const NC = GH + (size_t)lpw * rows * LW_ROW;        // NLDS: [lpw][n0][16] the N records
     const int t = threadIdx.x;
     const bool isq = t >= LW_BLOCK_THREADS;
     const int tq = t - LW_BLOCK_THREADS;
@@ -1195,13 +1207,20 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
         if (!isq) {
             const emg::WideBlock wb = emg::wide_block(j, mk);
             k = wb.k; mir = wb.mir;
-            T rb[5];
-            emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
             const size_t rec = (size_t)k * nlines + lid;
 #pragma unroll
             for (int q = 0; q < 15; ++q) Tk[q] = fac[rec * 15 + q];
 #pragma unroll
             for (int q = 0; q < 8; ++q) lf[q] = lfac[rec * 8 + q];
+            if constexpr (NLDS) {
+                T N[16];
+                emg::wide_n_record<T, 21>(Tk, lf, N);
+                T *const nc = NC + ((size_t)ll * n0 + k) * 16;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) nc[q] = N[q];
+            }
+            T rb[5];
+            emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
             T g[4];
             emg::wide_g<T, 21>(Tk, rb, g);
             T *const row = GY + ((size_t)ll * rows + k) * LW_ROW;
@@ -1234,13 +1253,14 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     const int wave = t >> 6, lane = t & 63, half = wave >> 1;
     const int cl = min((wave & 1) * 4 + (lane >> 4), nl - 1);
     const bool chain_wave = (wave & 1) * 4 < nl;
-    const T *const nbase = nfac + (size_t)line0 * 16;
-    const size_t nrow = (size_t)nlines * 16;
+    const T *const nbase = NLDS ? NC : nfac + (size_t)line0 * 16;
+    const size_t nrow = NLDS ? (size_t)16 : (size_t)nlines * 16;
+    const int noff = NLDS ? cl * n0 * 16 : cl * 16;
     // ---- (F) forward chains: y_k = g_k - N_k y_kn ---------------------------------------------------
     {
         const int nst = half ? nbb : nbt;
         if (chain_wave && nst > 0)
-            wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, nbase, nrow, cl * 16, half ? n0 - 1 : 0,
+            wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, nbase, nrow, noff, half ? n0 - 1 : 0,
                                  half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>());
     }
     WSTAMP(3);
@@ -1298,7 +1318,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
             const int kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
             T *const rw = GH + (size_t)cl * rows * LW_ROW;
             const T v0 = rw[kb0 * LW_ROW + (lane & 3)];
-            wide_chain<T, true>(rw, nbase, nrow, cl * 16, kb0 + dk, kb0, dk, nst, lane & 15, v0);
+            wide_chain<T, true>(rw, nbase, nrow, noff, kb0 + dk, kb0, dk, nst, lane & 15, v0);
         }
     }
     WSTAMP(7);
@@ -2299,13 +2319,18 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const size_t dummy_off = vstride - emg::LINE_DUMMY;
     if (line_wide_used(DIR, L.nx, L.ny, L.nz)) {
         const int lpw = wide_lpw(lc.n0);
-        const size_t smem = (size_t)2 * lpw * (lc.n0 + 1) * LW_ROW * sizeof(T);
+        const bool nlds = g_line_wide_n != 0;
+        const size_t smem = ((size_t)2 * lpw * (lc.n0 + 1) * LW_ROW + (nlds ? (size_t)lpw * lc.n0 * 16 : 0)) * sizeof(T);
         const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + lc.fac_off / 15 * 16;
         const dim3 grid(cdiv(lc.lines, lpw), L.batch);
-        if (L.batch > 1)
-            hipLaunchKernelGGL((k_line_wide<T, DIR, true>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
-        else
-            hipLaunchKernelGGL((k_line_wide<T, DIR, false>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
+#define LW_LAUNCH(B, N)                                                                                        \
+    do {                                                                                                       \
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_wide<T, DIR, B, N>), smem);                      \
+        hipLaunchKernelGGL((k_line_wide<T, DIR, B, N>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf); \
+    } while (0)
+        if (L.batch > 1) { if (nlds) LW_LAUNCH(true, true); else LW_LAUNCH(true, false); }
+        else { if (nlds) LW_LAUNCH(false, true); else LW_LAUNCH(false, false); }
+#undef LW_LAUNCH
         return;
     }
     const LinePlan P = line_plan<T>(lc, L.batch);
@@ -2687,7 +2712,8 @@ static const OptionEntry g_options[] = {
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
-    {"line_wide", &g_line_wide},         {"line_fused", &g_line_fused},         {"line_fused_w", &g_line_fused_w},
+    {"line_wide", &g_line_wide},         {"line_wide_n", &g_line_wide_n},
+            {"line_fused", &g_line_fused},         {"line_fused_w", &g_line_fused_w},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value

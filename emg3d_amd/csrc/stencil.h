@@ -1523,7 +1523,7 @@ constexpr size_t WIDE_RECORDS_MAX = (size_t)1 << 19;   // ... on levels with at 
 EMG_HD bool line_wide_capable(int n0, size_t records) { return n0 >= 2 && n0 <= WIDE_N0_MAX && records <= WIDE_RECORDS_MAX; }
 
 // N = (T C)[1..4, 1..4]: N[4 (a-1) + (b-1)] = T(a,0) l0[b] + T(a,b) d[b]
-template <class T> EMG_HD void wide_n_record(const T (&Tk)[15], const double (&lf)[8], T (&N)[16])
+template <class T, int NT = 15> EMG_HD void wide_n_record(const T (&Tk)[NT], const double (&lf)[8], T (&N)[16])
 {
 #pragma unroll
     for (int a = 1; a < 5; ++a)
