@@ -596,6 +596,12 @@ inline size_t line_nfac_elems(int dir, int nx, int ny, int nz)
     const size_t rec = line_records(dir, nx, ny, nz);
     return line_wide_capable(line_n0(dir, nx, ny, nz), rec) ? 16 * rec : 0;
 }
+// doubles of the right-hand-side coefficient tables of k_line_lanes (32 per block record), behind the N records, on
+// the levels that hold those
+inline size_t line_rtab_doubles(int dir, int nx, int ny, int nz)
+{
+    return line_nfac_elems(dir, nx, ny, nz) > 0 ? 32 * line_records(dir, nx, ny, nz) : 0;
+}
 inline size_t line_lfac_elems(int dir, int nx, int ny, int nz)
 {
     return (size_t)8 * line_padded(line_n0(dir, nx, ny, nz)) * line_total(dir, nx, ny, nz);

@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <cmath>
 #include <algorithm>
 #include <type_traits>
 #include <vector>
@@ -273,6 +274,29 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
     }
 }
 
+// the right-hand side of every block row of a direction in the table form of k_line_lanes (stencil.h: line_rhs_coefs /
+// line_rhs_entry) against line_rhs: the largest difference, relative to the largest entry
+template <class T, int DIR> double rhs_table_diff(const emg::Level<T> &L)
+{
+    const emg::Axes<T, DIR> A(L);
+    double worst = 0.0, scale = 0.0;
+    for (int i2 = 1; i2 < A.n2(); ++i2)
+        for (int i1 = 1; i1 < A.n1(); ++i1)
+            for (int k = 0; k < A.n0(); ++k) {
+                T want[5];
+                emg::line_rhs<T, DIR>(A, k, i1, i2, want);
+                double cf[30];
+                emg::line_rhs_coefs<T, DIR>(A, k, i1, i2, cf);
+                for (int r = 0; r < 5; ++r) {
+                    const double c6[6] = {cf[6 * r], cf[6 * r + 1], cf[6 * r + 2], cf[6 * r + 3], cf[6 * r + 4], cf[6 * r + 5]};
+                    const T got = emg::line_rhs_entry<T, DIR>(A, k, i1, i2, r, c6);
+                    worst = std::max(worst, emg::abs2(got - want[r]));
+                    scale = std::max(scale, emg::abs2(want[r]));
+                }
+            }
+    return scale > 0 ? std::sqrt(worst / scale) : 0.0;
+}
+
 template <class T> double residual(const LevelArgs *lv, void *rx, void *ry, void *rz)
 {
     emg::Level<T> L = to_level<T>(lv);
@@ -293,6 +317,16 @@ void emu_set_line_order(int o) { g_line_order = o; }
 void emu_set_line_wide(int w) { g_line_wide = w; }
 void emu_set_line_fused(int n0max, int w) { g_line_fused = n0max; g_line_fused_w = w; }
 void emu_set_point_order(int o) { emg::point_order_ref() = o; }
+
+double emu_rhs_table_diff(const LevelArgs *lv, int lr)
+{
+    if (lv->is_complex) {
+        const emg::Level<cplx> L = to_level<cplx>(lv);
+        return lr == 1 ? rhs_table_diff<cplx, 0>(L) : lr == 2 ? rhs_table_diff<cplx, 1>(L) : rhs_table_diff<cplx, 2>(L);
+    }
+    const emg::Level<double> L = to_level<double>(lv);
+    return lr == 1 ? rhs_table_diff<double, 0>(L) : lr == 2 ? rhs_table_diff<double, 1>(L) : rhs_table_diff<double, 2>(L);
+}
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
 {

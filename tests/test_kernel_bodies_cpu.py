@@ -442,3 +442,14 @@ def test_fused_line_passes_equal_pass_by_pass(shape, w):
     finally:
         lib.emu_set_line_wide(0)
         lib.emu_set_line_fused(0, 8)
+
+
+@pytest.mark.parametrize('shape,freq', [((6, 5, 7), 1.3), ((2, 9, 4), -2.0), ((12, 3, 3), 0.5), ((4, 4, 17), 1.3)])
+def test_rhs_table_form_equals_line_rhs(shape, freq):
+    """stencil.h: line_rhs_coefs / line_rhs_term / line_rhs_entry -- the right-hand side of a block row as source + six
+    tabulated (coefficient) x (field value) products per entry, what a lane of k_line_lanes evaluates -- against
+    line_rhs for every row of every line of the three directions (first and last rows, lines next to the faces):
+    the coefficients of the thirty terms, their field components and offsets, the zeroed last row."""
+    grid, vm, s, e0 = _random_case(shape, freq, 5)
+    for lr in (1, 2, 3):
+        assert emu.rhs_table_diff(e0, s, vm, lr) < 1e-14, (shape, lr)

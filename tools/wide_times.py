@@ -7,14 +7,14 @@ from emg3d_amd import _lib
 from microbench import make_level
 from fused_times import time_call
 lib = _lib.lib()
-for n in (4, 8, 16, 32, 64):
+for n in (2, 4, 8, 16, 32):
     shape = (256, n, n)
     lv, grid = make_level(0, 'triaxial', shape=shape)
     for lr in (2, 3):
         row = []
-        for name, opts in (('colour', {'line_wide': 0}), ('wide, N fetched', {'line_wide': 65, 'line_wide_n': 0}), ('wide, N in LDS', {'line_wide': 65, 'line_wide_n': 1})):
+        for name, opts in (('colour', {'line_wide': 0, 'line_lanes': 0}), ('wide', {'line_wide': 65, 'line_lanes': 0}), ('lanes', {'line_lanes': 33})):
             for k, v in opts.items():
                 lib.emg3d_set_option(k.encode(), v)
             row.append(f"{name} {time_call(lv, lr) / 7:7.2f}")
-        lib.emg3d_set_option(b'line_wide', 0); lib.emg3d_set_option(b'line_wide_n', 1)
+        lib.emg3d_set_option(b'line_wide', 17); lib.emg3d_set_option(b'line_lanes', 17)
         print(f"{str(shape):>14s} lr={lr}  us per launch:  " + '   '.join(row), flush=True)
