@@ -121,21 +121,9 @@ int g_line_stream_lf = 1;
 // the wide form of the line pass (k_line_wide: four-unknown chains on sixteen lanes per half-line, one thread per
 // block for everything else) on lines of at most this many blocks, where the level holds the N records (launch.h:
 // line_wide_capable -- a function of the level's shape alone, so that buffers sized once stay valid whatever the
-// option says); 0: never
+// option says); 0: never. Default 17 (round 5): on 4 ... 16-block lines a launch takes 6.0 / 6.1 / 8.5 us against 6.0 / 8.1 /
+// 12.0 of k_line_colour, on 32- and 64-block lines it is no faster (profiles/r05_small_level_experiments.txt)
 int g_line_wide = 17;
-// ... with eight lanes per block and tabulated right-hand-side coefficients (k_line_lanes) on lines of at most this
-// many blocks (<= 33; it takes precedence over k_line_wide there); 0: never
-int g_line_lanes = 17;
-// ... with the N records formed in the kernel and kept in LDS (1); 0 (default): fetched from the stored records
-// (measured, tools/wide_times.py: equal on lines of 4 ... 16 and 64 blocks, 16 % slower on 32-block lines -- the
-//  block threads' phase is what a launch waits for, and it gets longer)
-int g_line_wide_n = 0;
-// ALL colour passes of a smoothing call in one launch (k_line_fused + k_line_fused_back) on the slab / rod levels whose
-// lines have at most this many blocks (launch.h: fused_capable; <= FUSED_N0_CAP); 0: never. line_fused_w: node planes
-// a workgroup owns (4 .. 64; fewer = more workgroups, each with the same halo)
-int g_line_fused = 0;
-int g_line_fused_w = 8;
-constexpr int FUSED_N0_CAP = 17, FUSED_W_MIN = 4, FUSED_W_MAX = 64;
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
@@ -1123,58 +1111,23 @@ __device__ unsigned long long g_wide_stamps[32];
 // One chain of a 16-lane group: nst steps v <- acc_i - M_i v, M = N (forward) or N^T (BWD), acc_i from / result to
 // the LDS row krow0 + i dk, N from record kmat0 + i dk. v enters (and leaves an even number of steps) with lane
 // (a, b) holding entry b.
-// (es: distance between the sixteen entries of a record -- 1 in the factor buffer; the LDS copy of k_line_fused keeps
-//  entry q of all its records in one plane)
-template <class T, bool BWD, bool PRE>
-__device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow, int loff, int krow0, int kmat0,
-                                           int dk, int nst, int l16, T v, int es, const T (&pre)[4]);
 template <class T, bool BWD>
-__device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow, int loff, int krow0, int kmat0,
-                                           int dk, int nst, int l16, T v, int es = 1)
-{
-    const T none[4] = {v, v, v, v};
-    wide_chain<T, BWD, false>(rows, nbase, nrow, loff, krow0, kmat0, dk, nst, l16, v, es, none);
-}
-// The N entries of the first four steps of a chain, fetched ahead of time (wide_chain<..., PRE>): a launch on a small
-// level is a string of memory round trips -- arguments, the block threads' loads, the forward chains' first N
-// entries, the backward chains' --, and the last two need nothing that is computed in the launch.
-template <class T, bool BWD>
-__device__ __forceinline__ void wide_chain_preload(const T *nbase, size_t nrow, int loff, int kmat0, int dk, int nst, int l16,
-                                                   T (&pre)[4], int es = 1)
+__device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow, unsigned loff, int krow0, int kmat0,
+                                           int dk, int nst, int l16, T v)
 {
     const int a = l16 >> 2, b = l16 & 3;
-    const int e1 = 4 * a + b, e2 = 4 * b + a;
-    const int eI = loff + es * (BWD ? e2 : e1), eII = loff + es * (BWD ? e1 : e2);
-    if (nst <= 0) return;              // (no chain: no record either)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const int ic = min(d, nst - 1);
-        pre[d] = nbase[(ptrdiff_t)((size_t)(kmat0 + ic * dk) * nrow) + ((d & 1) ? eII : eI)];
-    }
-}
-template <class T, bool BWD, bool PRE>
-__device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow, int loff, int krow0, int kmat0,
-                                           int dk, int nst, int l16, T v, int es, const T (&pre)[4])
-{
-    const int a = l16 >> 2, b = l16 & 3;
-    const int e1 = 4 * a + b, e2 = 4 * b + a;
-    const int eI = loff + es * (BWD ? e2 : e1), eII = loff + es * (BWD ? e1 : e2);
+    const unsigned e1 = 4 * a + b, e2 = 4 * b + a;
+    const unsigned eI = loff + (BWD ? e2 : e1), eII = loff + (BWD ? e1 : e2);
     const int rdI = b == 0 ? a : 4, wrI = b == 0 ? a : 5;
     const int rdII = a == 0 ? b : 4, wrII = a == 0 ? b : 5;
     T nr[4], ac[4];
     auto fetch = [&](int d, int i) {
         const int ic = min(i, nst - 1);
-        nr[d] = nbase[(ptrdiff_t)((size_t)(kmat0 + ic * dk) * nrow) + ((d & 1) ? eII : eI)];
+        nr[d] = nbase[(size_t)(kmat0 + ic * dk) * nrow + ((d & 1) ? eII : eI)];
         ac[d] = rows[(krow0 + ic * dk) * LW_ROW + ((d & 1) ? rdII : rdI)];
     };
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        if constexpr (PRE) {
-            const int ic = min(d, nst - 1);
-            nr[d] = pre[d];
-            ac[d] = rows[(krow0 + ic * dk) * LW_ROW + ((d & 1) ? rdII : rdI)];
-        } else fetch(d, d);
-    }
+    for (int d = 0; d < 4; ++d) fetch(d, d);
     auto step = [&](int d, int i) {
         T p = emg::nmad(nr[d], v, ac[d]);
         if (!(d & 1)) {
@@ -1204,10 +1157,7 @@ __device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow,
     }
 }
 
-// NLDS: the N records of the workgroup's blocks are formed by the block threads (which hold T_k and C_k anyway:
-// sixteen multiply-adds, wide_n_record -- the bits of the stored records) and kept in LDS for the chains, instead of
-// being fetched from memory by the chain lanes: 256 of ~1 100 B per block less, and no memory latency inside the chains.
-template <class T, int DIR, bool BATCH, bool NLDS>
+template <class T, int DIR, bool BATCH>
 __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int colour, int cntp, int cntq, int lpw,
                                                          const T *fac, const double *lfac, const T *nfac)
 {
@@ -1221,7 +1171,6 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     const int rows = n0 + 1;                               // (row n0 of a line: the dummy row)
     T *const GY = reinterpret_cast<T *>(lw_smem);          // [lpw][rows][LW_ROW]: g, then y
     T *const GH = GY + (size_t)lpw * rows * LW_ROW;        //                      g', then h
-    T *const NC = GH + (size_t)lpw * rows * LW_ROW;        // NLDS: [lpw][n0][16] the N records
     const int t = threadIdx.x;
     const bool isq = t >= LW_BLOCK_THREADS;
     const int tq = t - LW_BLOCK_THREADS;
@@ -1235,22 +1184,6 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     int i1 = 0, i2 = 0, k = 0, mir = 0;
     T Tk[21], r[6];                                         // block thread: T_k (15), r -> c (5); middle: T_Q (21), r_Q (6)
     double lf[8], lf2[8];                                   // C_k; middle: B_m, U_{m+1}
-    // the chain groups: waves 0 / 1 the top halves of lines 0..3 / 4..7, waves 2 / 3 their bottom halves -- a wave's
-    // groups all walk the same number of steps; groups beyond the last line repeat it (identical stores); their first N
-    // entries are fetched before anything else (wide_chain_preload)
-    const int wave = t >> 6, lane = t & 63, half = wave >> 1;
-    const int cl = min((wave & 1) * 4 + (lane >> 4), nl - 1);
-    const bool chain_wave = (wave & 1) * 4 < nl;
-    const T *const nbase = NLDS ? NC : nfac + (size_t)line0 * 16;
-    const size_t nrow = NLDS ? (size_t)16 : (size_t)nlines * 16;
-    const int noff = NLDS ? cl * n0 * 16 : cl * 16;
-    T preF[4], preB[4];
-    if constexpr (!NLDS) {
-        if (chain_wave) {
-            wide_chain_preload<T, false>(nbase, nrow, noff, half ? n0 - 1 : 0, half ? -1 : 1, half ? nbb : nbt, lane & 15, preF);
-            wide_chain_preload<T, true>(nbase, nrow, noff, half ? mk + 2 : mk - 1, half ? 1 : -1, (half ? nbb : nbt) - 1, lane & 15, preB);
-        }
-    }
     // ---- (A) right-hand sides, factor records, g --------------------------------------------------
     if (has) {
         const int lid = line0 + ll;
@@ -1259,20 +1192,13 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
         if (!isq) {
             const emg::WideBlock wb = emg::wide_block(j, mk);
             k = wb.k; mir = wb.mir;
+            T rb[5];
+            emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
             const size_t rec = (size_t)k * nlines + lid;
 #pragma unroll
             for (int q = 0; q < 15; ++q) Tk[q] = fac[rec * 15 + q];
 #pragma unroll
             for (int q = 0; q < 8; ++q) lf[q] = lfac[rec * 8 + q];
-            if constexpr (NLDS) {
-                T N[16];
-                emg::wide_n_record<T, 21>(Tk, lf, N);
-                T *const nc = NC + ((size_t)ll * n0 + k) * 16;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) nc[q] = N[q];
-            }
-            T rb[5];
-            emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
             T g[4];
             emg::wide_g<T, 21>(Tk, rb, g);
             T *const row = GY + ((size_t)ll * rows + k) * LW_ROW;
@@ -1300,12 +1226,19 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     WSTAMP(1);
     __syncthreads();
     WSTAMP(2);
+    // the chain groups: waves 0 / 1 the top halves of lines 0..3 / 4..7, waves 2 / 3 their bottom halves -- a wave's
+    // groups all walk the same number of steps; groups beyond the last line repeat it (identical stores)
+    const int wave = t >> 6, lane = t & 63, half = wave >> 1;
+    const int cl = min((wave & 1) * 4 + (lane >> 4), nl - 1);
+    const bool chain_wave = (wave & 1) * 4 < nl;
+    const T *const nbase = nfac + (size_t)line0 * 16;
+    const size_t nrow = (size_t)nlines * 16;
     // ---- (F) forward chains: y_k = g_k - N_k y_kn ---------------------------------------------------
     {
         const int nst = half ? nbb : nbt;
         if (chain_wave && nst > 0)
-            wide_chain<T, false, !NLDS>(GY + (size_t)cl * rows * LW_ROW, nbase, nrow, noff, half ? n0 - 1 : 0,
-                                        half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>(), 1, preF);
+            wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, nbase, nrow, (unsigned)cl * 16, half ? n0 - 1 : 0,
+                                 half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>());
     }
     WSTAMP(3);
     __syncthreads();
@@ -1362,7 +1295,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
             const int kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
             T *const rw = GH + (size_t)cl * rows * LW_ROW;
             const T v0 = rw[kb0 * LW_ROW + (lane & 3)];
-            wide_chain<T, true, !NLDS>(rw, nbase, nrow, noff, kb0 + dk, kb0, dk, nst, lane & 15, v0, 1, preB);
+            wide_chain<T, true>(rw, nbase, nrow, (unsigned)cl * 16, kb0 + dk, kb0, dk, nst, lane & 15, v0);
         }
     }
     WSTAMP(7);
@@ -1380,599 +1313,6 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
         emg::wide_block_scatter<T, DIR>(A, k, mir, i1, i2, x);
     }
     WSTAMP(9);
-}
-
-// ---- the colour pass of small levels with EIGHT LANES PER BLOCK: k_line_lanes ------------------------------
-// k_line_wide shortened the recurrences; what a launch on a 256 x 4 x 4 ... 256 x 16 x 16 level then waits for is the
-// rest: one thread per block walks the five right-hand-side entries with their face averages, five rows of T r, c,
-// w_0, g', five rows of T (c - h) -- ~1 500 dependent-issue instructions in a wave that has the SIMD to itself
-// (profiles/r05_fused_phase_stamps.txt: ~6 ticks per instruction). Here every ENTRY / ROW has its own lane:
-//   * right-hand side: lane r of a block forms entry r as  source + six (coefficient) x (field value)  from the row's
-//     coefficient table (k_line_lanes_setup: thirty doubles per block row, model-only like the factors; stencil.h:
-//     line_rhs_coefs / line_rhs_entry) -- no zeta, no widths, no face averages in the pass;
-//   * every product with T_k: lane a holds ROW a of the packed record (five entries, loaded once, used for g, w_0 and
-//     x) and the five operands are exchanged through LDS inside the block's eight lanes (same wave: no barrier);
-//   * c, g', the middle block's z, x_Q, h: one lane per entry likewise.
-// The recurrences are k_line_wide's (wide_chain, sixteen lanes per half-line, N records). Same factors T_k, C_k, N_k;
-// the right-hand sides are summed in the table's order, so results agree with the other line kernels to rounding.
-constexpr int LL_THREADS = 256, LL_LANES = 8, LL_ROW = 6;
-inline int lanes_lpw(int n0) { return std::max(1, std::min(8, LL_THREADS / (LL_LANES * std::max(n0 - 1, 1)))); }
-constexpr int RTAB_DOUBLES = 32;          // per block row: 5 entries x 6 coefficients (+ 2 unused)
-
-// the coefficient tables of a direction, one thread per (block row, line) of every class (after k_line_setup)
-template <class T, int DIR>
-__global__ __launch_bounds__(128) void k_line_lanes_setup(emg::Level<T> L, SetupClasses S, double *rtab)
-{
-    const int c = blockIdx.z, cntp = S.cntp[c], cntq = S.cntq[c];
-    const emg::Axes<T, DIR> A(L);
-    const int n0 = A.n0(), n0p = emg::line_padded(n0);
-    const int lid = blockIdx.x * 128 + threadIdx.x, k = blockIdx.y;
-    if (cntp <= 0 || lid >= cntp * cntq || k >= n0) return;
-    int i1, i2, l2;
-    emg::line_of_thread<DIR>(c, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
-    double cf[30];
-    emg::line_rhs_coefs<T, DIR>(A, k, i1, i2, cf);
-    double *const o = rtab + ((size_t)(S.fac_off[c] / 15) + (size_t)k * (cntp * cntq) + lid) * RTAB_DOUBLES;
-#pragma unroll
-    for (int j = 0; j < 30; ++j) o[j] = cf[j];
-    (void)n0p;
-}
-
-// (LDS written by some lanes of a wave, read by others of the same wave: the hardware runs a wave's LDS operations in
-//  order; this keeps the compiler from moving them across)
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// row (two accumulators, as wide_row5 / wide_middle add them up)
-template <class T> __device__ __forceinline__ T lanes_row5(const T (&row)[6], const T *z)
-{
-    const T lo = emg::mad(row[4], z[4], emg::mad(row[1], z[1], emg::mad(row[0], z[0], emg::zero<T>())));
-    const T hi = emg::mad(row[3], z[3], emg::mad(row[2], z[2], emg::zero<T>()));
-    return lo + hi;
-}
-template <class T> __device__ __forceinline__ T lanes_row6(const T (&row)[6], const T *z)
-{
-    const T lo = emg::mad(row[4], z[4], emg::mad(row[2], z[2], emg::mad(row[0], z[0], emg::zero<T>())));
-    const T hi = emg::mad(row[5], z[5], emg::mad(row[3], z[3], emg::mad(row[1], z[1], emg::zero<T>())));
-    return lo + hi;
-}
-
-// line_rhs_entry (stencil.h) with the index arithmetic taken out of the terms: an array index is affine in the
-// position, so the seven values of an entry lie at  base(component) + d0 S0 + d1 S1 + d2 S2  with three base indices
-// and nine strides that are the same for all of them (the strides are uniform: scalar registers). Same values, same
-// order of the sums: the bits of line_rhs_entry.
-template <class T, int DIR> struct LanesIndex {
-    int base[3], s0[3], s1[3], s2[3];
-    ptrdiff_t eo[3], so[3];
-    __device__ __forceinline__ LanesIndex(const emg::Axes<T, DIR> &A, int k, int i1, int i2)
-    {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            base[c] = A.idx(c, k, i1, i2);
-            s0[c] = A.idx(c, 1, 0, 0) - A.idx(c, 0, 0, 0);
-            s1[c] = A.idx(c, 0, 1, 0) - A.idx(c, 0, 0, 0);
-            s2[c] = A.idx(c, 0, 0, 1) - A.idx(c, 0, 0, 0);
-            eo[c] = A.eoff(c);
-            so[c] = A.soff(c);
-        }
-    }
-    // (arithmetic with masks, not ?: -- a choice between uniform values by a lane's component became branches)
-    template <class V> static __device__ __forceinline__ V sel(const V (&v)[3], int c)
-    {
-        const V m1 = -(V)(c == 1), m2 = -(V)(c == 2);
-        return v[0] + ((v[1] - v[0]) & m1) + ((v[2] - v[0]) & m2);
-    }
-    // element offset (from component 0's array) of component c at (k + d0, i1 + d1, i2 + d2)
-    __device__ __forceinline__ ptrdiff_t at(int c, int d0, int d1, int d2, bool source) const
-    {
-        return (source ? sel(so, c) : sel(eo, c)) + (sel(base, c) + d0 * sel(s0, c) + d1 * sel(s1, c) + d2 * sel(s2, c));
-    }
-};
-template <class T, int DIR>
-__device__ __forceinline__ T lanes_rhs_entry(const emg::Axes<T, DIR> &A, const LanesIndex<T, DIR> &X, int k, int r, const double (&c6)[6])
-{
-    const int n0 = A.n0();
-    const int up = (k + 1 < n0 - 1 ? k + 1 : n0 - 1) - k;      // "i0" - k: 1, or 0 in the last row
-    const emg::RhsTerm so = emg::line_rhs_source(r);
-    const unsigned long long terms = emg::line_rhs_terms(r);
-    const T *const e0 = A.E(0);
-    T ev[6];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        const emg::RhsTerm tm = emg::rhs_unpack(terms, m);
-        ev[m] = e0[X.at(tm.comp, tm.d0 * up, tm.d1, tm.d2, false)];
-    }
-    T acc = A.S(0)[X.at(so.comp, so.d0 * up, so.d1, so.d2, true)];
-    if (r > 0 && k == n0 - 1) acc = emg::zero<T>();
-#pragma unroll
-    for (int m = 0; m < 6; ++m) acc = emg::mad(c6[m], ev[m], acc);
-    return acc;
-}
-
-template <class T, int DIR, bool BATCH>
-__global__ __launch_bounds__(LL_THREADS) void k_line_lanes(emg::Level<T> L, int colour, int cntp, int cntq, int lpw,
-                                                          const T *fac, const double *lfac, const T *nfac, const double *rtab)
-{
-    extern __shared__ double2 ll_smem[];
-    const size_t boff = BATCH ? blockIdx.y * L.bstride : 0;
-    const emg::Axes<T, DIR> A(L, boff);
-    const int n0 = A.n0(), mk = emg::line_mid(n0);
-    const int nbt = mk, nbb = n0 - mk - 2, nblk = n0 - 2, bl = n0 - 1, rows = n0 + 1;
-    const int nlines = cntp * cntq, line0 = blockIdx.x * lpw, nl = min(lpw, nlines - line0);
-    T *const GY = reinterpret_cast<T *>(ll_smem);          // [lpw][rows][LL_ROW]: g, then y
-    T *const GH = GY + (size_t)lpw * rows * LL_ROW;        //                       g', then h
-    T *const RV = GH + (size_t)lpw * rows * LL_ROW;        // [lpw][rows][LL_ROW]: r -> c -> z of a block (slot 5: w_0); middle: rows mk, mk + 1
-    const int t = threadIdx.x;
-    const int lpl = LL_LANES * bl;
-    const int ll = emg::fused_div(t, lpl), rem = t - ll * lpl, j = rem >> 3, r = rem & 7;
-    const bool isq = j == nblk;
-    const bool has = ll < nl && r < (isq ? 6 : 5);
-    int i1 = 1, i2 = 1, k = mk, mir = 0;
-    T val = emg::zero<T>(), row[6];
-    double cq[4] = {0.0, 0.0, 0.0, 0.0};
-    T *const rv = RV + (size_t)ll * rows * LL_ROW;
-    T *const gy = GY + (size_t)ll * rows * LL_ROW;
-    T *const gh = GH + (size_t)ll * rows * LL_ROW;
-    // the chain groups: waves 0 / 1 the top halves of lines 0..3 / 4..7, waves 2 / 3 their bottom halves (as k_line_wide);
-    // their first N entries on their way before anything else
-    const int wave = t >> 6, lane = t & 63, half = wave >> 1;
-    const int cl = min((wave & 1) * 4 + (lane >> 4), nl - 1);
-    const bool chain_wave = (wave & 1) * 4 < nl;
-    const T *const nbase = nfac + (size_t)line0 * 16;
-    const size_t nrow = (size_t)nlines * 16;
-    T preF[4], preB[4];
-    if (chain_wave) {
-        wide_chain_preload<T, false>(nbase, nrow, cl * 16, half ? n0 - 1 : 0, half ? -1 : 1, half ? nbb : nbt, lane & 15, preF);
-        wide_chain_preload<T, true>(nbase, nrow, cl * 16, half ? mk + 2 : mk - 1, half ? 1 : -1, (half ? nbb : nbt) - 1, lane & 15, preB);
-    }
-    // ---- (A) right-hand sides entry by entry; the rows of T; g ----
-    if (has) {
-        const int lid = line0 + ll;
-        int l2;
-        const int tq_ = emg::fused_div(lid, cntp);
-        emg::line_of_thread<DIR>(colour, cntp, cntq, lid - tq_ * cntp, tq_, i1, i2, l2);
-        if (!isq) {
-            const emg::WideBlock wb = emg::wide_block(j, mk);
-            k = wb.k; mir = wb.mir;
-            const int kr = r == 0 ? k : k - mir;
-            const size_t rec = (size_t)k * nlines + lid, recr = (size_t)kr * nlines + lid;
-            double c6[6];
-#pragma unroll
-            for (int m = 0; m < 6; ++m) c6[m] = rtab[recr * RTAB_DOUBLES + r * 6 + m];
-#pragma unroll
-            for (int b = 0; b < 5; ++b) row[b] = fac[rec * 15 + emg::sym(r, b)];
-            row[5] = emg::zero<T>();
-            if (r == 0) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) cq[b] = lfac[rec * 8 + b];
-            } else {
-                cq[0] = lfac[rec * 8 + r - 1];
-                cq[1] = lfac[rec * 8 + 4 + r - 1];
-            }
-            val = lanes_rhs_entry<T, DIR>(A, LanesIndex<T, DIR>(A, kr, i1, i2), kr, r, c6);
-            rv[k * LL_ROW + r] = val;
-        } else {
-            const size_t rm0 = (size_t)mk * nlines + lid, rm1 = rm0 + nlines;
-            const int kr = r == 5 ? mk + 1 : mk, re = r == 5 ? 0 : r;
-            double c6[6];
-#pragma unroll
-            for (int m = 0; m < 6; ++m) c6[m] = rtab[(r == 5 ? rm1 : rm0) * RTAB_DOUBLES + re * 6 + m];
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const int q = emg::sym(r, b);
-                row[b] = q < 15 ? fac[rm0 * 15 + q] : fac[rm1 * 15 + q - 15];
-            }
-            if (r == 0 || r == 5) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) cq[b] = lfac[(r == 0 ? rm0 : rm1) * 8 + b];
-            } else {
-                cq[0] = lfac[rm0 * 8 + r - 1]; cq[1] = lfac[rm0 * 8 + 4 + r - 1];
-                cq[2] = lfac[rm1 * 8 + r - 1]; cq[3] = lfac[rm1 * 8 + 4 + r - 1];
-            }
-            val = lanes_rhs_entry<T, DIR>(A, LanesIndex<T, DIR>(A, kr, i1, i2), kr, re, c6);
-        }
-    }
-    wave_sync();
-    if (has && !isq) {
-        if (r >= 1) gy[k * LL_ROW + r - 1] = lanes_row5<T>(row, rv + k * LL_ROW);
-        else { gy[k * LL_ROW + 4] = emg::zero<T>(); gh[k * LL_ROW + 4] = emg::zero<T>(); }
-    }
-    __syncthreads();
-    // ---- (F) forward chains ----
-    {
-        const int nst = half ? nbb : nbt;
-        if (chain_wave && nst > 0)
-            wide_chain<T, false, true>(GY + (size_t)cl * rows * LL_ROW, nbase, nrow, cl * 16, half ? n0 - 1 : 0,
-                                       half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>(), 1, preF);
-    }
-    __syncthreads();
-    // ---- (C) c = r - C w_kn, w_0, g' = C^T w entry by entry; the middle blocks ----
-    const int kn = mir ? k + 1 : k - 1;
-    const bool first = mir ? k == n0 - 1 : k == 0;
-    if (has) {
-        if (!isq) {
-            const T *const yp = gy + (first ? k : kn) * LL_ROW;
-            if (r == 0) {
-                T q0 = cq[0] * yp[0];
-#pragma unroll
-                for (int b = 1; b < 4; ++b) q0 = emg::mad(cq[b], yp[b], q0);
-                val = val - q0;
-            } else {
-                val = emg::nmad(cq[1], yp[r - 1], val);
-            }
-            rv[k * LL_ROW + r] = val;
-        } else {
-            const T *const yt = gy + max(mk - 1, 0) * LL_ROW;
-            const T *const yb = gy + min(mk + 2, n0 - 1) * LL_ROW;
-            if (r == 0 || r == 5) {
-                const T *const y = r == 0 ? yt : yb;
-                const bool any = r == 0 ? nbt > 0 : nbb > 0;
-                const T y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
-                T q = cq[0] * (any ? y0 : emg::zero<T>());
-                q = emg::mad(cq[1], any ? y1 : emg::zero<T>(), q);
-                q = emg::mad(cq[2], any ? y2 : emg::zero<T>(), q);
-                q = emg::mad(cq[3], any ? y3 : emg::zero<T>(), q);
-                val = val - q;
-            } else {
-                const T vt = yt[r - 1], vb = yb[r - 1];
-                const T yT = nbt > 0 ? vt : emg::zero<T>(), yB = nbb > 0 ? vb : emg::zero<T>();
-                val = emg::nmad(cq[3], yB, emg::nmad(cq[1], yT, val));
-            }
-            rv[mk * LL_ROW + r] = val;
-        }
-    }
-    wave_sync();
-    T xq = emg::zero<T>();
-    if (has) {
-        if (!isq) {
-            if (r == 0) rv[k * LL_ROW + 5] = lanes_row5<T>(row, rv + k * LL_ROW);
-        } else {
-            xq = lanes_row6<T>(row, rv + mk * LL_ROW);
-            rv[(mk + 1) * LL_ROW + r] = xq;
-        }
-    }
-    wave_sync();
-    if (has) {
-        if (!isq) {
-            if (r >= 1) {
-                const T w0 = rv[k * LL_ROW + 5], y = gy[k * LL_ROW + r - 1];
-                gh[(first ? n0 : kn) * LL_ROW + r - 1] = emg::mad(cq[0], w0, cq[1] * y);
-            }
-        } else {
-            if (r >= 1 && r <= 4) {
-                const T x0 = rv[(mk + 1) * LL_ROW + 0], x5 = rv[(mk + 1) * LL_ROW + 5];
-                gh[(nbt > 0 ? mk - 1 : n0) * LL_ROW + r - 1] = emg::mad(cq[0], x0, cq[1] * xq);
-                gh[(nbb > 0 ? mk + 2 : n0) * LL_ROW + r - 1] = emg::mad(cq[2], x5, cq[3] * xq);
-            }
-            // the middle block's solution: entries 0..4 of block mk, and E0(mk + 1)
-            if (r == 5) A.E(0)[A.idx(0, mk + 1, i1, i2)] = xq;
-            else {
-                const LanesIndex<T, DIR> X(A, mk, i1, i2);
-                A.E(0)[X.at((r + 1) >> 1, r == 0 ? 0 : 1, -(r == 1), -(r == 3), false)] = xq;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- (B) backward chains ----
-    {
-        const int nst = (half ? nbb : nbt) - 1;
-        if (chain_wave && nst > 0) {
-            const int kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
-            T *const rw = GH + (size_t)cl * rows * LL_ROW;
-            const T v0 = rw[kb0 * LL_ROW + (lane & 3)];
-            wide_chain<T, true, true>(rw, nbase, nrow, cl * 16, kb0 + dk, kb0, dk, nst, lane & 15, v0, 1, preB);
-        }
-    }
-    __syncthreads();
-    // ---- (E) x = T (c - h) row by row, scatter ----
-    if (has && !isq) {
-        if (r >= 1) val = val - gh[k * LL_ROW + r - 1];
-        rv[k * LL_ROW + r] = val;
-    }
-    wave_sync();
-    if (has && !isq) {
-        const T x = lanes_row5<T>(row, rv + k * LL_ROW);
-        const LanesIndex<T, DIR> X(A, k, i1, i2);
-        A.E(0)[X.at((r + 1) >> 1, r == 0 ? 0 : 1 - mir, -(r == 1), -(r == 3), false)] = x;
-    }
-}
-
-// ---- ALL colour passes of a smoothing call in one launch, on the slab / rod levels: k_line_fused ------------
-// (launch.h, "several colour passes of one line direction in ONE launch".) A level like 256 x 4 x 4 has ~190 lines of
-// four blocks per colour class: a pass is a launch of 6 us -- kernel boundary, first touch of memory, a chain of two
-// steps --, and a W-cycle on a 256^3 problem launches 1 800 of them per level. Here a workgroup owns `w` node planes
-// across the long axis, copies them and a halo into a private level IN LDS (field, source, zeta, widths), runs every
-// pass of the call there with workgroup barriers only -- the halo lines are solved redundantly instead of being
-// exchanged --, leaves its owned planes in the global scratch, and k_line_fused_back writes them back (a second
-// launch: a workgroup may only overwrite the level when every other workgroup has read its halo from it).
-// A pass is k_line_wide's five phases on the lines the patch needs in that pass (fused_lines), a thread per block
-// (middle blocks: from the next wave on, so that no wave runs both roles) and sixteen lanes per half-line chain. The
-// only global accesses of a pass are the factor records of its blocks, fetched at its start by LDS-direct loads
-// (no register holds them: entry q of the record of thread t lands at plane q, slot t) -- T, C and N records are
-// read from LDS where they are used, and only the right-hand sides r / c stay in registers between the phases.
-constexpr int LF_THREADS = 512;
-// phase stamps of workgroup 1 (thread 0), only in the -DEMG_FUSED_STAMPS build of tools/fused_stamps.py
-#ifdef EMG_FUSED_STAMPS
-__device__ unsigned long long g_fused_stamps[128];
-#define FSTAMP(i)                                                                                            \
-    do {                                                                                                     \
-        if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0 && (i) < 128) g_fused_stamps[(i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define FSTAMP(i)
-#endif
-// LDS of a launch, in elements of the field type: rows (g / y and g' / h of `chunk` lines), the staged records of a
-// round (blocks: 15 T + FC_PLANES C + 16 N planes of chunk * nblk slots; middle blocks: 21 T_Q + 2 FC_PLANES planes of
-// chunk slots), the private level
-template <class T> struct FusedLds {
-    static constexpr int FC = sizeof(T) == 16 ? 4 : 8;      // planes of a coupling record (8 doubles)
-    static constexpr int BLK = 15 + FC + 16, MID = 21 + 2 * FC;
-    static __host__ __device__ size_t rows(int chunk, int n0) { return (size_t)2 * chunk * (n0 + 1) * LW_ROW; }
-    static __host__ __device__ size_t staged(int chunk, int n0) { return (size_t)BLK * chunk * (n0 - 2) + (size_t)MID * chunk; }
-};
-// lines per round of a pass: the block threads fill whole waves, the middle-block threads follow
-inline int fused_chunk_threads(int n0)
-{
-    int c = LF_THREADS / (n0 - 1);
-    while (c > 1 && ((c * (n0 - 2) + 63) & ~63) + c > LF_THREADS) --c;
-    return std::max(1, c);
-}
-
-// entry q of the record at `src` into plane q (`stride` slots apart) of the staging area, slot of this thread:
-// complex: LDS-direct loads (a wave's lanes land side by side behind the wave-uniform base `wbase` = plane 0, slot
-// of the wave's first lane); real: through a register
-template <class T, int N> __device__ __forceinline__ void fused_stage(const T *src, T *wbase, int stride, int lane)
-{
-    if constexpr (sizeof(T) == 16) {
-        typedef const __attribute__((address_space(1))) void *gptr_t;
-        typedef __attribute__((address_space(3))) void *lptr_t;
-#pragma unroll
-        for (int q = 0; q < N; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + q), (lptr_t)(wbase + (size_t)q * stride), 16, 0, 0);
-    } else {
-        T v[N];
-#pragma unroll
-        for (int q = 0; q < N; ++q) v[q] = src[q];
-#pragma unroll
-        for (int q = 0; q < N; ++q) wbase[(size_t)q * stride + lane] = v[q];
-    }
-}
-// the eight doubles of a staged coupling record (planes of 16 bytes for complex fields, of 8 for real ones)
-template <class T> __device__ __forceinline__ void fused_get_c(const T *plane0, int stride, int slot, double (&lf)[8])
-{
-    if constexpr (sizeof(T) == 16) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const double2 v = *reinterpret_cast<const double2 *>(plane0 + (size_t)p * stride + slot);
-            lf[2 * p] = v.x; lf[2 * p + 1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) lf[p] = plane0[(size_t)p * stride + slot];
-    }
-}
-
-template <class T, int DIR, bool BATCH>
-__global__ __launch_bounds__(LF_THREADS) void k_line_fused(emg::Level<T> L, emg::FusedPlan P, int chunk, const T *fac,
-                                                          const double *lfac, const T *nfac, T *priv, size_t priv_stride)
-{
-    extern __shared__ double2 lf_smem[];
-    using LD = FusedLds<T>;
-    constexpr int FC = LD::FC;
-    // (the patch in LDS: its plane ranges are indexed by the pass at run time)
-    __shared__ emg::FusedPatch sF;
-    const int t = threadIdx.x;
-    const size_t boff = BATCH ? blockIdx.y * L.bstride : 0;
-    FSTAMP(0);
-    if (t == 0) emg::fused_patch(P, blockIdx.x, sF);
-    __syncthreads();
-    FSTAMP(1);
-    const emg::FusedPatch &F = sF;
-    const int n0 = P.n0, mk = emg::line_mid(n0);
-    const int nbt = mk, nbb = n0 - mk - 2, nblk = n0 - 2, rows = n0 + 1;
-    T *const GY = reinterpret_cast<T *>(lf_smem);          // [chunk][rows][LW_ROW]: g, then y
-    T *const GH = GY + (size_t)chunk * rows * LW_ROW;      //                        g', then h
-    T *const ST = GH + (size_t)chunk * rows * LW_ROW;      // the staged records of the round
-    T *const gpriv = priv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * priv_stride;
-    const emg::Level<T> Q = emg::fused_private_level(L, P, F, ST + LD::staged(chunk, n0));
-    emg::fused_copy_in(L, Q, P, F, boff, t, LF_THREADS);
-    __syncthreads();
-    FSTAMP(2);
-    const emg::Axes<T, DIR> A(Q);
-    const int wave = t >> 6, lane = t & 63, half = wave >> 2, gq = (wave & 3) * 4 + (lane >> 4);
-    for (int pass = 1; pass <= P.npass; ++pass) {
-        const emg::FusedLines S = emg::fused_lines(P, F, pass);
-        const int c = S.colour, nlines = S.cp * emg::fused_sel(P.cntq, c);
-        const long long rec0 = emg::fused_sel(P.rec0, c);
-        const T *const f = fac + rec0 * 15;
-        const double *const lfc = lfac + rec0 * 8;
-        const T *const nf = nfac + rec0 * 16;
-        for (int l0 = 0; l0 < S.n; l0 += chunk) {
-            const int nl = min(chunk, S.n - l0);
-            // the block threads first, the middle-block threads from the next wave on (no wave runs both roles)
-            const int nbs = nl * nblk, tq0 = (nbs + 63) & ~63;
-            const bool isq = t >= tq0;
-            const bool has = isq ? t - tq0 < nl : t < nbs;
-            int ll = 0, j = 0;
-            if (isq) ll = t - tq0;
-            else if (DIR == 0) { ll = emg::fused_div(t, nblk); j = t - ll * nblk; }      // x-lines: the field is contiguous along the line
-            else { j = emg::fused_div(t, nl); ll = t - j * nl; }
-            // staging planes of the round: blocks [T 15 | C | N 16] x nbs slots, then middle blocks [T_Q 21 | B | U] x nl slots
-            T *const FT = ST, *const FCb = ST + (size_t)15 * nbs, *const FN = ST + (size_t)(15 + FC) * nbs;
-            T *const MT = ST + (size_t)LD::BLK * nbs, *const MB = MT + (size_t)21 * nl, *const MU = MB + (size_t)FC * nl;
-            int i1 = 1, i2 = 1, lid = 0, k = 0, mir = 0;
-            T r[6];
-            // ---- (A) the records on their way into LDS; right-hand sides; g ----
-            if (has) {
-                if (pass == 2) FSTAMP(64);
-                emg::fused_line<DIR>(P, F, S, l0 + ll, i1, i2, lid);
-                const int w0 = __builtin_amdgcn_readfirstlane(t & ~63);
-                if (pass == 2) FSTAMP(65);
-                if (!isq) {
-                    const emg::WideBlock wb = emg::wide_block(j, mk);
-                    k = wb.k; mir = wb.mir;
-                    const size_t rec = (size_t)k * nlines + lid;
-                    fused_stage<T, 15>(f + rec * 15, FT + w0, nbs, lane);
-                    fused_stage<T, FC>(reinterpret_cast<const T *>(lfc + rec * 8), FCb + w0, nbs, lane);
-                    fused_stage<T, 16>(nf + rec * 16, FN + w0, nbs, lane);
-                    if (pass == 2) FSTAMP(66);
-                    T rb[5];
-                    emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
-                    if (pass == 2) FSTAMP(67);
-                    // (the records of this thread have landed: the compiler does not count LDS-direct loads)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (pass == 2) FSTAMP(68);
-                    T Tk[15], g[4];
-#pragma unroll
-                    for (int q = 0; q < 15; ++q) Tk[q] = FT[(size_t)q * nbs + t];
-                    emg::wide_g<T, 15>(Tk, rb, g);
-                    if (pass == 2) FSTAMP(69);
-                    T *const row = GY + ((size_t)ll * rows + k) * LW_ROW;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) row[q] = g[q];
-                    row[4] = emg::zero<T>();
-                    GH[((size_t)ll * rows + k) * LW_ROW + 4] = emg::zero<T>();
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) r[q] = rb[q];
-                } else {
-                    const size_t rm0 = (size_t)mk * nlines + lid, rm1 = rm0 + nlines;
-                    const int wq = w0 - tq0;
-                    fused_stage<T, 15>(f + rm0 * 15, MT + wq, nl, lane);
-                    fused_stage<T, 6>(f + rm1 * 15, MT + (size_t)15 * nl + wq, nl, lane);
-                    fused_stage<T, FC>(reinterpret_cast<const T *>(lfc + rm0 * 8), MB + wq, nl, lane);
-                    fused_stage<T, FC>(reinterpret_cast<const T *>(lfc + rm1 * 8), MU + wq, nl, lane);
-                    T rm[5];
-                    emg::line_rhs<T, DIR>(A, mk, i1, i2, rm);
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) r[q] = rm[q];
-                    r[5] = emg::line_rhs_e0<T, DIR>(A, mk + 1, i1, i2);
-                }
-            }
-            // (every record of the round has landed before any thread reads one: LDS-direct loads are not part of
-            //  what __syncthreads waits for)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (pass == 2) FSTAMP(70);
-            __syncthreads();
-            FSTAMP(3 + (pass - 1) * 5 + 0);
-            // ---- (F) forward chains: waves 0..3 the top halves, waves 4..7 the bottom halves, sixteen lines a round;
-            //      the N record of line cl, block record k belongs to thread cl nblk + j (x-lines) / j nl + cl, j = k or k - 2 ----
-            const int ks = DIR == 0 ? 1 : nl;
-            {
-                const int nst = half ? nbb : nbt;
-                if (nst > 0)
-                    for (int base = 0; base + (wave & 3) * 4 < nl; base += 16) {
-                        const int cl = min(base + gq, nl - 1);
-                        wide_chain<T, false>(GY + (size_t)cl * rows * LW_ROW, FN, (size_t)ks, (DIR == 0 ? cl * nblk : cl) - (half ? 2 * ks : 0),
-                                             half ? n0 - 1 : 0, half ? n0 - 1 : 0, half ? -1 : 1, nst, lane & 15, emg::zero<T>(), nbs);
-                    }
-            }
-            __syncthreads();
-            FSTAMP(3 + (pass - 1) * 5 + 1);
-            // ---- (C) per block: c = r - C w_kn, w_0, g' = C^T w; the middle blocks ----
-            if (has) {
-                if (!isq) {
-                    const int kn = mir ? k + 1 : k - 1;
-                    const bool first = mir ? k == n0 - 1 : k == 0;
-                    const T *const yr = GY + ((size_t)ll * rows + (first ? k : kn)) * LW_ROW;
-                    const T *const yo = GY + ((size_t)ll * rows + k) * LW_ROW;
-                    T yp[4], y[4], cc[5], rb[5], gp[4], T0[15];
-                    double lf[8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { yp[q] = yr[q]; y[q] = yo[q]; }
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) rb[q] = r[q];
-                    fused_get_c<T>(FCb, nbs, t, lf);
-                    // row 0 of T: packed entries sym(0, m) = m (m + 1) / 2
-#pragma unroll
-                    for (int m = 0; m < 5; ++m) T0[emg::sym(0, m)] = FT[(size_t)emg::sym(0, m) * nbs + t];
-                    emg::wide_c<T>(lf, rb, yp, cc);
-                    const T w0 = emg::wide_row5<T, 15>(T0, 0, cc);
-                    emg::wide_gp<T>(lf, w0, y, gp);
-                    T *const o = GH + ((size_t)ll * rows + (first ? n0 : kn)) * LW_ROW;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = gp[q];
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) r[q] = cc[q];
-                } else {
-                    const T *const yt = GY + ((size_t)ll * rows + max(mk - 1, 0)) * LW_ROW;
-                    const T *const yb = GY + ((size_t)ll * rows + min(mk + 2, n0 - 1)) * LW_ROW;
-                    T yT[4], yB[4], xq[6], hT[4], hB[4], Tq[21];
-                    double lf[8], lf2[8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const T vt = yt[q], vb = yb[q];
-                        yT[q] = nbt > 0 ? vt : emg::zero<T>();
-                        yB[q] = nbb > 0 ? vb : emg::zero<T>();
-                    }
-#pragma unroll
-                    for (int q = 0; q < 21; ++q) Tq[q] = MT[(size_t)q * nl + ll];
-                    fused_get_c<T>(MB, nl, ll, lf);
-                    fused_get_c<T>(MU, nl, ll, lf2);
-                    emg::wide_middle<T>(Tq, lf, lf2, r, yT, yB, xq, hT, hB);
-                    T *const ot = GH + ((size_t)ll * rows + (nbt > 0 ? mk - 1 : n0)) * LW_ROW;
-                    T *const ob = GH + ((size_t)ll * rows + (nbb > 0 ? mk + 2 : n0)) * LW_ROW;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ot[q] = hT[q];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ob[q] = hB[q];
-                    const T xs[5] = {xq[0], xq[1], xq[2], xq[3], xq[4]};
-                    emg::wide_block_scatter<T, DIR>(A, mk, 0, i1, i2, xs);
-                    A.E(0)[A.idx(0, mk + 1, i1, i2)] = xq[5];
-                }
-            }
-            __syncthreads();
-            FSTAMP(3 + (pass - 1) * 5 + 2);
-            // ---- (B) backward chains: outwards from the block next to the middle ----
-            {
-                const int nst = (half ? nbb : nbt) - 1;
-                if (nst > 0) {
-                    const int kb0 = half ? mk + 2 : mk - 1, dk = half ? 1 : -1;
-                    for (int base = 0; base + (wave & 3) * 4 < nl; base += 16) {
-                        const int cl = min(base + gq, nl - 1);
-                        T *const rw = GH + (size_t)cl * rows * LW_ROW;
-                        const T v0 = rw[kb0 * LW_ROW + (lane & 3)];
-                        wide_chain<T, true>(rw, FN, (size_t)ks, (DIR == 0 ? cl * nblk : cl) - (half ? 2 * ks : 0), kb0 + dk, kb0, dk, nst,
-                                            lane & 15, v0, nbs);
-                    }
-                }
-            }
-            __syncthreads();
-            FSTAMP(3 + (pass - 1) * 5 + 3);
-            // ---- (E) per block: x = T (c - h), scatter into the private field ----
-            if (has && !isq) {
-                const T *const hr = GH + ((size_t)ll * rows + k) * LW_ROW;
-                T h[4], cc[5], x[5], Tk[15];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) h[q] = hr[q];
-#pragma unroll
-                for (int q = 0; q < 5; ++q) cc[q] = r[q];
-#pragma unroll
-                for (int q = 0; q < 15; ++q) Tk[q] = FT[(size_t)q * nbs + t];
-                emg::wide_x<T, 15>(Tk, cc, h, x);
-                emg::wide_block_scatter<T, DIR>(A, k, mir, i1, i2, x);
-            }
-            __syncthreads();           // (the rows and staged records are reused; the next pass reads what this one scattered)
-            FSTAMP(3 + (pass - 1) * 5 + 4);
-        }
-    }
-    // the owned planes into the scratch copy of the private level, where k_line_fused_back finds them
-    emg::fused_copy_owned(Q, emg::fused_private_level(L, P, F, gpriv), P, F, t, LF_THREADS);
-    FSTAMP(3 + P.npass * 5);
-}
-
-// the owned planes of every patch back into the level (after ALL workgroups of k_line_fused have read their halos)
-template <class T, bool BATCH>
-__global__ __launch_bounds__(256) void k_line_fused_back(emg::Level<T> L, emg::FusedPlan P, T *priv, size_t priv_stride)
-{
-    __shared__ emg::FusedPatch sF;
-    const size_t boff = BATCH ? blockIdx.y * L.bstride : 0;
-    if (threadIdx.x == 0) emg::fused_patch(P, blockIdx.x, sF);
-    __syncthreads();
-    const emg::Level<T> Q = emg::fused_private_level(L, P, sF, priv + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * priv_stride);
-    emg::fused_copy_out(L, Q, P, sF, boff, threadIdx.x, 256);
 }
 
 // ---- fused colour pass with STREAMED records (the largest levels): k_line_stream -----------------
@@ -2569,63 +1909,6 @@ inline bool line_wide_used(int dir, int nx, int ny, int nz)
     return g_line_wide > 0 && emg::line_n0(dir, nx, ny, nz) <= g_line_wide && emg::line_nfac_elems(dir, nx, ny, nz) > 0;
 }
 
-// does the direction run k_line_lanes on this level? (option line_lanes = longest line; the level must hold the tables)
-inline bool line_lanes_used(int dir, int nx, int ny, int nz)
-{
-    return g_line_lanes > 0 && emg::line_n0(dir, nx, ny, nz) <= std::min(g_line_lanes, 33) && emg::line_n0(dir, nx, ny, nz) >= 3 &&
-           emg::line_rtab_doubles(dir, nx, ny, nz) > 0;
-}
-// does the direction run the fused passes on this level? (option line_fused = longest line)
-inline bool line_fused_used(int dir, int nx, int ny, int nz)
-{
-    return g_line_fused > 0 && emg::fused_capable(dir, nx, ny, nz, std::min(g_line_fused, FUSED_N0_CAP));
-}
-// scratch elements (per right-hand side) the fused passes may need on a level, whatever the options say
-inline size_t fused_scratch_elems(int dir, int nx, int ny, int nz)
-{
-    if (!emg::fused_capable(dir, nx, ny, nz, FUSED_N0_CAP)) return 0;
-    const emg::FusedPlan P = emg::fused_plan(dir, nx, ny, nz, emg::FUSED_MAXPASS / 4, 2, false, FUSED_W_MIN);
-    return (size_t)P.nwg * emg::fused_private_elems(P.dl, P.nmax, nx, ny, nz);
-}
-
-// LDS plan of a fused launch: lines per round (0: the private level does not fit beside the rows and staged records of
-// a round of at least `min(8, most lines of a pass)` lines -- the call is then launched pass by pass)
-template <class T> int fused_chunk(const emg::FusedPlan &P, int nx, int ny, int nz, size_t &smem)
-{
-    const size_t stride = emg::fused_private_elems(P.dl, P.nmax, nx, ny, nz);
-    // no more lines than a pass can have (planes of one parity x lines of the class per plane)
-    const int other = P.dl_is_p ? std::max(P.cntq[1], P.cntq[2]) : std::max(P.cntp[1], P.cntp[2]);
-    const int most = std::max(1, (P.nmax / 2 + 1) * std::max(other, 1));
-    int chunk = std::min(fused_chunk_threads(P.n0), most);
-    const size_t lds_cu = 160 * 1024 - 1024;
-    auto bytes = [&](int ch) { return (FusedLds<T>::rows(ch, P.n0) + FusedLds<T>::staged(ch, P.n0) + stride) * sizeof(T); };
-    const int least = std::min(8, most);
-    while (chunk > least && bytes(chunk) > lds_cu) --chunk;
-    smem = bytes(chunk);
-    return smem <= lds_cu ? chunk : 0;
-}
-
-template <class T, int DIR>
-bool launch_line_fused(const emg::Level<T> &L, const emg::FusedPlan &P, const T *fac, const double *lfac, T *priv, hipStream_t st)
-{
-    size_t smem = 0;
-    const int chunk = fused_chunk<T>(P, L.nx, L.ny, L.nz, smem);
-    if (chunk <= 0) return false;
-    const size_t stride = emg::fused_private_elems(P.dl, P.nmax, L.nx, L.ny, L.nz);
-    const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz);
-    const dim3 grid(P.nwg, L.batch);
-#define LF_LAUNCH(B)                                                                                                      \
-    do {                                                                                                                  \
-        (void)allow_lds(reinterpret_cast<const void *>(&k_line_fused<T, DIR, B>), smem);                                   \
-        hipLaunchKernelGGL((k_line_fused<T, DIR, B>), grid, dim3(LF_THREADS), smem, st, L, P, chunk, fac, lfac, nf, priv, stride); \
-        hipLaunchKernelGGL((k_line_fused_back<T, B>), grid, dim3(256), 0, st, L, P, priv, stride);                          \
-    } while (0)
-    if (L.batch > 1) LF_LAUNCH(true);
-    else LF_LAUNCH(false);
-#undef LF_LAUNCH
-    return true;
-}
-
 template <class T, int DIR, int B>
 void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const T *f, const double *lf, T *vec,
                          size_t vstride, int b0, int lpw, hipStream_t st)
@@ -2665,33 +1948,15 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
     const size_t vstride = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz);    // scratch of one right-hand side
     const size_t dummy_off = vstride - emg::LINE_DUMMY;
-    if (line_lanes_used(DIR, L.nx, L.ny, L.nz)) {
-        const int lpw = lanes_lpw(lc.n0);
-        const size_t smem = (size_t)3 * lpw * (lc.n0 + 1) * LL_ROW * sizeof(T);
-        const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + lc.fac_off / 15 * 16;
-        const double *rt = reinterpret_cast<const double *>(fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) +
-                                                            emg::line_nfac_elems(DIR, L.nx, L.ny, L.nz)) + lc.fac_off / 15 * RTAB_DOUBLES;
-        const dim3 grid(cdiv(lc.lines, lpw), L.batch);
-        if (L.batch > 1)
-            hipLaunchKernelGGL((k_line_lanes<T, DIR, true>), grid, dim3(LL_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf, rt);
-        else
-            hipLaunchKernelGGL((k_line_lanes<T, DIR, false>), grid, dim3(LL_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf, rt);
-        return;
-    }
     if (line_wide_used(DIR, L.nx, L.ny, L.nz)) {
         const int lpw = wide_lpw(lc.n0);
-        const bool nlds = g_line_wide_n != 0;
-        const size_t smem = ((size_t)2 * lpw * (lc.n0 + 1) * LW_ROW + (nlds ? (size_t)lpw * lc.n0 * 16 : 0)) * sizeof(T);
+        const size_t smem = (size_t)2 * lpw * (lc.n0 + 1) * LW_ROW * sizeof(T);
         const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + lc.fac_off / 15 * 16;
         const dim3 grid(cdiv(lc.lines, lpw), L.batch);
-#define LW_LAUNCH(B, N)                                                                                        \
-    do {                                                                                                       \
-        (void)allow_lds(reinterpret_cast<const void *>(&k_line_wide<T, DIR, B, N>), smem);                      \
-        hipLaunchKernelGGL((k_line_wide<T, DIR, B, N>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf); \
-    } while (0)
-        if (L.batch > 1) { if (nlds) LW_LAUNCH(true, true); else LW_LAUNCH(true, false); }
-        else { if (nlds) LW_LAUNCH(false, true); else LW_LAUNCH(false, false); }
-#undef LW_LAUNCH
+        if (L.batch > 1)
+            hipLaunchKernelGGL((k_line_wide<T, DIR, true>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
+        else
+            hipLaunchKernelGGL((k_line_wide<T, DIR, false>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
         return;
     }
     const LinePlan P = line_plan<T>(lc, L.batch);
@@ -2781,19 +2046,6 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
     // for the tiled one
     const T *pst = (lr == 0 && !tiled) ? (const T *)fac : nullptr;
     const hipStream_t st_ = st;
-    if (lr != 0 && line_fused_used(lr - 1, nx, ny, nz)) {
-        const int w = std::max(FUSED_W_MIN, std::min(FUSED_W_MAX, g_line_fused_w));
-        const emg::FusedPlan P = emg::fused_plan(lr - 1, nx, ny, nz, nu, g_line_order, g_skip_repeat != 0, w);
-        if (P.npass <= emg::FUSED_MAXPASS) {
-            const bool done = lr == 1   ? launch_line_fused<T, 0>(L, P, (const T *)fac, lfac, (T *)scratch, st)
-                              : lr == 2 ? launch_line_fused<T, 1>(L, P, (const T *)fac, lfac, (T *)scratch, st)
-                                        : launch_line_fused<T, 2>(L, P, (const T *)fac, lfac, (T *)scratch, st);
-            if (done) {
-                HIP_TRY(hipGetLastError());
-                return 0;
-            }
-        }
-    }
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;   // first sweep backward (reference emg3d/core.py:301,311)
@@ -2908,13 +2160,6 @@ void launch_line_setup_dir(const emg::Level<T> &L, T *fac, double *lfac, hipStre
     if (gx > 0 && gy > 0 && emg::line_nfac_elems(DIR, L.nx, L.ny, L.nz) > 0)
         hipLaunchKernelGGL(k_line_wide_setup<T>, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, (const T *)fac,
                            (const double *)lfac, fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz), nrec);
-    // the right-hand-side coefficient tables of k_line_lanes, behind the N records
-    if (gx > 0 && gy > 0 && emg::line_rtab_doubles(DIR, L.nx, L.ny, L.nz) > 0) {
-        int most = 0;
-        for (int c = 0; c < 4; ++c) most = std::max(most, S.cntp[c] * S.cntq[c]);
-        double *const rt = reinterpret_cast<double *>(fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + emg::line_nfac_elems(DIR, L.nx, L.ny, L.nz));
-        hipLaunchKernelGGL((k_line_lanes_setup<T, DIR>), dim3(cdiv(most, 128), emg::line_n0(DIR, L.nx, L.ny, L.nz), 4), dim3(128), 0, st, L, S, rt);
-    }
 }
 
 template <class T>
@@ -3080,9 +2325,7 @@ static const OptionEntry g_options[] = {
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
-    {"line_wide", &g_line_wide},         {"line_lanes", &g_line_lanes},
-            {"line_wide_n", &g_line_wide_n},
-            {"line_fused", &g_line_fused},         {"line_fused_w", &g_line_fused_w},
+    {"line_wide", &g_line_wide},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value
@@ -3105,11 +2348,6 @@ int emg3d_set_option(const char *name, int value)
         return fail(EMG3D_ERR_BADARG, "line_stream_r: 0 (= 16) or a multiple of 4 in 4..32");
     if (!std::strcmp(name, "line_order") && (value < 0 || value > 2)) return fail(EMG3D_ERR_BADARG, "line_order: 0, 1 or 2");
     if (!std::strcmp(name, "point_order") && (value < 0 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_order: 0 or 1");
-    if (!std::strcmp(name, "line_lanes") && (value < 0 || value > 33)) return fail(EMG3D_ERR_BADARG, "line_lanes: 0 (never) or the longest line in blocks, at most 33");
-    if (!std::strcmp(name, "line_fused") && (value < 0 || value > FUSED_N0_CAP))
-        return fail(EMG3D_ERR_BADARG, "line_fused: 0 (never) or the longest fused line in blocks, at most 17");
-    if (!std::strcmp(name, "line_fused_w") && (value < FUSED_W_MIN || value > FUSED_W_MAX))
-        return fail(EMG3D_ERR_BADARG, "line_fused_w: 4 .. 64 node planes per workgroup");
     for (const OptionEntry &o : g_options)
         if (!std::strcmp(name, o.name)) {
             if (*o.value != value) ++g_options_generation;
@@ -3120,13 +2358,6 @@ int emg3d_set_option(const char *name, int value)
 }
 
 int emg3d_options_generation(void) { return g_options_generation; }
-
-#ifdef EMG_FUSED_STAMPS
-int emg3d_debug_fused_stamps(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 128);
-}
-#endif
 
 #ifdef EMG_WIDE_STAMPS
 int emg3d_debug_wide_stamps(unsigned long long *out)
@@ -3141,13 +2372,6 @@ const char *emg3d_line_kernel_name(int lr, int nx, int ny, int nz, int is_comple
     // the largest colour class (odd, odd) decides, as it does for the scratch size
     const emg::LineClass lc = emg::line_class(lr - 1, nx, ny, nz, 3);
     if (lc.lines <= 0) return "";
-    if (line_fused_used(lr - 1, nx, ny, nz)) {      // (decided for a call of two sweeps, the cycles' smoothing calls)
-        const emg::FusedPlan P = emg::fused_plan(lr - 1, nx, ny, nz, 2, g_line_order, g_skip_repeat != 0,
-                                                 std::max(FUSED_W_MIN, std::min(FUSED_W_MAX, g_line_fused_w)));
-        size_t smem = 0;
-        if ((is_complex ? fused_chunk<cplx>(P, nx, ny, nz, smem) : fused_chunk<double>(P, nx, ny, nz, smem)) > 0) return "k_line_fused";
-    }
-    if (line_lanes_used(lr - 1, nx, ny, nz)) return "k_line_lanes";
     if (line_wide_used(lr - 1, nx, ny, nz)) return "k_line_wide";
     const LinePlan P = is_complex ? line_plan<cplx>(lc, batch > 1 ? batch : 1) : line_plan<double>(lc, batch > 1 ? batch : 1);
     switch (P.kind) {
@@ -3175,15 +2399,13 @@ int emg3d_device_count(void)
 size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex)
 {
     if (lr < 1 || lr > 3) return 0;
-    // (the private levels of the fused passes, where the level can take them: a function of the shape alone)
-    return std::max(emg::line_vec_elems(lr - 1, nx, ny, nz), fused_scratch_elems(lr - 1, nx, ny, nz)) * (is_complex ? 16 : 8);
+    return emg::line_vec_elems(lr - 1, nx, ny, nz) * (is_complex ? 16 : 8);
 }
 
 size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex)
 {
     if (lr < 1 || lr > 3) return 0;
-    return (emg::line_fac_elems(lr - 1, nx, ny, nz) + emg::line_nfac_elems(lr - 1, nx, ny, nz)) * (is_complex ? 16 : 8) +
-           emg::line_rtab_doubles(lr - 1, nx, ny, nz) * 8;
+    return (emg::line_fac_elems(lr - 1, nx, ny, nz) + emg::line_nfac_elems(lr - 1, nx, ny, nz)) * (is_complex ? 16 : 8);
 }
 
 size_t emg3d_line_lfac_bytes(int lr, int nx, int ny, int nz)

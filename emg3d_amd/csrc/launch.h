@@ -596,12 +596,6 @@ inline size_t line_nfac_elems(int dir, int nx, int ny, int nz)
     const size_t rec = line_records(dir, nx, ny, nz);
     return line_wide_capable(line_n0(dir, nx, ny, nz), rec) ? 16 * rec : 0;
 }
-// doubles of the right-hand-side coefficient tables of k_line_lanes (32 per block record), behind the N records, on
-// the levels that hold those
-inline size_t line_rtab_doubles(int dir, int nx, int ny, int nz)
-{
-    return line_nfac_elems(dir, nx, ny, nz) > 0 ? 32 * line_records(dir, nx, ny, nz) : 0;
-}
 inline size_t line_lfac_elems(int dir, int nx, int ny, int nz)
 {
     return (size_t)8 * line_padded(line_n0(dir, nx, ny, nz)) * line_total(dir, nx, ny, nz);
@@ -673,249 +667,6 @@ EMG_HD void line_scatter_thread(const Level<T> &L, int colour, int cntp, int cnt
 // forward/backward kernels: FOUR lanes per line, 16 lines per wave
 inline Dim3 linequad_block() { return Dim3{64, 1, 1}; }
 inline Dim3 linequad_grid(const LineClass &c) { return Dim3{cdiv(c.lines * 4, 64), 1, 1}; }
-
-// ---- several colour passes of one line direction in ONE launch (kernels.hip: k_line_fused) ------------------
-// On the slab- and rod-shaped levels of a semicoarsened hierarchy (e.g. 256 x 4 x 4) a colour pass is a launch of
-// a few microseconds, most of it kernel boundary and first touch of memory, and a W-cycle has thousands of them.
-// Here the level is cut along its LONG axis `dl` into patches of `w` interior node planes. A workgroup copies its
-// patch plus a halo into a private level (the same Level struct with its own dimensions: every per-line function
-// of stencil.h works on it unchanged), runs ALL colour passes of the call on the private copy, and its owned
-// planes are copied back afterwards. No workgroup ever waits for another one: instead of exchanging the lines at
-// the patch faces after every pass, each workgroup also solves the neighbouring lines its own lines depend on --
-// a line at plane i reads only edges written by lines at planes i-1, i, i+1, and in one pass only planes of ONE
-// parity are solved, so the planes that must hold true values shrink by at most one plane per pass and side:
-//   need[npass] = the owned planes (+ the plane below them: its lines write the dl-edges between the two),
-//   need[t-1]   = need[t], extended by one plane on a side whose outermost plane is solved in pass t.
-// Pass t solves the lines of its class in need[t]; the private level is need[0] plus one plane of cells per side,
-// whose outer faces play the part of the level's boundary (never written). The arithmetic per line is that of the
-// wide form (stencil.h: line_wide_ref) with the level's own factor records: the same bits as the pass-by-pass
-// launches of k_line_wide.
-constexpr int FUSED_MAXPASS = 16;
-
-struct FusedPlan {
-    int dir;                  // line direction 0 / 1 / 2
-    int dl;                   // physical axis the level is cut along (!= dir)
-    int dl_is_p;              // that axis is the p index of the (p, q) class numbering above (else q)
-    int ndl;                  // cells along dl
-    int w, nwg;               // interior node planes owned by a workgroup; workgroups
-    int npass;
-    unsigned long long colours;   // class of pass t (1 .. npass): bits 2 (t - 1), 2 (t - 1) + 1
-    int cntp[4], cntq[4];     // lines along p / q of the four classes
-    long long rec0[4];        // block records of the classes before this one
-    // (a kernel argument indexed at run time is copied to scratch memory: the passes' classes are packed into one
-    //  word, and the class tables are read through fused_sel)
-    int n0, n0p;              // blocks per line (real, padded)
-    int nmax;                 // cells along dl of the largest private level
-};
-EMG_HD int fused_dlpar(const FusedPlan &P, int colour) { return P.dl_is_p ? (colour & 1) : ((colour >> 1) & 1); }
-EMG_HD int fused_colour(const FusedPlan &P, int t) { return (int)((P.colours >> (2 * (t - 1))) & 3); }
-template <class V> EMG_HD V fused_sel(const V (&a)[4], int c) { return c == 0 ? a[0] : c == 1 ? a[1] : c == 2 ? a[2] : a[3]; }
-// a / b for 0 <= a < 2^19, b > 0 without the integer-division sequence
-EMG_HD int fused_div(int a, int b) { return (int)(((float)a + 0.5f) / (float)b); }
-
-struct FusedPatch {
-    int a, b;                                           // owned interior node planes a .. b
-    int lo[FUSED_MAXPASS + 1], hi[FUSED_MAXPASS + 1];   // need[t]: planes lo[t] .. hi[t] are true after pass t
-    int c0, c1;                                         // the private level: cells c0 .. c1 - 1 along dl
-};
-EMG_HD void fused_patch(const FusedPlan &P, int wg, FusedPatch &F)
-{
-    F.a = 1 + wg * P.w;
-    F.b = F.a + P.w - 1 < P.ndl - 1 ? F.a + P.w - 1 : P.ndl - 1;
-    int lo = F.a > 1 ? F.a - 1 : 1, hi = F.b;
-    F.lo[P.npass] = lo; F.hi[P.npass] = hi;
-    for (int t = P.npass; t >= 1; --t) {
-        const int par = fused_dlpar(P, fused_colour(P, t));
-        if ((lo & 1) == par && lo > 1) --lo;
-        if ((hi & 1) == par && hi < P.ndl - 1) ++hi;
-        F.lo[t - 1] = lo; F.hi[t - 1] = hi;
-    }
-    F.c0 = lo - 1; F.c1 = hi + 1;
-}
-// the lines pass t (1 .. npass) solves in a patch: n lines, cdl of them along dl starting at class index t0
-struct FusedLines { int n, cdl, t0, colour, cp; };   // (cp: lines along p of the class)
-EMG_HD FusedLines fused_lines(const FusedPlan &P, const FusedPatch &F, int t)
-{
-    FusedLines S;
-    S.colour = fused_colour(P, t);
-    const int first = first_par(fused_dlpar(P, S.colour));
-    const int lo = F.lo[t], hi = F.hi[t];
-    S.t0 = lo <= first ? 0 : (lo - first + 1) >> 1;
-    const int t1 = hi < first ? -1 : (hi - first) >> 1;
-    S.cdl = t1 - S.t0 + 1 > 0 ? t1 - S.t0 + 1 : 0;
-    S.cp = fused_sel(P.cntp, S.colour);
-    S.n = S.cdl * (P.dl_is_p ? fused_sel(P.cntq, S.colour) : S.cp);
-    return S;
-}
-// line ll of the pass: class indices (tp, tq) -- the level's line id is tp + cntp tq --, and its transverse node
-// (i1, i2) in the abstract axes of the PRIVATE level
-template <int DIR>
-EMG_HD void fused_line(const FusedPlan &P, const FusedPatch &F, const FusedLines &S, int ll, int &i1, int &i2, int &lid)
-{
-    int tp, tq;
-    if (P.dl_is_p) { tq = fused_div(ll, S.cdl); tp = S.t0 + ll - tq * S.cdl; }
-    else { const int r = fused_div(ll, S.cp); tp = ll - r * S.cp; tq = S.t0 + r; }
-    lid = tp + S.cp * tq;
-    const int p = first_par(S.colour & 1) + 2 * tp - (P.dl_is_p ? F.c0 : 0);
-    const int q = first_par((S.colour >> 1) & 1) + 2 * tq - (P.dl_is_p ? 0 : F.c0);
-    i1 = DIR == 1 ? q : p;
-    i2 = DIR == 1 ? p : q;
-}
-// elements (of the field type) of the private level of a patch with n cells along dl: [e | s | zeta (doubles)]
-EMG_HD size_t fused_edges(int nx, int ny, int nz)
-{
-    return (size_t)nx * (ny + 1) * (nz + 1) + (size_t)(nx + 1) * ny * (nz + 1) + (size_t)(nx + 1) * (ny + 1) * nz;
-}
-EMG_HD size_t fused_private_elems(int dl, int n, int nx, int ny, int nz)
-{
-    const int px = dl == 0 ? n : nx, py = dl == 1 ? n : ny, pz = dl == 2 ? n : nz;
-    // (zeta and the three inverse-width arrays: doubles, rounded up to whole complex elements)
-    return 2 * fused_edges(px, py, pz) + ((size_t)px * py * pz + 1) / 2 * 2 + ((size_t)(px + py + pz) + 1) / 2 * 2;
-}
-// the private level of a patch in `buf` (fused_private_elems(..., nmax, ...) elements per workgroup)
-template <class T> EMG_HD Level<T> fused_private_level(const Level<T> &L, const FusedPlan &P, const FusedPatch &F, T *buf)
-{
-    Level<T> Q = L;
-    const int n = F.c1 - F.c0;
-    if (P.dl == 0) Q.nx = n;
-    else if (P.dl == 1) Q.ny = n;
-    else Q.nz = n;
-    const size_t nex = (size_t)Q.nx * (Q.ny + 1) * (Q.nz + 1), ney = (size_t)(Q.nx + 1) * Q.ny * (Q.nz + 1);
-    const size_t ne = fused_edges(Q.nx, Q.ny, Q.nz);
-    Q.ex = buf; Q.ey = buf + nex; Q.ez = buf + nex + ney;
-    Q.sx = buf + ne; Q.sy = buf + ne + nex; Q.sz = buf + ne + nex + ney;
-    double *const d = reinterpret_cast<double *>(buf + 2 * ne);
-    const size_t nc = ((size_t)Q.nx * Q.ny * Q.nz + 1) / 2 * 2;
-    Q.zeta = d; Q.ihx = d + nc; Q.ihy = d + nc + Q.nx; Q.ihz = d + nc + Q.nx + Q.ny;
-    Q.eta_x = Q.eta_y = Q.eta_z = nullptr;         // (the factor records hold what the lines need of eta)
-    Q.batch = 1; Q.bstride = 0;
-    return Q;
-}
-// One array of the private level against the level's: `visit(private index, level index)` for every element whose
-// index along dl (array extent ndp in the private level) lies in r0 .. r1; thread tid of nth.
-template <class F>
-EMG_HD void fused_box(int dl, int c0, int dx, int dy, int dz, int gdx, int gdy, int r0, int r1, int tid, int nth, F visit)
-{
-    const int ex = dl == 0 ? r1 - r0 + 1 : dx, ey = dl == 1 ? r1 - r0 + 1 : dy, ez = dl == 2 ? r1 - r0 + 1 : dz;
-    const int ox = dl == 0 ? r0 : 0, oy = dl == 1 ? r0 : 0, oz = dl == 2 ? r0 : 0;
-    const int gx = dl == 0 ? c0 : 0, gy = dl == 1 ? c0 : 0, gz = dl == 2 ? c0 : 0;
-    const int total = ex * ey * ez;
-    for (int i = tid; i < total; i += nth) {
-        const int x = i % ex + ox, r = i / ex, y = r % ey + oy, z = r / ey + oz;
-        visit((size_t)x + (size_t)dx * (y + (size_t)dy * z), (size_t)(x + gx) + (size_t)gdx * ((y + gy) + (size_t)gdy * (z + gz)));
-    }
-}
-// copy the patch into its private level (field of right-hand side `boff`, source, zeta)
-template <class T>
-EMG_HD void fused_copy_in(const Level<T> &L, const Level<T> &Q, const FusedPlan &P, const FusedPatch &F, size_t boff, int tid, int nth)
-{
-    const int n = F.c1 - F.c0, dl = P.dl;
-    T *const qe[3] = {Q.ex, Q.ey, Q.ez};
-    T *const qs[3] = {const_cast<T *>(Q.sx), const_cast<T *>(Q.sy), const_cast<T *>(Q.sz)};
-    const T *const le[3] = {L.ex + boff, L.ey + boff, L.ez + boff};
-    const T *const ls[3] = {L.sx + boff, L.sy + boff, L.sz + boff};
-    for (int c = 0; c < 3; ++c) {
-        // extents of component c: cells along its own axis, nodes along the others
-        const int dx = Q.nx + (c != 0), dy = Q.ny + (c != 1), dz = Q.nz + (c != 2);
-        const int gdx = L.nx + (c != 0), gdy = L.ny + (c != 1);
-        const int nd = n + (c != dl);
-        T *const de = qe[c]; T *const ds = qs[c];
-        const T *const se = le[c]; const T *const ss = ls[c];
-        fused_box(dl, F.c0, dx, dy, dz, gdx, gdy, 0, nd - 1, tid, nth, [&](size_t ip, size_t ig) { de[ip] = se[ig]; ds[ip] = ss[ig]; });
-    }
-    double *const dz_ = const_cast<double *>(Q.zeta);
-    const double *const sz_ = L.zeta;
-    fused_box(dl, F.c0, Q.nx, Q.ny, Q.nz, L.nx, L.ny, 0, n - 1, tid, nth, [&](size_t ip, size_t ig) { dz_[ip] = sz_[ig]; });
-    double *const qh[3] = {const_cast<double *>(Q.ihx), const_cast<double *>(Q.ihy), const_cast<double *>(Q.ihz)};
-    const double *const lh[3] = {L.ihx, L.ihy, L.ihz};
-    const int nq[3] = {Q.nx, Q.ny, Q.nz};
-    for (int c = 0; c < 3; ++c)
-        for (int i = tid; i < nq[c]; i += nth) qh[c][i] = lh[c][i + (c == dl ? F.c0 : 0)];
-}
-// the owned planes of the private field `Q` into the same places of another copy `R` of the private level
-template <class T>
-EMG_HD void fused_copy_owned(const Level<T> &Q, const Level<T> &R, const FusedPlan &P, const FusedPatch &F, int tid, int nth)
-{
-    const int dl = P.dl;
-    const T *const qe[3] = {Q.ex, Q.ey, Q.ez};
-    T *const re[3] = {R.ex, R.ey, R.ez};
-    for (int c = 0; c < 3; ++c) {
-        const int dx = Q.nx + (c != 0), dy = Q.ny + (c != 1), dz = Q.nz + (c != 2);
-        int r0, r1;
-        if (c == dl) { r0 = F.a - 1 - F.c0; r1 = (F.b == P.ndl - 1 ? F.b : F.b - 1) - F.c0; }
-        else { r0 = F.a - F.c0; r1 = F.b - F.c0; }
-        const T *const se = qe[c]; T *const de = re[c];
-        fused_box(dl, 0, dx, dy, dz, dx, dy, r0, r1, tid, nth, [&](size_t ip, size_t) { de[ip] = se[ip]; });
-    }
-}
-// copy the owned planes of the private field back: the components across dl at node planes a .. b, the component
-// along dl in cells a-1 .. b-1 (the workgroup of the last plane also owns the last cell)
-template <class T>
-EMG_HD void fused_copy_out(const Level<T> &L, const Level<T> &Q, const FusedPlan &P, const FusedPatch &F, size_t boff, int tid, int nth)
-{
-    const int dl = P.dl;
-    const T *const qe[3] = {Q.ex, Q.ey, Q.ez};
-    T *const le[3] = {L.ex + boff, L.ey + boff, L.ez + boff};
-    for (int c = 0; c < 3; ++c) {
-        const int dx = Q.nx + (c != 0), dy = Q.ny + (c != 1), dz = Q.nz + (c != 2);
-        const int gdx = L.nx + (c != 0), gdy = L.ny + (c != 1);
-        int r0, r1;
-        if (c == dl) { r0 = F.a - 1 - F.c0; r1 = (F.b == P.ndl - 1 ? F.b : F.b - 1) - F.c0; }
-        else { r0 = F.a - F.c0; r1 = F.b - F.c0; }
-        const T *const se = qe[c]; T *const de = le[c];
-        fused_box(dl, F.c0, dx, dy, dz, gdx, gdy, r0, r1, tid, nth, [&](size_t ip, size_t ig) { de[ig] = se[ip]; });
-    }
-}
-
-// Which levels / directions take the fused form, and the plan of a call of nu sweeps. n0max: option line_fused (the
-// longest lines, in blocks, that are fused; 0 = never). The level must hold the N records of the wide form, be long
-// along one axis across the lines, and small across it.
-constexpr int FUSED_MIN_LONG = 32;          // cells along the cut axis, at least
-constexpr int FUSED_MAX_PLANE_LINES = 64;   // lines per node plane across the cut axis, at most
-inline int fused_cut_axis(int dir, int nx, int ny, int nz)
-{
-    const int n[3] = {nx, ny, nz};
-    const int a = (dir + 1) % 3, b = (dir + 2) % 3;
-    return n[a] >= n[b] ? a : b;
-}
-inline bool fused_capable(int dir, int nx, int ny, int nz, int n0max)
-{
-    const int n[3] = {nx, ny, nz};
-    const int n0 = line_n0(dir, nx, ny, nz);
-    if (n0max <= 0 || n0 > n0max || n0 < 3) return false;
-    if (!line_wide_capable(n0, line_records(dir, nx, ny, nz))) return false;
-    const int dl = fused_cut_axis(dir, nx, ny, nz), other = 3 - dir - dl;
-    return n[dl] >= FUSED_MIN_LONG && n[other] - 1 <= FUSED_MAX_PLANE_LINES;
-}
-inline FusedPlan fused_plan(int dir, int nx, int ny, int nz, int nu, int order, bool skip_repeat, int w)
-{
-    FusedPlan P;
-    const int n[3] = {nx, ny, nz};
-    P.dir = dir;
-    P.dl = fused_cut_axis(dir, nx, ny, nz);
-    // (p, q) = DIR 0: (y, z); DIR 1: (x, z); DIR 2: (x, y)
-    P.dl_is_p = (dir == 0 && P.dl == 1) || (dir != 0 && P.dl == 0);
-    P.ndl = n[P.dl];
-    P.w = w < 1 ? 1 : w;
-    P.nwg = cdiv(P.ndl - 1, P.w);
-    P.npass = 0;
-    P.colours = 0;
-    for (int it = 0; it < nu; ++it)
-        for (int cc = 0; cc < 4; ++cc) {
-            if (skip_repeat && cc == 0 && line_pass_repeats(order, it)) continue;
-            if (P.npass < FUSED_MAXPASS) P.colours |= (unsigned long long)line_sweep_colour(order, it, cc) << (2 * P.npass);
-            ++P.npass;
-        }
-    for (int c = 0; c < 4; ++c) {
-        const LineClass lc = line_class(dir, nx, ny, nz, c);
-        P.cntp[c] = lc.cntp; P.cntq[c] = lc.cntq; P.rec0[c] = (long long)(lc.fac_off / 15);
-        P.n0 = lc.n0; P.n0p = lc.n0p;
-    }
-    // the largest private level: w owned planes, the plane below, one plane per pass and side, one cell per side
-    const int nmax = P.w + 1 + 2 * (P.npass < FUSED_MAXPASS ? P.npass : FUSED_MAXPASS) + 2;
-    P.nmax = nmax < P.ndl ? nmax : P.ndl;
-    return P;
-}
 
 // ---- "extended cell" kernels (residual, prolongation, PEC): one thread per node-indexed
 //      cell (ix,iy,iz), 0 <= ix <= nx etc.

@@ -97,24 +97,6 @@ template <class T, int DIR> struct Axes {
         const int phys = (c + DIR) % 3;
         return (phys == 0 ? L.sx : phys == 1 ? L.sy : L.sz) + boff;
     }
-    // The same with a component that is known only at run time (k_line_lanes: the lane's entry decides): element offset
-    // of component c's array from component 0's -- a choice between two DIFFERENCES of the pointers. (Choosing between
-    // the pointers themselves makes the compiler fetch the chosen one from the kernel-argument block by a computed
-    // index: a dependent load in front of every field value.) The three components are parts of one buffer.
-    EMG_HD ptrdiff_t eoff(int c) const
-    {
-        const ptrdiff_t oy = L.ey - L.ex, oz = L.ez - L.ex;
-        const ptrdiff_t o0 = DIR == 0 ? 0 : DIR == 1 ? oy : oz;
-        const int phys = (c + DIR) % 3;
-        return (phys == 0 ? (ptrdiff_t)0 : phys == 1 ? oy : oz) - o0;
-    }
-    EMG_HD ptrdiff_t soff(int c) const
-    {
-        const ptrdiff_t oy = L.sy - L.sx, oz = L.sz - L.sx;
-        const ptrdiff_t o0 = DIR == 0 ? 0 : DIR == 1 ? oy : oz;
-        const int phys = (c + DIR) % 3;
-        return (phys == 0 ? (ptrdiff_t)0 : phys == 1 ? oy : oz) - o0;
-    }
     EMG_HD const T *ETA(int c) const
     {
         const int phys = (c + DIR) % 3;
@@ -955,114 +937,6 @@ EMG_HD void line_rhs(const Axes<T, DIR> &A, int k, int i1, int i2, T (&rhs)[5])
 }
 
 
-// ---- the right-hand side of a block row as a TABLE (kernels.hip: k_line_lanes) ---------------------------
-// Every entry of line_rhs is  source + sum of at most six (real coefficient) x (field value)  products, and the
-// coefficients depend on zeta and the widths only. line_rhs_coefs evaluates the thirty coefficients of row k
-// (entry r, term m at cf[6 r + m]; the face averages by the expressions of line_rhs_t / line_rhs_e0) once per
-// level and direction; line_rhs_term names the field value of a term -- component and offsets from (k, i1, i2),
-// the same for every row -- and line_rhs_entry adds an entry up from the two. One lane per ENTRY can then form
-// the right-hand sides of a block with six multiply-adds each instead of one thread walking all five entries
-// with their face averages. The products h (m e) of line_rhs_t become (h m) e: equal to rounding, not bit for bit.
-struct RhsTerm { int comp, d0, d1, d2; };   // field component (abstract axes) and offsets of the term's edge from (k, i1, i2)
-// (the tables are packed into 64-bit constants, eight bits per term -- comp | d0 << 2 | (d1 + 1) << 3 | (d2 + 1) << 5 --
-//  and picked by comparisons: a table in memory indexed by the lane's entry would put a dependent load in front of every
-//  field value)
-constexpr unsigned long long rhs_pack(const int (&t)[6][4])
-{
-    unsigned long long p = 0;
-    for (int m = 0; m < 6; ++m)
-        p |= (unsigned long long)(t[m][0] | (t[m][1] << 2) | ((t[m][2] + 1) << 3) | ((t[m][3] + 1) << 5)) << (8 * m);
-    return p;
-}
-// entry 0: the along-line edge E0(k); entries 1..4: the transverse edges at node k + 1 (d0 = 1: "i0", 0: "i0m")
-constexpr int RHS_T0[6][4] = {{0, 0, 1, 0}, {0, 0, -1, 0}, {0, 0, 0, 1}, {0, 0, 0, -1}, {0, 0, 1, 0}, {0, 0, 1, 0}};
-constexpr int RHS_T1[6][4] = {{0, 1, -1, 0}, {0, 0, -1, 0}, {2, 1, -1, 0}, {2, 1, -1, -1}, {1, 1, -1, 1}, {1, 1, -1, -1}};
-constexpr int RHS_T2[6][4] = {{0, 0, 1, 0}, {0, 1, 1, 0}, {2, 1, 1, -1}, {2, 1, 1, 0}, {1, 1, 0, 1}, {1, 1, 0, -1}};
-constexpr int RHS_T3[6][4] = {{0, 1, 0, -1}, {0, 0, 0, -1}, {1, 1, 0, -1}, {1, 1, -1, -1}, {2, 1, 1, -1}, {2, 1, -1, -1}};
-constexpr int RHS_T4[6][4] = {{0, 0, 0, 1}, {0, 1, 0, 1}, {1, 1, -1, 1}, {1, 1, 0, 1}, {2, 1, 1, 0}, {2, 1, -1, 0}};
-// the source entry of the five row entries, packed the same way (term m = entry r)
-constexpr int RHS_S[6][4] = {{0, 0, 0, 0}, {1, 1, -1, 0}, {1, 1, 0, 0}, {2, 1, 0, -1}, {2, 1, 0, 0}, {0, 0, 0, 0}};
-EMG_HD RhsTerm rhs_unpack(unsigned long long p, int m)
-{
-    const int code = (int)((p >> (8 * m)) & 0xff);
-    return RhsTerm{code & 3, (code >> 2) & 1, ((code >> 3) & 3) - 1, ((code >> 5) & 3) - 1};
-}
-EMG_HD unsigned long long line_rhs_terms(int r)
-{
-    constexpr unsigned long long P0 = rhs_pack(RHS_T0), P1 = rhs_pack(RHS_T1), P2 = rhs_pack(RHS_T2), P3 = rhs_pack(RHS_T3),
-                                 P4 = rhs_pack(RHS_T4);
-    unsigned long long p = P0;
-    p = r == 1 ? P1 : p;
-    p = r == 2 ? P2 : p;
-    p = r == 3 ? P3 : p;
-    p = r == 4 ? P4 : p;
-    return p;
-}
-EMG_HD RhsTerm line_rhs_term(int r, int m) { return rhs_unpack(line_rhs_terms(r), m); }
-EMG_HD RhsTerm line_rhs_source(int r)
-{
-    constexpr unsigned long long PS = rhs_pack(RHS_S);
-    return rhs_unpack(PS, r);
-}
-template <class T, int DIR>
-EMG_HD void line_rhs_coefs(const Axes<T, DIR> &A, int k, int i1, int i2, double (&cf)[30])
-{
-    const int n0 = A.n0();
-    const int i0m = k;
-    const int i0 = (k + 1 < n0 - 1) ? k + 1 : n0 - 1;
-    const int i1m = i1 - 1, i2m = i2 - 1;
-    const double h00 = A.ih0()[i0m], h01 = A.ih0()[i0];
-    const double h10 = A.ih1()[i1m], h11 = A.ih1()[i1];
-    const double h20 = A.ih2()[i2m], h21 = A.ih2()[i2];
-    const double k00 = 0.5 * h00, k01 = 0.5 * h01, k10 = 0.5 * h10, k11 = 0.5 * h11;
-    const double k20 = 0.5 * h20, k21 = 0.5 * h21;
-    const double z000 = A.zeta(i0m, i1m, i2m), z010 = A.zeta(i0m, i1, i2m);
-    const double z001 = A.zeta(i0m, i1m, i2), z011 = A.zeta(i0m, i1, i2);
-    const double z100 = A.zeta(i0, i1m, i2m), z110 = A.zeta(i0, i1, i2m);
-    const double z101 = A.zeta(i0, i1m, i2), z111 = A.zeta(i0, i1, i2);
-    const double mzyLxm = k10 * (z001 + z000), mzyRxm = k11 * (z011 + z010);
-    const double myzLxm = k20 * (z010 + z000), myzRxm = k21 * (z011 + z001);
-    const double mzxLym = k00 * (z001 + z000), mzxRym = k01 * (z101 + z100);
-    const double mxzLym = k20 * (z100 + z000), mxzRym = k21 * (z101 + z001);
-    const double mzxLyp = k00 * (z011 + z010), mzxRyp = k01 * (z111 + z110);
-    const double mxzLyp = k20 * (z110 + z010), mxzRyp = k21 * (z111 + z011);
-    const double myxLzm = k00 * (z010 + z000), myxRzm = k01 * (z110 + z100);
-    const double mxyLzm = k10 * (z100 + z000), mxyRzm = k11 * (z110 + z010);
-    const double myxLzp = k00 * (z011 + z001), myxRzp = k01 * (z111 + z101);
-    const double mxyLzp = k10 * (z101 + z001), mxyRzp = k11 * (z111 + z011);
-    const bool last = k == n0 - 1;          // (the last row has only the along-line edge)
-    const double t[30] = {
-        mzyRxm * h11, mzyLxm * h10, myzRxm * h21, myzLxm * h20, 0.0, 0.0,
-        h10 * mzxRym, -(h10 * mzxLym), h10 * mxzRym, -(h10 * mxzLym), mxzRym * h21, mxzLym * h20,
-        h11 * mzxLyp, -(h11 * mzxRyp), h11 * mxzLyp, -(h11 * mxzRyp), mxzRyp * h21, mxzLyp * h20,
-        h20 * myxRzm, -(h20 * myxLzm), h20 * mxyRzm, -(h20 * mxyLzm), mxyRzm * h11, mxyLzm * h10,
-        h21 * myxLzp, -(h21 * myxRzp), h21 * mxyLzp, -(h21 * mxyRzp), mxyRzp * h11, mxyLzp * h10};
-#pragma unroll
-    for (int j = 0; j < 30; ++j) cf[j] = (last && j >= 6) ? 0.0 : t[j];
-}
-// entry r of the right-hand side of row k from its six coefficients: source + the products, in the order of the table
-// (the last row's entries 1..4 are zero, not the source)
-template <class T, int DIR>
-EMG_HD T line_rhs_entry(const Axes<T, DIR> &A, int k, int i1, int i2, int r, const double (&c6)[6])
-{
-    const int n0 = A.n0();
-    const int i0 = (k + 1 < n0 - 1) ? k + 1 : n0 - 1;
-    const RhsTerm so = line_rhs_source(r);
-    const unsigned long long terms = line_rhs_terms(r);
-    // (all seven values on their way before the first is used)
-    T ev[6];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        const RhsTerm tm = rhs_unpack(terms, m);
-        ev[m] = A.E(0)[A.eoff(tm.comp) + A.idx(tm.comp, tm.d0 ? i0 : k, i1 + tm.d1, i2 + tm.d2)];
-    }
-    T acc = A.S(0)[A.soff(so.comp) + A.idx(so.comp, so.d0 ? i0 : k, i1 + so.d1, i2 + so.d2)];
-    if (r > 0 && k == n0 - 1) acc = zero<T>();
-#pragma unroll
-    for (int m = 0; m < 6; ++m) acc = mad(c6[m], ev[m], acc);
-    return acc;
-}
-
 // The eight coupling entries of record k of a line's `lfac` (line_setup: put_B), recomputed from zeta and the
 // widths: c[m-1] = first row, c[3+m] = diagonal, m = 1..4. Records 1 .. m of the top half hold B_k (left0 /
 // leftd of line_matrix(k)), records >= m + 1 of the bottom half U_k of the mirrored block (mid[.][0] / leftd of
@@ -1649,7 +1523,7 @@ constexpr size_t WIDE_RECORDS_MAX = (size_t)1 << 19;   // ... on levels with at 
 EMG_HD bool line_wide_capable(int n0, size_t records) { return n0 >= 2 && n0 <= WIDE_N0_MAX && records <= WIDE_RECORDS_MAX; }
 
 // N = (T C)[1..4, 1..4]: N[4 (a-1) + (b-1)] = T(a,0) l0[b] + T(a,b) d[b]
-template <class T, int NT = 15> EMG_HD void wide_n_record(const T (&Tk)[NT], const double (&lf)[8], T (&N)[16])
+template <class T> EMG_HD void wide_n_record(const T (&Tk)[15], const double (&lf)[8], T (&N)[16])
 {
 #pragma unroll
     for (int a = 1; a < 5; ++a)

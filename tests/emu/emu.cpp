@@ -9,7 +9,6 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
-#include <cmath>
 #include <algorithm>
 #include <type_traits>
 #include <vector>
@@ -32,7 +31,6 @@ struct LevelArgs {
 int g_point_slab = 0;
 int g_point_tile_min = 1 << 20;
 int g_line_order = 1;
-int g_line_fused = 0, g_line_fused_w = 8;   // the fused form of launch.h (k_line_fused): longest lines, planes per patch
 int g_line_wide = 0;          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
@@ -140,37 +138,6 @@ void line_colour_wide(const emg::Level<T> &L, int c, const T *fac, const double 
     }
 }
 
-// all colour passes of a call on the private levels of the patches (kernels.hip: k_line_fused + k_line_fused_back):
-// every patch is loaded from the level as it was before the call, the owned planes are written back at the end
-template <class T, int DIR>
-void line_fused(const emg::Level<T> &L, const emg::FusedPlan &P, const T *fac, const double *lfac, const T *nfac)
-{
-    std::vector<std::vector<T>> bufs(P.nwg);
-    for (int wg = 0; wg < P.nwg; ++wg) {
-        emg::FusedPatch F;
-        emg::fused_patch(P, wg, F);
-        bufs[wg].assign(emg::fused_private_elems(P.dl, P.nmax, L.nx, L.ny, L.nz), T(1e300));
-        const emg::Level<T> Q = emg::fused_private_level(L, P, F, bufs[wg].data());
-        emg::fused_copy_in(L, Q, P, F, 0, 0, 1);
-        const emg::Axes<T, DIR> A(Q);
-        for (int t = 1; t <= P.npass; ++t) {
-            const emg::FusedLines S = emg::fused_lines(P, F, t);
-            const int c = S.colour, lines = P.cntp[c] * P.cntq[c];   // (host: plain indexing)
-            for (int ll = 0; ll < S.n; ++ll) {
-                int i1, i2, lid;
-                emg::fused_line<DIR>(P, F, S, ll, i1, i2, lid);
-                emg::line_wide_ref<T, DIR>(A, i1, i2, lines, lid, fac + P.rec0[c] * 15, lfac + P.rec0[c] * 8, nfac + P.rec0[c] * 16);
-            }
-        }
-    }
-    for (int wg = 0; wg < P.nwg; ++wg) {
-        emg::FusedPatch F;
-        emg::fused_patch(P, wg, F);
-        const emg::Level<T> Q = emg::fused_private_level(L, P, F, bufs[wg].data());
-        emg::fused_copy_out(L, Q, P, F, 0, 0, 1);
-    }
-}
-
 template <class T, int DIR> void line_setup_all(const emg::Level<T> &L, T *fac, double *lfac)
 {
     for (int c = 0; c < 4; ++c) {
@@ -236,15 +203,6 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
                         else emg::tile_pst_setup<T, TB, false>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
                     }
     }
-    if (wide && emg::fused_capable(lr - 1, nx, ny, nz, g_line_fused)) {
-        const emg::FusedPlan P = emg::fused_plan(lr - 1, nx, ny, nz, nu, g_line_order, false, g_line_fused_w);
-        if (P.npass <= emg::FUSED_MAXPASS) {
-            if (lr == 1) line_fused<T, 0>(L, P, fac.data(), lfac.data(), nfac.data());
-            else if (lr == 2) line_fused<T, 1>(L, P, fac.data(), lfac.data(), nfac.data());
-            else line_fused<T, 2>(L, P, fac.data(), lfac.data(), nfac.data());
-            return;
-        }
-    }
     int iback = 0;
     for (int it = 0; it < nu; ++it) {
         iback = 1 - iback;
@@ -274,29 +232,6 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
     }
 }
 
-// the right-hand side of every block row of a direction in the table form of k_line_lanes (stencil.h: line_rhs_coefs /
-// line_rhs_entry) against line_rhs: the largest difference, relative to the largest entry
-template <class T, int DIR> double rhs_table_diff(const emg::Level<T> &L)
-{
-    const emg::Axes<T, DIR> A(L);
-    double worst = 0.0, scale = 0.0;
-    for (int i2 = 1; i2 < A.n2(); ++i2)
-        for (int i1 = 1; i1 < A.n1(); ++i1)
-            for (int k = 0; k < A.n0(); ++k) {
-                T want[5];
-                emg::line_rhs<T, DIR>(A, k, i1, i2, want);
-                double cf[30];
-                emg::line_rhs_coefs<T, DIR>(A, k, i1, i2, cf);
-                for (int r = 0; r < 5; ++r) {
-                    const double c6[6] = {cf[6 * r], cf[6 * r + 1], cf[6 * r + 2], cf[6 * r + 3], cf[6 * r + 4], cf[6 * r + 5]};
-                    const T got = emg::line_rhs_entry<T, DIR>(A, k, i1, i2, r, c6);
-                    worst = std::max(worst, emg::abs2(got - want[r]));
-                    scale = std::max(scale, emg::abs2(want[r]));
-                }
-            }
-    return scale > 0 ? std::sqrt(worst / scale) : 0.0;
-}
-
 template <class T> double residual(const LevelArgs *lv, void *rx, void *ry, void *rz)
 {
     emg::Level<T> L = to_level<T>(lv);
@@ -315,18 +250,7 @@ void emu_set_point_slab(int t) { g_point_slab = t; }
 void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
 void emu_set_line_order(int o) { g_line_order = o; }
 void emu_set_line_wide(int w) { g_line_wide = w; }
-void emu_set_line_fused(int n0max, int w) { g_line_fused = n0max; g_line_fused_w = w; }
 void emu_set_point_order(int o) { emg::point_order_ref() = o; }
-
-double emu_rhs_table_diff(const LevelArgs *lv, int lr)
-{
-    if (lv->is_complex) {
-        const emg::Level<cplx> L = to_level<cplx>(lv);
-        return lr == 1 ? rhs_table_diff<cplx, 0>(L) : lr == 2 ? rhs_table_diff<cplx, 1>(L) : rhs_table_diff<cplx, 2>(L);
-    }
-    const emg::Level<double> L = to_level<double>(lv);
-    return lr == 1 ? rhs_table_diff<double, 0>(L) : lr == 2 ? rhs_table_diff<double, 1>(L) : rhs_table_diff<double, 2>(L);
-}
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
 {

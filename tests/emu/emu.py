@@ -29,7 +29,6 @@ def lib():
         _lib = ctypes.CDLL(build())
         _lib.emu_residual.restype = ctypes.c_double
         _lib.emu_residual_column.restype = ctypes.c_double
-        _lib.emu_rhs_table_diff.restype = ctypes.c_double
     return _lib
 
 
@@ -145,11 +144,3 @@ def blocks_to_amat(amat, bvec, middle, left, rhs, im, nc):
     rhs = np.ascontiguousarray(rhs, dtype=dt)
     lib().emu_blocks_to_amat(_ptr(amat), _ptr(bvec), _ptr(middle), _ptr(left), _ptr(rhs),
                              int(im), int(nc), int(dt == np.complex128))
-
-
-def rhs_table_diff(e, s, vm, lr):
-    """Largest difference between line_rhs and its table form (line_rhs_coefs / line_rhs_entry), relative to the
-    largest right-hand-side entry, over all block rows of direction lr."""
-    keep = []
-    lv = make_level(e, s, vm, keep)
-    return lib().emu_rhs_table_diff(ctypes.byref(lv), int(lr))

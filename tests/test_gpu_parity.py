@@ -689,127 +689,6 @@ def test_wide_line_kernel_vs_oracle(shape, lr, dtype):
     assert relerr(b.field, c.field) < 1e-11
 
 
-LANES_SHAPES = [(sh, lr) for sh, lr in SHORT_SHAPES if 3 <= sh[lr - 1] <= 32]
-
-
-@pytest.mark.parametrize('shape,lr', LANES_SHAPES)
-@pytest.mark.parametrize('dtype', [complex, float])
-def test_lanes_line_kernel_vs_oracle(shape, lr, dtype):
-    """k_line_lanes (option line_lanes: eight lanes per block -- one per right-hand-side entry / row of T --, tabulated
-    right-hand-side coefficients, the recurrences of k_line_wide) on every short line length -- 3 ... 32 blocks: no top
-    half, no bottom half, halves of unequal length, one to eight lines per workgroup, surplus chain groups -- nu = 3
-    sweeps against the oracle in the same ordering, and against k_line_wide and k_line_colour (same factors, the
-    right-hand sides summed in the table's order: equal to rounding)."""
-    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + 7 * lr)
-    a, b, c, d = e0.copy(), e0.copy(), e0.copy(), e0.copy()
-    args = (s0.fx, s0.fy, s0.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
-    getattr(ocore, SMOOTHERS[lr])(a.fx, a.fy, a.fz, *args, order=1)
-    with _option('line_lanes', 0), _option('line_wide', 0):
-        getattr(core, SMOOTHERS[lr])(c.fx, c.fy, c.fz, *args)
-    with _option('line_lanes', 0), _option('line_wide', 64):
-        getattr(core, SMOOTHERS[lr])(d.fx, d.fy, d.fz, *args)
-    with _option('line_lanes', 33):
-        assert _lib.lib().emg3d_line_kernel_name(lr, *shape, int(dtype is complex), 1) == b'k_line_lanes'
-        getattr(core, SMOOTHERS[lr])(b.fx, b.fy, b.fz, *args)
-    assert np.any(b.field != e0.field)
-    assert relerr(b.field, a.field) < 1e-11
-    assert relerr(b.field, c.field) < 1e-11
-    assert relerr(b.field, d.field) < 1e-11
-
-
-@pytest.mark.parametrize('shape,lr', [((4, 40, 9), 1), ((34, 16, 30), 2), ((20, 21, 8), 3)])
-@pytest.mark.parametrize('batch,dtype', [(2, complex), (5, complex), (3, float)])
-def test_lanes_line_kernel_batch_equals_single_source(shape, lr, batch, dtype):
-    """k_line_lanes with several right-hand sides (grid.y = right-hand side) gives every source the bits it gets alone."""
-    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + lr + batch)
-    dev = torch.device('cuda')
-    rng = np.random.default_rng(batch)
-    n = e0.field.size
-    srcs = [s0.field * (1 + b) + (0.3 * b) * rng.standard_normal(n) for b in range(batch)]
-    starts = [e0.field * (1.0 - 0.2 * b) for b in range(batch)]
-    with _option('line_lanes', 33):
-        assert _lib.lib().emg3d_line_kernel_name(lr, *shape, int(dtype is complex), batch) == b'k_line_lanes'
-        single = DeviceLevel.from_host(vm, dev)
-        want = []
-        for b in range(batch):
-            single.s.copy_(torch.from_numpy(srcs[b]))
-            single.e.copy_(torch.from_numpy(starts[b]))
-            single.smooth(lr, 3)
-            want.append(single.e.cpu().numpy())
-        many = DeviceLevel.from_host(vm, dev, batch=batch)
-        many._factors = single._factors              # the same factor buffers (they depend on the model only)
-        many.s.copy_(torch.from_numpy(np.concatenate(srcs)))
-        many.e.copy_(torch.from_numpy(np.concatenate(starts)))
-        many.smooth(lr, 3)
-        got = many.e.cpu().numpy().reshape(batch, n)
-    for b in range(batch):
-        assert np.any(want[b] != starts[b])
-        assert np.array_equal(got[b], want[b]), (b, relerr(got[b], want[b]))
-
-
-FUSED_SHAPES = [((256, 4, 4), 2), ((256, 4, 4), 3), ((4, 256, 4), 1), ((4, 256, 4), 3), ((4, 4, 256), 1), ((4, 4, 256), 2),
-                ((128, 8, 8), 2), ((8, 96, 8), 3), ((8, 6, 70), 1), ((40, 3, 16), 3), ((33, 16, 2), 2), ((16, 12, 100), 2),
-                ((100, 16, 16), 3)]
-
-
-@pytest.mark.parametrize('shape,lr', FUSED_SHAPES)
-@pytest.mark.parametrize('dtype,w', [(complex, 8), (float, 5), (complex, 64)])
-def test_fused_line_passes_vs_oracle_and_pass_by_pass(shape, lr, dtype, w):
-    """k_line_fused + k_line_fused_back (option line_fused: ALL colour passes of a smoothing call in one launch on
-    private copies of overlapping patches of a slab / rod level): nu = 1, 2, 3 sweeps (4, 7, 10 passes) against the
-    oracle in the same ordering, and against the same passes launched one by one in the same arithmetic
-    (k_line_wide) -- patches of 5, 8 and 64 node planes (1 ... 51 workgroups, halos clipped at the level's faces),
-    cuts along x, y and z, p- and q-type class numbering along the cut, lines of 2 ... 16 blocks."""
-    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + 5 * lr)
-    for nu in (1, 2, 3):
-        a, b, c = e0.copy(), e0.copy(), e0.copy()
-        args = (s0.fx, s0.fy, s0.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, nu)
-        getattr(ocore, SMOOTHERS[lr])(a.fx, a.fy, a.fz, *args, order=1)
-        with _option('line_wide', 64):
-            getattr(core, SMOOTHERS[lr])(c.fx, c.fy, c.fz, *args)
-        with _option('line_fused', 17), _option('line_fused_w', w):
-            # (the private level of a patch must fit the LDS of a CU beside the rows and staged records of a round of
-            #  lines: the 4-cell levels always do; larger ones fall back to the pass-by-pass launches)
-            name = _lib.lib().emg3d_line_kernel_name(lr, *shape, int(dtype is complex), 1)
-            assert name == b'k_line_fused' or sorted(shape)[1] > 4 or w == 64, (shape, lr, w, name)
-            getattr(core, SMOOTHERS[lr])(b.fx, b.fy, b.fz, *args)
-        assert np.any(b.field != e0.field)
-        assert relerr(b.field, a.field) < 1e-11, (nu, relerr(b.field, a.field))
-        if name == b'k_line_fused' and nu == 2:      # (same arithmetic as the wide form, pass by pass)
-            assert relerr(b.field, c.field) < 1e-13, (nu, relerr(b.field, c.field))
-
-
-@pytest.mark.parametrize('shape,lr', [((4, 70, 4), 1), ((64, 4, 4), 2), ((6, 3, 64), 1)])
-@pytest.mark.parametrize('batch,dtype', [(2, complex), (5, complex), (3, float)])
-def test_fused_line_passes_batch_equals_single_source(shape, lr, batch, dtype):
-    """k_line_fused with several right-hand sides (grid.y = right-hand side, a private level per patch and right-hand
-    side) gives every source the bits it gets alone."""
-    grid, vm, s0, e0 = _random_level_fields(shape, dtype, sum(shape) + lr + batch)
-    dev = torch.device('cuda')
-    rng = np.random.default_rng(batch)
-    n = e0.field.size
-    srcs = [s0.field * (1 + b) + (0.3 * b) * rng.standard_normal(n) for b in range(batch)]
-    starts = [e0.field * (1.0 - 0.2 * b) for b in range(batch)]
-    with _option('line_fused', 17):
-        assert _lib.lib().emg3d_line_kernel_name(lr, *shape, int(dtype is complex), batch) == b'k_line_fused'
-        single = DeviceLevel.from_host(vm, dev)
-        want = []
-        for b in range(batch):
-            single.s.copy_(torch.from_numpy(srcs[b]))
-            single.e.copy_(torch.from_numpy(starts[b]))
-            single.smooth(lr, 2)
-            want.append(single.e.cpu().numpy())
-        many = DeviceLevel.from_host(vm, dev, batch=batch)
-        many._factors = single._factors              # the same factor buffers (they depend on the model only)
-        many.s.copy_(torch.from_numpy(np.concatenate(srcs)))
-        many.e.copy_(torch.from_numpy(np.concatenate(starts)))
-        many.smooth(lr, 2)
-        got = many.e.cpu().numpy().reshape(batch, n)
-    for b in range(batch):
-        assert np.any(want[b] != starts[b])
-        assert np.array_equal(got[b], want[b]), (b, relerr(got[b], want[b]))
-
-
 @pytest.mark.parametrize('shape,lr', [((4, 40, 9), 1), ((34, 16, 30), 2), ((20, 21, 64), 3)])
 @pytest.mark.parametrize('batch,dtype', [(2, complex), (5, complex), (3, float)])
 def test_wide_line_kernel_batch_equals_single_source(shape, lr, batch, dtype):

@@ -412,44 +412,3 @@ def test_wide_line_form_matches_oracle(shape, freq):
             assert relerr(b.field, a.field) < tol, (shape, fn)
     finally:
         emu.lib().emu_set_line_wide(0)
-
-
-@pytest.mark.parametrize('shape', [(40, 4, 6), (4, 37, 5), (6, 4, 33), (33, 8, 2), (64, 3, 16)])
-@pytest.mark.parametrize('w', [1, 5, 8, 64])
-def test_fused_line_passes_equal_pass_by_pass(shape, w):
-    """launch.h: fused_plan / fused_patch / fused_lines / fused_copy_in / _out -- all colour passes of a call on
-    private copies of overlapping patches (what k_line_fused + k_line_fused_back do) against the same passes one
-    after the other on the whole level (wide form): the halo rule (one more plane per side where the outermost
-    needed plane is solved in a pass), the class indices of the lines of a patch, the private level's index
-    arithmetic and the ownership of the planes written back. Bit for bit, for every line direction across the
-    long axis, nu = 1 .. 3 (4, 8, 12 passes in the emulation, which does not skip the repeated pass), patches of
-    1, 5, 8 planes and a single patch."""
-    grid, vm, s, e0 = _random_case(shape, 1.3, 11)
-    lib = emu.lib()
-    try:
-        lib.emu_set_line_wide(1)
-        for lr in (1, 2, 3):
-            if shape[lr - 1] == max(shape):
-                continue
-            for nu in (1, 2, 3):
-                a, b = e0.copy(), e0.copy()
-                lib.emu_set_line_fused(0, w)
-                emu.gauss_seidel(a, s, vm, lr, nu)
-                lib.emu_set_line_fused(17, w)
-                emu.gauss_seidel(b, s, vm, lr, nu)
-                assert not np.array_equal(a.field, e0.field)
-                assert np.array_equal(a.field, b.field), (shape, lr, nu, w, relerr(b.field, a.field))
-    finally:
-        lib.emu_set_line_wide(0)
-        lib.emu_set_line_fused(0, 8)
-
-
-@pytest.mark.parametrize('shape,freq', [((6, 5, 7), 1.3), ((2, 9, 4), -2.0), ((12, 3, 3), 0.5), ((4, 4, 17), 1.3)])
-def test_rhs_table_form_equals_line_rhs(shape, freq):
-    """stencil.h: line_rhs_coefs / line_rhs_term / line_rhs_entry -- the right-hand side of a block row as source + six
-    tabulated (coefficient) x (field value) products per entry, what a lane of k_line_lanes evaluates -- against
-    line_rhs for every row of every line of the three directions (first and last rows, lines next to the faces):
-    the coefficients of the thirty terms, their field components and offsets, the zeroed last row."""
-    grid, vm, s, e0 = _random_case(shape, freq, 5)
-    for lr in (1, 2, 3):
-        assert emu.rhs_table_diff(e0, s, vm, lr) < 1e-14, (shape, lr)
