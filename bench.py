@@ -467,23 +467,39 @@ def time_to_tol_cpu(ttt, value, seconds=40.0):
                    'worth in cycles of the reference ordering, measured on the reduced copy')
 
 
+def csrc_sha16():
+    """First 16 hex digits of the SHA-256 over the library's source files (name order): names the build a committed
+    measurement belongs to on a box without git."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'emg3d_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload_name, kernel):
     """(HBM bytes per launch of the dominant kernel, where the figure comes from): read from the
     committed PMC summary of the newest round (profiles/rNN_pmc_traffic.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes of this very command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured in this run, counters cannot be read
     from inside the process; (None, None) if there is no entry for this workload and kernel."""
-    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        name = os.path.basename(path)
         try:
-            with open(os.path.join(ROOT, 'profiles', name)) as f:
+            with open(path) as f:
                 doc = json.load(f)
             entry = doc[workload_name][kernel]
             src = {'file': 'profiles/' + name, 'measured_in_this_run': False,
                    'how': 'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command '
                           '(tools/profile_bench.sh), FETCH_SIZE x 2'}
-            for k in ('library_commit', 'date', 'passes'):
+            for k in ('library_commit', 'date', 'passes', 'csrc_sha16'):
                 if k in doc.get('_meta', {}):
                     src[k] = doc['_meta'][k]
+            # stale: the counters were collected with other library sources than the ones this run uses
+            src['stale'] = src.get('csrc_sha16') != csrc_sha16()
             return entry['bytes_per_launch'], src
         except (OSError, KeyError, ValueError):
             continue

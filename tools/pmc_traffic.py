@@ -1,4 +1,4 @@
-"""Turn the two PMC passes of a bench run into profiles/<round>_pmc_traffic.json (round: env PMC_ROUND, default r04).
+"""Turn the two PMC passes of a bench run into profiles/<round>_pmc_traffic.json (round: env PMC_ROUND, default r05).
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/f -o run -- python bench.py ...
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/w -o run -- python bench.py ...
@@ -66,7 +66,7 @@ def main():
         res['k_gs_point_tile'] = {'bytes_per_launch': 2 * fetch[k][1] * 1024 + write.get(k, (0, 0, 0))[1] * 1024,
                                   'kernels': {'k_gs_point_tile': {'read': 2 * fetch[k][1] * 1024, 'write': write.get(k, (0, 0, 0))[1] * 1024,
                                                                   'grid': fetch[k][0], 'launches': fetch[k][2]}}}
-    rnd = os.environ.get('PMC_ROUND', 'r04')
+    rnd = os.environ.get('PMC_ROUND', 'r05')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', f'{rnd}_pmc_traffic.json')
     try:
         with open(path) as f:
@@ -80,6 +80,11 @@ def main():
     meta['passes'] = 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, tools/profile_bench.sh'
     if os.environ.get('PMC_COMMIT'):
         meta['library_commit'] = os.environ['PMC_COMMIT']
+    # what the counters were measured on: the hash of the library's sources (bench.py flags a summary whose hash is not
+    # that of the sources it runs with -- there is no git on the GPU box)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from bench import csrc_sha16
+    meta['csrc_sha16'] = csrc_sha16()
     with open(path, 'w') as f:
         json.dump(allres, f, indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))

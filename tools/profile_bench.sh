@@ -4,7 +4,7 @@
 #   two PMC passes of the same command (separate runs, no trace options combined with --pmc), and
 #   the same three passes over the 256^3 smoother measurement (tools/microbench.py: the north-star
 #   kernel k_gs_point_tile); summaries under gpurun_out/ -- copy what is to be judged to profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 WL=${2:-triaxial256}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
