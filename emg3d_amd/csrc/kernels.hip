@@ -1157,6 +1157,26 @@ __device__ __forceinline__ void wide_chain(T *rows, const T *nbase, size_t nrow,
     }
 }
 
+// (LDS written by some lanes of a wave, read by others of the same wave: the hardware runs a wave's LDS operations in
+//  order; this keeps the compiler from moving them across)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// row r of T_Q z (two accumulators, summed as wide_middle sums them)
+template <class T> __device__ __forceinline__ T wide_row6(const T (&row)[6], const T *z)
+{
+    const T lo = emg::mad(row[4], z[4], emg::mad(row[2], z[2], emg::mad(row[0], z[0], emg::zero<T>())));
+    const T hi = emg::mad(row[5], z[5], emg::mad(row[3], z[3], emg::mad(row[1], z[1], emg::zero<T>())));
+    return lo + hi;
+}
+
+// The middle blocks (6 x 6) have EIGHT LANES per line (wave 3: lane r = 0..5 owns entry / row r): one thread walking
+// wide_middle -- six z entries, six rows of T_Q z, eight h entries: ~2 700 ticks -- was what the workgroup waited for at
+// the barrier behind phase C (the block threads need ~1 200, profiles/r05_small_level_experiments.txt). The operations
+// and their order are wide_middle's, entry by entry: the same bits.
 template <class T, int DIR, bool BATCH>
 __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int colour, int cntp, int cntq, int lpw,
                                                          const T *fac, const double *lfac, const T *nfac)
@@ -1171,36 +1191,44 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     const int rows = n0 + 1;                               // (row n0 of a line: the dummy row)
     T *const GY = reinterpret_cast<T *>(lw_smem);          // [lpw][rows][LW_ROW]: g, then y
     T *const GH = GY + (size_t)lpw * rows * LW_ROW;        //                      g', then h
+    T *const RQ = GH + (size_t)lpw * rows * LW_ROW;        // [lpw][2][LW_ROW]: the middle blocks' r_Q -> z, and x_Q
     const int t = threadIdx.x;
     const bool isq = t >= LW_BLOCK_THREADS;
     const int tq = t - LW_BLOCK_THREADS;
-    const bool has = isq ? tq < nl : t < nl * nblk;
+    const int rq = tq & 7;                                 // middle blocks: lane rq of the line's eight
+    const bool has = isq ? (tq >> 3) < nl && rq < 6 : t < nl * nblk;
     int ll = 0, j = 0;
-    if (isq) ll = tq;
+    if (isq) ll = tq >> 3;
     else if (has) {
-        if (DIR == 0) { ll = t / nblk; j = t - ll * nblk; }      // x-lines: the field is contiguous along the line
-        else { j = t / nl; ll = t - j * nl; }
+        if (DIR == 0) { ll = emg::fast_div(t, nblk); j = t - ll * nblk; }      // x-lines: the field is contiguous along the line
+        else { j = emg::fast_div(t, nl); ll = t - j * nl; }
     }
     int i1 = 0, i2 = 0, k = 0, mir = 0;
-    T Tk[21], r[6];                                         // block thread: T_k (15), r -> c (5); middle: T_Q (21), r_Q (6)
-    double lf[8], lf2[8];                                   // C_k; middle: B_m, U_{m+1}
+    T Tk[15], r[5];                                         // block thread: T_k, r -> c
+    double lf[8];                                           // C_k
+    T qrow[6];                                              // middle lane: row rq of T_Q
+    double cq[4] = {0.0, 0.0, 0.0, 0.0};                    //   its entries of B_m / U_{m+1}: lane 0 / 5 the first row, 1..4 {B(0,b), B(b,b), U(0,b), U(b,b)}
+    T *const rqv = RQ + (size_t)ll * 2 * LW_ROW;
     // ---- (A) right-hand sides, factor records, g --------------------------------------------------
     if (has) {
         const int lid = line0 + ll;
         int l2;
-        emg::line_of_thread<DIR>(colour, cntp, cntq, lid % cntp, lid / cntp, i1, i2, l2);
+        const int tq_ = emg::fast_div(lid, cntp);
+        emg::line_of_thread<DIR>(colour, cntp, cntq, lid - tq_ * cntp, tq_, i1, i2, l2);
         if (!isq) {
             const emg::WideBlock wb = emg::wide_block(j, mk);
             k = wb.k; mir = wb.mir;
             T rb[5];
             emg::wide_block_rhs<T, DIR>(A, k, mir, i1, i2, rb);
+            // (the factor records behind the right-hand sides in program order: fetched first, the phase got slower --
+            //  5.7 -> 6.25 us per launch on 4- and 8-block lines)
             const size_t rec = (size_t)k * nlines + lid;
 #pragma unroll
             for (int q = 0; q < 15; ++q) Tk[q] = fac[rec * 15 + q];
 #pragma unroll
             for (int q = 0; q < 8; ++q) lf[q] = lfac[rec * 8 + q];
             T g[4];
-            emg::wide_g<T, 21>(Tk, rb, g);
+            emg::wide_g<T, 15>(Tk, rb, g);
             T *const row = GY + ((size_t)ll * rows + k) * LW_ROW;
 #pragma unroll
             for (int q = 0; q < 4; ++q) row[q] = g[q];
@@ -1209,18 +1237,28 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
 #pragma unroll
             for (int q = 0; q < 5; ++q) r[q] = rb[q];
         } else {
-            T rm[5];
-            emg::line_rhs<T, DIR>(A, mk, i1, i2, rm);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) r[q] = rm[q];
-            r[5] = emg::line_rhs_e0<T, DIR>(A, mk + 1, i1, i2);
+            // every lane its row of T_Q (21 packed entries over the records m and m + 1) and its coupling entries ...
             const size_t rm0 = (size_t)mk * nlines + lid, rm1 = rm0 + nlines;
 #pragma unroll
-            for (int q = 0; q < 15; ++q) Tk[q] = fac[rm0 * 15 + q];
+            for (int b = 0; b < 6; ++b) {
+                const int q = emg::sym(rq, b);
+                qrow[b] = q < 15 ? fac[rm0 * 15 + q] : fac[rm1 * 15 + q - 15];
+            }
+            if (rq == 0 || rq == 5) {
 #pragma unroll
-            for (int q = 0; q < 6; ++q) Tk[15 + q] = fac[rm1 * 15 + q];
+                for (int b = 0; b < 4; ++b) cq[b] = lfac[(rq == 0 ? rm0 : rm1) * 8 + b];
+            } else {
+                cq[0] = lfac[rm0 * 8 + rq - 1]; cq[1] = lfac[rm0 * 8 + 4 + rq - 1];
+                cq[2] = lfac[rm1 * 8 + rq - 1]; cq[3] = lfac[rm1 * 8 + 4 + rq - 1];
+            }
+            // ... and lane 0 the six right-hand-side entries of the block, for all of them
+            if (rq == 0) {
+                T rm[5];
+                emg::line_rhs<T, DIR>(A, mk, i1, i2, rm);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { lf[q] = lfac[rm0 * 8 + q]; lf2[q] = lfac[rm1 * 8 + q]; }
+                for (int q = 0; q < 5; ++q) rqv[q] = rm[q];
+                rqv[5] = emg::line_rhs_e0<T, DIR>(A, mk + 1, i1, i2);
+            }
         }
     }
     WSTAMP(1);
@@ -1256,7 +1294,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
 #pragma unroll
             for (int q = 0; q < 5; ++q) rb[q] = r[q];
             emg::wide_c<T>(lf, rb, yp, c);
-            const T w0 = emg::wide_row5<T, 21>(Tk, 0, c);
+            const T w0 = emg::wide_row5<T, 15>(Tk, 0, c);
             emg::wide_gp<T>(lf, w0, y, gp);
             T *const o = GH + ((size_t)ll * rows + (first ? n0 : kn)) * LW_ROW;
 #pragma unroll
@@ -1264,26 +1302,47 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
 #pragma unroll
             for (int q = 0; q < 5; ++q) r[q] = c[q];
         } else {
+            // z entry by entry (wide_middle): z_0 = r_0 - B(0,.) y_T, z_5 = r_5 - U(0,.) y_B, z_b = r_b - B(b,b) y_T,b - U(b,b) y_B,b
             const T *const yt = GY + ((size_t)ll * rows + max(mk - 1, 0)) * LW_ROW;
             const T *const yb = GY + ((size_t)ll * rows + min(mk + 2, n0 - 1)) * LW_ROW;
-            T yT[4], yB[4], xq[6], hT[4], hB[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const T vt = yt[q], vb = yb[q];
-                yT[q] = nbt > 0 ? vt : emg::zero<T>();
-                yB[q] = nbb > 0 ? vb : emg::zero<T>();
+            T z = rqv[rq];
+            if (rq == 0 || rq == 5) {
+                const T *const y = rq == 0 ? yt : yb;
+                const bool any = rq == 0 ? nbt > 0 : nbb > 0;
+                const T y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+                T q = cq[0] * (any ? y0 : emg::zero<T>());
+                q = emg::mad(cq[1], any ? y1 : emg::zero<T>(), q);
+                q = emg::mad(cq[2], any ? y2 : emg::zero<T>(), q);
+                q = emg::mad(cq[3], any ? y3 : emg::zero<T>(), q);
+                z = z - q;
+            } else {
+                const T vt = yt[rq - 1], vb = yb[rq - 1];
+                const T yT = nbt > 0 ? vt : emg::zero<T>(), yB = nbb > 0 ? vb : emg::zero<T>();
+                z = emg::nmad(cq[3], yB, emg::nmad(cq[1], yT, z));
             }
-            emg::wide_middle<T>(Tk, lf, lf2, r, yT, yB, xq, hT, hB);
-            T *const ot = GH + ((size_t)ll * rows + (nbt > 0 ? mk - 1 : n0)) * LW_ROW;
-            T *const ob = GH + ((size_t)ll * rows + (nbb > 0 ? mk + 2 : n0)) * LW_ROW;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ot[q] = hT[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ob[q] = hB[q];
-            const T xs[5] = {xq[0], xq[1], xq[2], xq[3], xq[4]};
-            emg::wide_block_scatter<T, DIR>(A, mk, 0, i1, i2, xs);
-            A.E(0)[A.idx(0, mk + 1, i1, i2)] = xq[5];
+            rqv[LW_ROW + rq] = z;
         }
+    }
+    wave_sync();
+    T xq = emg::zero<T>();
+    if (has && isq) {
+        xq = wide_row6<T>(qrow, rqv + LW_ROW);             // x_Q row by row
+        rqv[rq] = xq;
+    }
+    wave_sync();
+    if (has && isq) {
+        if (rq >= 1 && rq <= 4) {                          // h of the two neighbouring blocks, entry by entry
+            const T x0 = rqv[0], x5 = rqv[5];
+            GH[((size_t)ll * rows + (nbt > 0 ? mk - 1 : n0)) * LW_ROW + rq - 1] = emg::mad(cq[0], x0, cq[1] * xq);
+            GH[((size_t)ll * rows + (nbb > 0 ? mk + 2 : n0)) * LW_ROW + rq - 1] = emg::mad(cq[2], x5, cq[3] * xq);
+        }
+        // the middle block's solution: entries 0..4 of block m (wide_block_scatter), and E0(m + 1)
+        if (rq == 0) A.E(0)[A.idx(0, mk, i1, i2)] = xq;
+        else if (rq == 1) A.E(1)[A.idx(1, mk + 1, i1 - 1, i2)] = xq;
+        else if (rq == 2) A.E(1)[A.idx(1, mk + 1, i1, i2)] = xq;
+        else if (rq == 3) A.E(2)[A.idx(2, mk + 1, i1, i2 - 1)] = xq;
+        else if (rq == 4) A.E(2)[A.idx(2, mk + 1, i1, i2)] = xq;
+        else A.E(0)[A.idx(0, mk + 1, i1, i2)] = xq;
     }
     WSTAMP(5);
     __syncthreads();
@@ -1309,7 +1368,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
         for (int q = 0; q < 4; ++q) h[q] = hr[q];
 #pragma unroll
         for (int q = 0; q < 5; ++q) c[q] = r[q];
-        emg::wide_x<T, 21>(Tk, c, h, x);
+        emg::wide_x<T, 15>(Tk, c, h, x);
         emg::wide_block_scatter<T, DIR>(A, k, mir, i1, i2, x);
     }
     WSTAMP(9);
@@ -1950,7 +2009,7 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const size_t dummy_off = vstride - emg::LINE_DUMMY;
     if (line_wide_used(DIR, L.nx, L.ny, L.nz)) {
         const int lpw = wide_lpw(lc.n0);
-        const size_t smem = (size_t)2 * lpw * (lc.n0 + 1) * LW_ROW * sizeof(T);
+        const size_t smem = ((size_t)2 * lpw * (lc.n0 + 1) + 2 * lpw) * LW_ROW * sizeof(T);
         const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + lc.fac_off / 15 * 16;
         const dim3 grid(cdiv(lc.lines, lpw), L.batch);
         if (L.batch > 1)

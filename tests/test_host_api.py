@@ -475,3 +475,17 @@ def test_stall_switch_control_flow_without_a_gpu(auto, monkeypatch):
     assert top.calls[first_to - 1] == ('residual', True, False) and top.calls[:first_to].count('cycle') == 4
     assert top.calls.index('reserve') < first_to
     assert top._b_valid is False
+
+
+def test_fast_div_is_exact():
+    """launch.h: fast_div (single-precision quotient of (a + 1/2) / b, what the small line kernels use instead of the
+    integer-division sequence) equals a // b on the whole range it is used on (a < 2^19, every divisor up to 4096,
+    and larger divisors at the quotient boundaries)."""
+    a = np.arange(1 << 19, dtype=np.int64)
+    for b in list(range(1, 4097, 7)) + [1, 2, 3, 5, 8, 63, 64, 65, 127, 191, 255, 256, 4095, 4096]:
+        q = ((a.astype(np.float32) + np.float32(0.5)) / np.float32(b)).astype(np.int64)
+        assert np.array_equal(q, a // b), b
+    for b in (10007, 65537, 262147, (1 << 19) - 1):
+        aa = np.unique(np.clip(np.concatenate([np.arange(0, 1 << 19, b) + d for d in (-1, 0, 1)]), 0, (1 << 19) - 1))
+        q = ((aa.astype(np.float32) + np.float32(0.5)) / np.float32(b)).astype(np.int64)
+        assert np.array_equal(q, aa // b), b
