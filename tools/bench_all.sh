@@ -1,7 +1,7 @@
 #!/bin/bash
-# The bench lines of a round (through gpurun, from the repo root):  TAG=r04 bash tools/bench_all.sh
+# The bench lines of a round (through gpurun, from the repo root):  TAG=r05 bash tools/bench_all.sh
 # -> gpurun_out/${TAG}_bench_<workload>.json; copy what is to be judged to profiles/.
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 python bench.py > gpurun_out/${TAG}_bench_triaxial256.json 2> gpurun_out/${TAG}_bench.err
 for w in marine128 salt384 uniform256; do python bench.py --workload $w --no-survey --no-256 > gpurun_out/${TAG}_bench_$w.json 2>/dev/null; done
 TAG=$TAG python - <<'PY'
