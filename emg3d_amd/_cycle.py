@@ -175,7 +175,7 @@ GRAPH_AFTER = int(os.environ.get('EMG3D_AMD_GRAPH_AFTER', '2'))   # eager occurr
 CONCURRENT = 0
 
 
-def coarse_correction(clv, var, budget, first_level=1, graphed=None):
+def coarse_correction(clv, var, budget, first_level=1, graphed=None, top=None):
     """Everything below ``first_level - 1``: eager, or through a HIP graph captured at the
     variant's third occurrence (the first, eager one builds all levels, factors and scratch;
     capturing costs about as much host time as an eager pass and pays off only for variants
@@ -204,7 +204,9 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None):
             if stale:
                 for k in stale:
                     del cache[k]
-                _drop_stale_point_factors(clv)
+                # (from the finest level on, where the caller names it: its eta-sum buffer is the largest of them, and
+                #  the subtrees of the other semicoarsening directions hang off it)
+                _drop_stale_point_factors(top if top is not None else clv)
             entry = cache[key] = {'work': None, 'graph': None, 'seen': 0}
         if entry['seen'] < GRAPH_AFTER:
             before = var.smoother_cell_sweeps
@@ -413,7 +415,7 @@ def _one_cycle(top, var, it, loud):
             _log_smoothing(var, 0, top, "pre-smoothing", it)
     sc = current_sc_dir(var.sc_dir, top.grid)
     top.residual(store=True, norm=False)
-    coarse_correction(top.restrict_to(sc), var, var.cycmax)
+    coarse_correction(top.restrict_to(sc), var, var.cycmax, top=top)
     top.prolong_from(sc)
     if var.first_cycle and var.verb > 3:
         var.level_all.append(0)

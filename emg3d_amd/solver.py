@@ -404,7 +404,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
         sc_dir = _current_sc_dir(svar.sc_dir, lv.grid)
         lv.residual(store=True, norm=False)
         clv = lv.restrict_to(sc_dir)
-        _cycle.coarse_correction(clv, svar, cycmax)       # eager, or the captured graph of this variant
+        _cycle.coarse_correction(clv, svar, cycmax, top=lv)       # eager, or the captured graph of this variant
         lv.prolong_from(sc_dir)
         if svar.nu_post > 0:
             _smooth(lv, svar.nu_post, svar.lr_dir, svar)
