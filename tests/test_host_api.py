@@ -412,7 +412,9 @@ def test_bench_helpers_without_a_gpu():
         assert lib.emg3d_set_option(b'line_stream_r', bad) != 0
     assert lib.emg3d_set_option(b'line_stream_r', 8) == 0 and lib.emg3d_set_option(b'line_stream_r', 0) == 0
     traffic, src = bench.pmc_traffic('triaxial256', 'k_gs_line<y>')
-    assert traffic > 3e9 and src['file'].startswith('profiles/r04') and src['measured_in_this_run'] is False
+    assert traffic > 3e9 and src['file'].startswith('profiles/r') and src['measured_in_this_run'] is False
+    # the summary names the sources it was measured on; `stale` says whether they are the ones in the tree
+    assert src['stale'] == (src.get('csrc_sha16') != bench.csrc_sha16())
     assert bench.pmc_traffic('no_such_workload', 'k') == (None, None)
 
 
