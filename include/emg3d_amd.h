@@ -100,7 +100,8 @@ int emg3d_version(void);
 const char *emg3d_last_error(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int emg3d_device_count(void);
-/* Tuning knobs; all but "point_tile_min", "line_order" and "point_order" never change results. "point_slab": plane-slab thickness of the point
+/* Tuning knobs; all but "point_tile_min", "line_order", "point_order" (the order of the sweeps) and "line_wide" (the
+ * rounding of the short-line solves) never change results. "point_slab": plane-slab thickness of the point
  * smoother's launch schedule (0 = one launch per colour over all planes). "point_tile_min"
  * DOES select the sweep order of the point smoother (see above; <= 0 never tiled). "line_lds":
  * 1 (default) keeps the right-hand-side / solution records of a fused line launch in LDS
@@ -127,6 +128,12 @@ int emg3d_device_count(void);
  * serve GROUPS of up to four right-hand sides per workgroup, every factor row fetched once per group
  * (k_line_stream<.., B>; per source the same arithmetic: bit-identical to separate solves) -- with the batch
  * as a grid dimension every source's workgroups fetch the factors again.
+ * "line_wide": lines of at most this many blocks (default 17; 0 = never; only on levels small enough to hold one more
+ * 16-entry record per block) are solved by k_line_wide: the same direct solve of the line system as the other line
+ * kernels (emg3d/core.py:1481-1616) with the same factors, but with the block recurrences restated in four unknowns
+ * through the model-only matrices N_k = (T_k C_k)[1..4, 1..4], which are one more rounding of T_k C_k -- fields agree
+ * with the other kernels' to rounding (~1e-13 per call), not bit for bit. A level runs the same kernel for every
+ * right-hand side, alone or in a batch, so batched and separate solves stay bit-identical under any value.
  * "line_order" and "point_order" DO select the order of the sweeps (see above), like
  * "point_tile_min".
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
