@@ -121,9 +121,14 @@ int g_line_stream_lf = 1;
 // the wide form of the line pass (k_line_wide: four-unknown chains on sixteen lanes per half-line, one thread per
 // block for everything else) on lines of at most this many blocks, where the level holds the N records (launch.h:
 // line_wide_capable -- a function of the level's shape alone, so that buffers sized once stay valid whatever the
-// option says); 0: never. Default 17 (round 5): on 4 ... 16-block lines a launch takes 6.0 / 6.1 / 8.5 us against 6.0 / 8.1 /
-// 12.0 of k_line_colour, on 32- and 64-block lines it is no faster (profiles/r05_small_level_experiments.txt)
-int g_line_wide = 17;
+// option says); 0: never. Default 33 (round 5): on 4 ... 32-block lines a launch takes 5.7 / 5.7 / 8.4 / 17.3 us against 6.0 /
+// 8.1 / 12.0 / 20.4 of k_line_colour, on 64-block lines it is no faster (profiles/r05_small_level_experiments.txt)
+int g_line_wide = 33;
+// block threads of a k_line_wide workgroup (+ 64 for the middle blocks): 0 (default) 192, or 256 where that gives a
+// workgroup more lines (lines of 26 and more blocks: 8 instead of 6 lines of 32 blocks -- 2 048 lines per class are
+// then one workgroup per CU: 21.1 -> 17.3 us per launch at 256 x 32 x 32, k_line_colour 20.4; on shorter lines the fifth
+// wave only adds to the barriers: 5.8 -> 6.5 us); 192 / 256: forced
+int g_line_wide_bt = 0;
 // TIMING EXPERIMENTS ONLY (wrong results): bit 0: the records of all blocks of a line alias one row of
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
@@ -1079,7 +1084,7 @@ constexpr int LW_THREADS = 256;
 constexpr int LW_BLOCK_THREADS = 192;      // waves 0..2: one thread per top / bottom block; wave 3: the middle blocks
 constexpr int LW_ROW = 6;                  // entries of an LDS row: values 1..4, a zero, a dummy
 // lines per workgroup: at most 8 (two chain waves per half), and every block of them needs a thread
-inline int wide_lpw(int n0) { return std::max(1, std::min(8, LW_BLOCK_THREADS / std::max(n0 - 2, 1))); }
+inline int wide_lpw(int n0, int nbthr = LW_BLOCK_THREADS) { return std::max(1, std::min(8, nbthr / std::max(n0 - 2, 1))); }
 
 template <class T> __global__ __launch_bounds__(256) void k_line_wide_setup(const T *fac, const double *lfac, T *nfac, size_t nrec)
 {
@@ -1101,7 +1106,7 @@ template <class T> __global__ __launch_bounds__(256) void k_line_wide_setup(cons
 __device__ unsigned long long g_wide_stamps[32];
 #define WSTAMP(i)                                                                                       \
     do {                                                                                                \
-        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == LW_BLOCK_THREADS))                   \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == nbthr))                   \
             g_wide_stamps[(threadIdx.x ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime();                 \
     } while (0)
 #else
@@ -1178,8 +1183,8 @@ template <class T> __device__ __forceinline__ T wide_row6(const T (&row)[6], con
 // the barrier behind phase C (the block threads need ~1 200, profiles/r05_small_level_experiments.txt). The operations
 // and their order are wide_middle's, entry by entry: the same bits.
 template <class T, int DIR, bool BATCH>
-__global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int colour, int cntp, int cntq, int lpw,
-                                                         const T *fac, const double *lfac, const T *nfac)
+__global__ __launch_bounds__(LW_THREADS + 64) void k_line_wide(emg::Level<T> L, int colour, int cntp, int cntq, int lpw,
+                                                              const T *fac, const double *lfac, const T *nfac, int nbthr)
 {
     extern __shared__ double2 lw_smem[];
     WSTAMP(0);
@@ -1193,8 +1198,8 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     T *const GH = GY + (size_t)lpw * rows * LW_ROW;        //                      g', then h
     T *const RQ = GH + (size_t)lpw * rows * LW_ROW;        // [lpw][2][LW_ROW]: the middle blocks' r_Q -> z, and x_Q
     const int t = threadIdx.x;
-    const bool isq = t >= LW_BLOCK_THREADS;
-    const int tq = t - LW_BLOCK_THREADS;
+    const bool isq = t >= nbthr;                           // (nbthr block threads: 192, or 256 with a fifth wave for the middle blocks)
+    const int tq = t - nbthr;
     const int rq = tq & 7;                                 // middle blocks: lane rq of the line's eight
     const bool has = isq ? (tq >> 3) < nl && rq < 6 : t < nl * nblk;
     int ll = 0, j = 0;
@@ -1268,7 +1273,7 @@ __global__ __launch_bounds__(LW_THREADS) void k_line_wide(emg::Level<T> L, int c
     // groups all walk the same number of steps; groups beyond the last line repeat it (identical stores)
     const int wave = t >> 6, lane = t & 63, half = wave >> 1;
     const int cl = min((wave & 1) * 4 + (lane >> 4), nl - 1);
-    const bool chain_wave = (wave & 1) * 4 < nl;
+    const bool chain_wave = wave < 4 && (wave & 1) * 4 < nl;
     const T *const nbase = nfac + (size_t)line0 * 16;
     const size_t nrow = (size_t)nlines * 16;
     // ---- (F) forward chains: y_k = g_k - N_k y_kn ---------------------------------------------------
@@ -2008,14 +2013,15 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const size_t vstride = emg::line_vec_elems(DIR, L.nx, L.ny, L.nz);    // scratch of one right-hand side
     const size_t dummy_off = vstride - emg::LINE_DUMMY;
     if (line_wide_used(DIR, L.nx, L.ny, L.nz)) {
-        const int lpw = wide_lpw(lc.n0);
+        const int nbthr = g_line_wide_bt == 256 || (g_line_wide_bt == 0 && wide_lpw(lc.n0, 256) > wide_lpw(lc.n0, LW_BLOCK_THREADS)) ? 256 : LW_BLOCK_THREADS;
+        const int lpw = wide_lpw(lc.n0, nbthr);
         const size_t smem = ((size_t)2 * lpw * (lc.n0 + 1) + 2 * lpw) * LW_ROW * sizeof(T);
         const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + lc.fac_off / 15 * 16;
         const dim3 grid(cdiv(lc.lines, lpw), L.batch);
         if (L.batch > 1)
-            hipLaunchKernelGGL((k_line_wide<T, DIR, true>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
+            hipLaunchKernelGGL((k_line_wide<T, DIR, true>), grid, dim3(nbthr + 64), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf, nbthr);
         else
-            hipLaunchKernelGGL((k_line_wide<T, DIR, false>), grid, dim3(LW_THREADS), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf);
+            hipLaunchKernelGGL((k_line_wide<T, DIR, false>), grid, dim3(nbthr + 64), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf, nbthr);
         return;
     }
     const LinePlan P = line_plan<T>(lc, L.batch);
@@ -2384,7 +2390,8 @@ static const OptionEntry g_options[] = {
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
-    {"line_wide", &g_line_wide},
+    {"line_wide", &g_line_wide},         {"line_wide_bt", &g_line_wide_bt},
+   
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value
@@ -2405,6 +2412,7 @@ int emg3d_set_option(const char *name, int value)
     // ring pass would be read past its end), and two chunks x two halves x 16 lines must fit the LDS of a CU
     if (!std::strcmp(name, "line_stream_r") && value != 0 && (value < 4 || value > 32 || value % emg::LINE_PAD != 0))
         return fail(EMG3D_ERR_BADARG, "line_stream_r: 0 (= 16) or a multiple of 4 in 4..32");
+    if (!std::strcmp(name, "line_wide_bt") && value != 0 && value != 192 && value != 256) return fail(EMG3D_ERR_BADARG, "line_wide_bt: 0, 192 or 256");
     if (!std::strcmp(name, "line_order") && (value < 0 || value > 2)) return fail(EMG3D_ERR_BADARG, "line_order: 0, 1 or 2");
     if (!std::strcmp(name, "point_order") && (value < 0 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_order: 0 or 1");
     for (const OptionEntry &o : g_options)

@@ -128,7 +128,7 @@ int emg3d_device_count(void);
  * serve GROUPS of up to four right-hand sides per workgroup, every factor row fetched once per group
  * (k_line_stream<.., B>; per source the same arithmetic: bit-identical to separate solves) -- with the batch
  * as a grid dimension every source's workgroups fetch the factors again.
- * "line_wide": lines of at most this many blocks (default 17; 0 = never; only on levels small enough to hold one more
+ * "line_wide": lines of at most this many blocks (default 33; 0 = never; only on levels small enough to hold one more
  * 16-entry record per block) are solved by k_line_wide: the same direct solve of the line system as the other line
  * kernels (emg3d/core.py:1481-1616) with the same factors, but with the block recurrences restated in four unknowns
  * through the model-only matrices N_k = (T_k C_k)[1..4, 1..4], which are one more rounding of T_k C_k -- fields agree

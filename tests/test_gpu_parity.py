@@ -689,6 +689,23 @@ def test_wide_line_kernel_vs_oracle(shape, lr, dtype):
     assert relerr(b.field, c.field) < 1e-11
 
 
+@pytest.mark.parametrize('shape,lr', [((5, 33, 9), 1), ((35, 8, 37), 2), ((70, 5, 32), 3), ((33, 70, 6), 1), ((40, 63, 40), 2)])
+def test_wide_line_kernel_block_thread_count_does_not_change_bits(shape, lr):
+    """k_line_wide with 192 and with 256 block threads per workgroup (option line_wide_bt; 0 picks 256 where it gives a
+    workgroup more lines, i.e. on lines of 26 and more blocks): another distribution of the same blocks over threads and
+    workgroups -- 6 / 8 lines of 32 blocks, the middle blocks in wave 3 / wave 4 -- and the same bits."""
+    grid, vm, s0, e0 = _random_level_fields(shape, complex, sum(shape) + 3 * lr)
+    args = (s0.fx, s0.fy, s0.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta, *grid.h, 3)
+    out = []
+    for bt in (0, 192, 256):
+        b = e0.copy()
+        with _option('line_wide', 64), _option('line_wide_bt', bt):
+            getattr(core, SMOOTHERS[lr])(b.fx, b.fy, b.fz, *args)
+        out.append(b.field.copy())
+    assert np.any(out[0] != e0.field)
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+
+
 @pytest.mark.parametrize('shape,lr', [((4, 40, 9), 1), ((34, 16, 30), 2), ((20, 21, 64), 3)])
 @pytest.mark.parametrize('batch,dtype', [(2, complex), (5, complex), (3, float)])
 def test_wide_line_kernel_batch_equals_single_source(shape, lr, batch, dtype):

@@ -399,7 +399,7 @@ def test_bench_helpers_without_a_gpu():
         assert bench.line_kernel_name(lr, (64, 64, 64)) == 'k_line_colour'
         assert bench.line_kernel_name(lr, (256, 256, 256), batch=4) == 'k_line_stream'
         assert bench.line_kernel_name(lr, (64, 64, 64), batch=4) == 'k_line_colour'
-    assert bench.line_kernel_name(1, (384, 256, 256)) == 'k_line_stream' and bench.line_kernel_name(2, (256, 16, 16)) == 'k_line_wide' and bench.line_kernel_name(2, (256, 32, 32)) == 'k_line_colour'
+    assert bench.line_kernel_name(1, (384, 256, 256)) == 'k_line_stream' and bench.line_kernel_name(2, (256, 32, 32)) == 'k_line_wide' and bench.line_kernel_name(2, (256, 64, 64)) == 'k_line_colour'
     assert bench.line_kernel_name(2, (128, 128, 128), batch=8) == 'k_line_stream'
     lib = _lib.lib()
     old = lib.emg3d_get_option(b'line_lpw')

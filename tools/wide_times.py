@@ -26,9 +26,9 @@ for n in (2, 4, 8, 16, 32, 64):
     lv, grid = make_level(0, 'triaxial', shape=shape)
     for lr in (2, 3):
         row = []
-        for name, opts in (('colour', {'line_wide': 0}), ('wide', {'line_wide': 64})):
+        for name, opts in (('colour', {'line_wide': 0}), ('wide', {'line_wide': 64, 'line_wide_bt': 192}), ('wide 256', {'line_wide': 64, 'line_wide_bt': 256})):
             for k, v in opts.items():
                 lib.emg3d_set_option(k.encode(), v)
             row.append(f"{name} {time_call(lv, lr) / 7:7.2f}")
-        lib.emg3d_set_option(b'line_wide', 17)
+        lib.emg3d_set_option(b'line_wide', 33); lib.emg3d_set_option(b'line_wide_bt', 0)
         print(f"{str(shape):>14s} lr={lr}  us per launch:  " + '   '.join(row), flush=True)
