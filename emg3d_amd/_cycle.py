@@ -322,6 +322,10 @@ def run_cycles(top, var):
     # cond of a block, relative to the right-hand side they are given -- then scale with the
     # residual, not with the field, and the iteration converges to round-off.
     resform = bool(getattr(var, 'residual_form', False)) and not var.sslsolver and top.batch == 1
+    if getattr(getattr(top, 'work', None), 'line_compact', False) and not var.sslsolver and top.batch == 1 and not resform:
+        # compact line records (solver.Hierarchy(line_compact=...)): the streamed line solves are perturbed by
+        # eps32 x cond, the finest level must see residuals, not the field
+        resform = var.residual_form = True
     if resform:
         top._b_valid = False
     l2_last = top.residual(store=resform, norm=True)

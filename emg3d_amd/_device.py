@@ -63,6 +63,9 @@ class Workspace:
         # HBM: 304 B per cell and direction) or 'rebuild' (DeviceLevel.line_factors)
         self.factor_policy = 'resident'
         self.factor_epoch = 0          # advanced by every coarse-grid correction (_cycle.coarse_correction)
+        # compact line records on the levels that stream them (solver.Hierarchy(line_compact=...)): every level of
+        # the hierarchy carries LEVEL_LINE_COMPACT, and the finest level runs in residual form (_cycle.run_cycles)
+        self.line_compact = False
 
     def upload(self, a):
         """Small host array -> device tensor through a pinned staging pool, asynchronously on
@@ -187,6 +190,16 @@ class DeviceLevel:
                                  for lr in (1, 2, 3)))
         return top
 
+    def set_line_compact(self, on=True):
+        """Mark this level (and the coarse levels made from it afterwards) as solving correction equations only:
+        the streamed line passes keep their T and w records in single precision (include/emg3d_amd.h:
+        EMG3D_LEVEL_LINE_COMPACT). Before the first line factorisation of the level."""
+        if self._factors or self.__dict__.get('_slots') or self.children:
+            raise RuntimeError("set_line_compact: the level already has factors or coarse levels")
+        self.flags = (self.flags | _lib.LEVEL_LINE_COMPACT) if on else (self.flags & ~_lib.LEVEL_LINE_COMPACT)
+        self._c.flags = self.flags
+        self.work.line_compact = bool(on)
+
     @property
     def r(self):
         if self._r is None:
@@ -262,8 +275,9 @@ class DeviceLevel:
         if lr not in self._factors:
             lib = _lib.lib()
             nx, ny, nz = self.grid.shape_cells
-            fac = torch.empty(lib.emg3d_line_fac_bytes(lr, nx, ny, nz, self.is_complex),
-                              dtype=torch.uint8, device=self.device)
+            # (sized for THIS level: 120 instead of 240 B per block where the direction keeps compact records,
+            # emg3d_level.flags & LEVEL_LINE_COMPACT)
+            fac = torch.empty(lib.emg3d_line_fac_bytes_lv(self._cref, lr), dtype=torch.uint8, device=self.device)
             lfac = torch.empty(lib.emg3d_line_lfac_bytes(lr, nx, ny, nz), dtype=torch.uint8,
                                device=self.device)
             _lib.check(lib.emg3d_dev_line_setup(self._cref, lr, _ptr(fac), _ptr(lfac), _stream()),

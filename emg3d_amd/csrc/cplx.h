@@ -44,6 +44,29 @@ EMG_HD cplx &operator+=(cplx &a, double b) { a.re += b; return a; }
 EMG_HD cplx &operator*=(cplx &a, cplx b) { a = a * b; return a; }
 EMG_HD cplx &operator*=(cplx &a, double b) { a.re *= b; a.im *= b; return a; }
 
+// Compact (single-precision) STORAGE types of the line factors and w records ("compact line
+// factors"): values are rounded once when they are stored and widened when they are loaded; every arithmetic
+// operation stays fp64. compact_of<T>::type: cplx -> cplxf, double -> float.
+struct cplxf {
+    float re, im;
+    EMG_HD cplxf() {}
+    EMG_HD cplxf(float r, float i) : re(r), im(i) {}
+};
+template <class T> struct compact_of;
+template <> struct compact_of<double> { using type = float; };
+template <> struct compact_of<cplx> { using type = cplxf; };
+EMG_HD double widen(double a) { return a; }
+EMG_HD double widen(float a) { return (double)a; }
+EMG_HD cplx widen(cplx a) { return a; }
+EMG_HD cplx widen(cplxf a) { return cplx((double)a.re, (double)a.im); }
+// value of type T as the storage type S (S = T: unchanged; S = compact_of<T>: rounded to nearest)
+template <class S> struct narrow_to;
+template <> struct narrow_to<double> { static EMG_HD double of(double a) { return a; } };
+template <> struct narrow_to<float> { static EMG_HD float of(double a) { return (float)a; } };
+template <> struct narrow_to<cplx> { static EMG_HD cplx of(cplx a) { return a; } };
+template <> struct narrow_to<cplxf> { static EMG_HD cplxf of(cplx a) { return cplxf((float)a.re, (float)a.im); } };
+template <class S, class T> EMG_HD S narrow(T a) { return narrow_to<S>::of(a); }
+
 // 1/z with one real division: conj(z) / |z|^2.
 EMG_HD cplx recip(cplx a)
 {

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include "../../include/emg3d_amd.h"
 #include "launch.h"
@@ -133,6 +134,23 @@ int g_line_wide_bt = 0;
 // the global scratch -- what the level-0 pass would cost if its right-hand-side / solution records
 // never left the chip
 int g_line_debug = 0;
+// COMPACT line factors (k_line_stream): the T records and the w records of the streamed colour passes stored in
+// single precision (120 + 2 x 40 instead of 240 + 2 x 80 B per block and pass; every operation in fp64). 0 (default):
+// where the level asks for it (emg3d_level::flags & EMG3D_LEVEL_LINE_COMPACT -- the caller's promise that the level
+// solves a correction equation, include/emg3d_amd.h); 1: on every level whose direction streams (timing / tests);
+// -1: never
+int g_line_compact = 0;
+// ... depth of the chain waves' factor prefetch ring in the compact kernel (4 or 8 block steps ahead: a compact ring
+// entry holds 12 instead of 24 registers). 0 (default): 8 for x-lines, 4 for y- and z-lines -- same-box A/B at 256^3,
+// ms per launch x / y / z: fp64 records 0.885 / 0.955 / 0.969, compact with 4: 0.817 / 0.757 / 0.748, with 8: 0.740 /
+// 0.794 / 0.789 (the producers of y / z lines, whose gathers use half of every cache line, are what the chains wait
+// for: more chain loads in flight delay them; x-line producers read whole lines)
+int g_line_compact_rd = 0;
+// ... workgroups per CU of the compact kernel: 1 (four producer waves, 16 rows per ring chunk: 147 KB of LDS) or 2 (two
+// producer waves, 8 rows per chunk: 74 KB -- two workgroups of four waves share a CU and fill each other's start-up,
+// middle-block and drain phases)
+int g_line_compact_occ = 1;
+int g_line_compact_np = 256;       // producer threads of the compact kernel: 256 or 384 (experiment)
 
 // eta edge sums of the tiled point smoother: 8-byte storage (launch.h: tile_pst_*) for real
 // fields and for complex fields whose eta are purely imaginary (emg3d_level::flags)
@@ -363,17 +381,18 @@ __global__ __launch_bounds__(256) void k_any_real_part(const cplx *a, size_t n, 
 // All four colour classes in one launch (grid.z = colour): the recurrence of a line is one long
 // dependent chain, and a class alone puts one wave pair on every CU -- four of them interleave.
 struct SetupClasses { int cntp[4], cntq[4]; size_t fac_off[4], lfac_off[4]; };
-template <class T, int DIR>
-__global__ __launch_bounds__(128) void k_line_setup(emg::Level<T> L, SetupClasses S, T *fac0, double *lfac0)
+// FT: storage type of the T records (T, or emg::compact_of<T>: rounded when stored)
+template <class T, int DIR, class FT = T>
+__global__ __launch_bounds__(128) void k_line_setup(emg::Level<T> L, SetupClasses S, FT *fac0, double *lfac0)
 {
     __shared__ T xch[15][64];
     const int colour = blockIdx.z, cntp = S.cntp[colour], cntq = S.cntq[colour];
-    T *const fac = fac0 + S.fac_off[colour];
+    FT *const fac = fac0 + S.fac_off[colour];
     double *const lfac = lfac0 + S.lfac_off[colour];
     const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int i1, i2, lid;
     const bool valid = emg::line_of_thread<DIR>(colour, cntp, cntq, blockIdx.x * 64 + lane, blockIdx.y, i1, i2, lid);
-    const emg::LineStore<T> st{fac, lfac, cntp * cntq, lid};
+    const emg::LineStore<T, FT> st{fac, lfac, cntp * cntq, lid};
     const int n0p = emg::line_padded(emg::Axes<T, DIR>(L).n0());
     T C[10], dinv[5];
 #pragma unroll
@@ -382,9 +401,9 @@ __global__ __launch_bounds__(128) void k_line_setup(emg::Level<T> L, SetupClasse
     for (int j = 0; j < 5; ++j) dinv[j] = T(1.0);
     if (valid) {
         if (role == 0) {
-            emg::line_setup_top<T, DIR>(L, i1, i2, st, C, dinv);
+            emg::line_setup_top<T, DIR, FT>(L, i1, i2, st, C, dinv);
         } else {
-            emg::line_setup_bottom<T, DIR>(L, i1, i2, st, n0p, C, dinv);
+            emg::line_setup_bottom<T, DIR, FT>(L, i1, i2, st, n0p, C, dinv);
 #pragma unroll
             for (int j = 0; j < 10; ++j) xch[j][lane] = C[j];
 #pragma unroll
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(128) void k_line_setup(emg::Level<T> L, SetupClasse
         for (int j = 0; j < 10; ++j) Cb[j] = xch[j][lane];
 #pragma unroll
         for (int j = 0; j < 5; ++j) db[j] = xch[10 + j][lane];
-        emg::line_setup_middle<T, DIR>(L, i1, i2, st, C, dinv, Cb, db);
+        emg::line_setup_middle<T, DIR, FT>(L, i1, i2, st, C, dinv, Cb, db);
     }
 }
 
@@ -504,9 +523,13 @@ template <int R, class T> __device__ __forceinline__ T quad_rot(T x)
 // The row of T_k is kept in ROTATED order, t[r] = T_k(j, (j + r) & 3): the quad all-gathers a
 // 4-vector with three cyclic shifts (12 DPP moves) instead of four broadcasts (16), lane j
 // then holds entry (j + r) & 3 in its r-th register.
-template <class T> struct QuadRow {
-    T t[5];          // T_k(j, (j+r)&3), r = 0..3;  t[4] = T_k(j, 4)
-    T t44;           // T_k(4,4)
+// FT: the type the T entries are HELD in -- T, or their compact storage type (emg::compact_of<T>): the ring then keeps
+// the values as they were loaded (half the registers) and the step functions widen them where they use them. (Widened
+// right after the load, the compiler converts a whole ring pass at the end of the loop body behind s_waitcnt
+// vmcnt(0): the prefetch distance is gone -- measured 8 % slower than fp64 records.)
+template <class T, class FT = T> struct QuadRow {
+    FT t[5];         // T_k(j, (j+r)&3), r = 0..3;  t[4] = T_k(j, 4)
+    FT t44;          // T_k(4,4)
     T v, v4;         // vec[j], vec[4]
     double bA;       // lane j >= 1: B_k(0, j);  lane 0: B_k(0, 4)
     double bD;       // lane j >= 1: B_k(j, j)   (lane 0: B_k(1,1), masked out)
@@ -524,9 +547,10 @@ template <class T> struct QuadRow {
     template <class A, bool RECS = true, bool LF = true> __device__ __forceinline__ void load(const A &a, int k)
     {
         const char *f = a.fac + (size_t)k * a.frow, *lf = a.lfac + (size_t)k * a.lrow;
+        static_assert(std::is_same<FT, typename A::fac_t>::value, "QuadRow: held type = storage type of the T records");
 #pragma unroll
-        for (int r = 0; r < 5; ++r) t[r] = *reinterpret_cast<const T *>(f + a.ft[r]);
-        t44 = *reinterpret_cast<const T *>(f + a.ft[5]);
+        for (int r = 0; r < 5; ++r) t[r] = *reinterpret_cast<const FT *>(f + a.ft[r]);
+        t44 = *reinterpret_cast<const FT *>(f + a.ft[5]);
         if constexpr (!RECS) {
         } else if constexpr (A::split) {
             // split records: the slot is in LDS or in the global scratch, depending on the row --
@@ -612,8 +636,10 @@ template <class T> struct VecRef {
 // loop-invariant, non-negative 32-bit per-lane part. Without the split every load of every
 // step pays 64-bit per-lane multiplies (v_mad_u64_u32: quarter rate) -- a quarter of the
 // issue slots of a step.
-template <class T, int HALF, bool SPLIT = false> struct LaneAddr {
+// FT / WT: storage types of the T records / of the right-hand-side and w records (T, or emg::compact_of<T>)
+template <class T, int HALF, bool SPLIT = false, class FT = T, class WT = T> struct LaneAddr {
     static constexpr bool split = SPLIT;
+    using fac_t = FT;
     const char *fac, *lfac;      // uniform
     size_t frow, lrow;           // bytes of one block row of the factor arrays (all lines)
     unsigned ft[6];              // lane byte offsets in a fac row: T(j,(j+r)&3) r=0..3, T(j,4), T(4,4)
@@ -627,21 +653,21 @@ template <class T, int HALF, bool SPLIT = false> struct LaneAddr {
     size_t gvrow;
     unsigned gvj;
     int klo, khi, radd;
-    const T *ldum, *gdum;
-    __device__ __forceinline__ LaneAddr(const T *f, const double *lf, int nlines, int line, int j, const VecRef<T> &V)
+    const WT *ldum, *gdum;
+    __device__ __forceinline__ LaneAddr(const FT *f, const double *lf, int nlines, int line, int j, const VecRef<WT> &V)
     {
         fac = reinterpret_cast<const char *>(f);
         lfac = reinterpret_cast<const char *>(lf);
-        frow = (size_t)nlines * 15 * sizeof(T);
+        frow = (size_t)nlines * 15 * sizeof(FT);
         lrow = (size_t)nlines * 8 * sizeof(double);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = (j + r) & 3;
             const int idx = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
-            ft[r] = (unsigned)((line * 15 + idx) * sizeof(T));
+            ft[r] = (unsigned)((line * 15 + idx) * sizeof(FT));
         }
-        ft[4] = (unsigned)((line * 15 + 10 + j) * sizeof(T));
-        ft[5] = (unsigned)((line * 15 + 14) * sizeof(T));
+        ft[4] = (unsigned)((line * 15 + 10 + j) * sizeof(FT));
+        ft[5] = (unsigned)((line * 15 + 14) * sizeof(FT));
         la = (unsigned)((line * 8 + (j == 0 ? 3 : j - 1)) * sizeof(double));
         ld = (unsigned)((line * 8 + 4 + max(j, 1) - 1) * sizeof(double));
         l04 = (unsigned)((line * 8 + 3) * sizeof(double));
@@ -650,18 +676,18 @@ template <class T, int HALF, bool SPLIT = false> struct LaneAddr {
         // uniform part uses k-1, lane 0 adds one row
         vb = reinterpret_cast<char *>(V.base);
         vb4 = reinterpret_cast<char *>(V.base4);
-        vrow = (size_t)V.stride * V.width * sizeof(T);
-        vrow4 = (size_t)V.stride4 * 5 * sizeof(T);
-        vj = (unsigned)(((line - V.line0) * V.width + j) * sizeof(T)) + ((HALF && j == 0) ? (unsigned)vrow : 0u);
-        v4 = (unsigned)(((line - V.line04) * 5 + 4) * sizeof(T));
+        vrow = (size_t)V.stride * V.width * sizeof(WT);
+        vrow4 = (size_t)V.stride4 * 5 * sizeof(WT);
+        vj = (unsigned)(((line - V.line0) * V.width + j) * sizeof(WT)) + ((HALF && j == 0) ? (unsigned)vrow : 0u);
+        v4 = (unsigned)(((line - V.line04) * 5 + 4) * sizeof(WT));
         if (SPLIT) {
             gvb = reinterpret_cast<char *>(V.gbase);
-            gvrow = (size_t)V.gstride * 5 * sizeof(T);
-            gvj = (unsigned)((line * 5 + j) * sizeof(T));
+            gvrow = (size_t)V.gstride * 5 * sizeof(WT);
+            gvj = (unsigned)((line * 5 + j) * sizeof(WT));
             klo = V.klo; khi = V.khi;
             radd = (HALF && j == 0) ? 1 : 0;
-            ldum = reinterpret_cast<const T *>(vb + (size_t)V.klo * vrow + (unsigned)(((line - V.line0) * V.width + j) * sizeof(T)));
-            gdum = reinterpret_cast<const T *>(gvb + gvj);
+            ldum = reinterpret_cast<const WT *>(vb + (size_t)V.klo * vrow + (unsigned)(((line - V.line0) * V.width + j) * sizeof(WT)));
+            gdum = reinterpret_cast<const WT *>(gvb + gvj);
         }
     }
     // SPLIT: is this lane's slot of block k (record row k, or k-1 (+1 for lane 0) in a mirrored half) in LDS?
@@ -670,17 +696,17 @@ template <class T, int HALF, bool SPLIT = false> struct LaneAddr {
         const int row = (HALF ? k - 1 : k) + radd;
         return row >= klo && row < khi;
     }
-    __device__ __forceinline__ T *gpvj(int k) const
+    __device__ __forceinline__ WT *gpvj(int k) const
     {
-        return reinterpret_cast<T *>(gvb + (size_t)((HALF ? k - 1 : k) + radd) * gvrow + gvj);
+        return reinterpret_cast<WT *>(gvb + (size_t)((HALF ? k - 1 : k) + radd) * gvrow + gvj);
     }
-    __device__ __forceinline__ T *pvj(int k) const
+    __device__ __forceinline__ WT *pvj(int k) const
     {
-        return reinterpret_cast<T *>(vb + (size_t)(HALF ? k - 1 : k) * vrow + vj);
+        return reinterpret_cast<WT *>(vb + (size_t)(HALF ? k - 1 : k) * vrow + vj);
     }
-    __device__ __forceinline__ T *pv4(int k) const
+    __device__ __forceinline__ WT *pv4(int k) const
     {
-        return reinterpret_cast<T *>(vb4 + (size_t)(HALF ? k - 1 : k) * vrow4 + v4);
+        return reinterpret_cast<WT *>(vb4 + (size_t)(HALF ? k - 1 : k) * vrow4 + v4);
     }
 };
 
@@ -691,10 +717,12 @@ template <class T, int HALF, bool SPLIT = false> struct LaneAddr {
 // last line walk the last line again but store into a dummy area behind the records.
 // One block step of a forward half-chain: (v, v4) = this lane's right-hand-side entries j and 4 of
 // the block, q its factor record; updates the carried (wsel, w4p), returns w_j and w_4.
-template <class T>
-__device__ __forceinline__ void quad_forward_step(const QuadRow<T> &q, const T v, const T v4, const double nz,
+template <class T, class Q>
+__device__ __forceinline__ void quad_forward_step(const Q &q, const T v, const T v4, const double nz,
                                                   const double is0, T &wsel, T &w4p, T &wn, T &w4)
 {
+    const T t0 = emg::widen(q.t[0]), t1 = emg::widen(q.t[1]), t2 = emg::widen(q.t[2]), t3 = emg::widen(q.t[3]),
+            t4 = emg::widen(q.t[4]), t44 = emg::widen(q.t44);
     // c_j = rhs_j - (B w_prev)_j ; row 0: the row sum ; row j: B(j,j) w_j
     const T rowsum = quad_sum(xop::mul(q.bA, wsel));
     const T cj = emg::nmad(xop::mul(q.bD, nz), wsel, emg::nmad(is0, rowsum, v));
@@ -702,8 +730,8 @@ __device__ __forceinline__ void quad_forward_step(const QuadRow<T> &q, const T v
     const T c1 = quad_rot<1>(cj), c2 = quad_rot<2>(cj), c3 = quad_rot<3>(cj);
     // w_j = sum_m T(j,m) c_m ; w_4 from the partial products T(j,4) c_j
     // two accumulators, four fused multiply-adds per complex product (cplx.h: mad)
-    wn = xop::add(emg::mad(q.t[4], c4, emg::mad(q.t[1], c1, xop::mul(q.t[0], cj))), emg::mad(q.t[3], c3, xop::mul(q.t[2], c2)));
-    w4 = emg::mad(q.t44, c4, quad_sum(xop::mul(q.t[4], cj)));
+    wn = xop::add(emg::mad(t4, c4, emg::mad(t1, c1, xop::mul(t0, cj))), emg::mad(t3, c3, xop::mul(t2, c2)));
+    w4 = emg::mad(t44, c4, quad_sum(xop::mul(t4, cj)));
     wsel = emg::mad(nz, wn, xop::mul(is0, w4));
     w4p = w4;
 }
@@ -770,9 +798,9 @@ __global__ __launch_bounds__(64) void k_line_forward(int n0, int n0p, int nlines
 // x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}]). Every lane forms the 6-vector z (cheap,
 // real x complex), lane j the rows j and j2 = 4 + (j & 1) of T_Q z (rows 4 / 5 are computed
 // twice); xa = x_Q[j], xb = x_Q[j2].
-template <class T>
-__device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int line, int j, const T *fac,
-                                            const double *lfac, const VecRef<T> V, T &xa, T &xb)
+template <class T, class FT = T, class WT = T>
+__device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int line, int j, const FT *fac,
+                                            const double *lfac, const VecRef<WT> V, T &xa, T &xb)
 {
     const int mk = emg::line_mid(n0);
     const size_t rm = (size_t)mk * nlines + line, rp = rm + nlines;
@@ -785,21 +813,21 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
     for (int m = 0; m < 6; ++m) {
         const int ia = j >= m ? j * (j + 1) / 2 + m : m * (m + 1) / 2 + j;
         const int ib = j2 >= m ? j2 * (j2 + 1) / 2 + m : m * (m + 1) / 2 + j2;
-        ta[m] = ia < 15 ? fac[rm * 15 + ia] : fac[rp * 15 + (ia - 15)];
-        tb[m] = ib < 15 ? fac[rm * 15 + ib] : fac[rp * 15 + (ib - 15)];
+        ta[m] = emg::widen(ia < 15 ? fac[rm * 15 + ia] : fac[rp * 15 + (ia - 15)]);
+        tb[m] = emg::widen(ib < 15 ? fac[rm * 15 + ib] : fac[rp * 15 + (ib - 15)]);
     }
     T z[6];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[r] = *V.p(mk, line, r);
-    z[4] = *V.p4(mk, line);
-    z[5] = *V.p(mk + 1, line, 0);
+    for (int r = 0; r < 4; ++r) z[r] = emg::widen(*V.p(mk, line, r));
+    z[4] = emg::widen(*V.p4(mk, line));
+    z[5] = emg::widen(*V.p(mk + 1, line, 0));
     {   // top coupling B_m w_{m-1} (zero if there is no top half: B_0 is stored as zeros)
         const int kt = mk > 0 ? mk - 1 : mk;
         const double *lf = lfac + rm * 8;
         T q0 = emg::zero<T>();
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
-            const T y = m < 4 ? *V.p(kt, line, m) : *V.p4(kt, line);
+            const T y = emg::widen(m < 4 ? *V.p(kt, line, m) : *V.p4(kt, line));
             q0 = emg::mad(lf[m - 1], y, q0);
             z[m] = emg::nmad(lf[3 + m], y, z[m]);
         }
@@ -811,7 +839,7 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
         T q0 = emg::zero<T>();
 #pragma unroll
         for (int m = 1; m < 5; ++m) {
-            const T y = m < 4 ? *V.p(mk + 1, line, m) : *V.p4(mk + 1, line);
+            const T y = emg::widen(m < 4 ? *V.p(mk + 1, line, m) : *V.p4(mk + 1, line));
             q0 = emg::mad(lf[m - 1], y, q0);
             z[m] = emg::nmad(lf[3 + m], y, z[m]);
         }
@@ -925,8 +953,8 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
 // One block step of a backward half-chain for one right-hand side: (wj, w4) = this lane's entries j and 4 of
 // the block's w record, q its factor record, (upA, upD, up04, up44) the coupling to the block solved before;
 // updates the carried x_0 / x_4 / own entry and returns the block's x_j and x_4.
-template <class T>
-__device__ __forceinline__ void quad_backward_step(const QuadRow<T> &q, const T wj, const T w4, const double nz,
+template <class T, class Q>
+__device__ __forceinline__ void quad_backward_step(const Q &q, const T wj, const T w4, const double nz,
                                                    const double upA, const double upD, const double up04,
                                                    const double up44, T &x0, T &x4, T &xmine, T &xn, T &xn4)
 {
@@ -934,9 +962,11 @@ __device__ __forceinline__ void quad_backward_step(const QuadRow<T> &q, const T 
     const T hj = emg::mad(xop::mul(upA, nz), x0, xop::mul(xop::mul(upD, nz), xmine));
     const T h4 = emg::mad(up04, x0, xop::mul(up44, x4));
     const T h1 = quad_rot<1>(hj), h2 = quad_rot<2>(hj), h3 = quad_rot<3>(hj);
-    xn = xop::sub(emg::nmad(q.t[4], h4, emg::nmad(q.t[1], h1, emg::nmad(q.t[0], hj, wj))),
-                  emg::mad(q.t[3], h3, xop::mul(q.t[2], h2)));
-    xn4 = xop::sub(emg::nmad(q.t44, h4, w4), quad_sum(xop::mul(q.t[4], hj)));
+    const T t0 = emg::widen(q.t[0]), t1 = emg::widen(q.t[1]), t2 = emg::widen(q.t[2]), t3 = emg::widen(q.t[3]),
+            t4 = emg::widen(q.t[4]), t44 = emg::widen(q.t44);
+    xn = xop::sub(emg::nmad(t4, h4, emg::nmad(t1, h1, emg::nmad(t0, hj, wj))),
+                  emg::mad(t3, h3, xop::mul(t2, h2)));
+    xn4 = xop::sub(emg::nmad(t44, h4, w4), quad_sum(xop::mul(t4, hj)));
     x0 = quad_bcast<0>(xn);
     x4 = xn4;
     xmine = xn;
@@ -1458,22 +1488,25 @@ constexpr int LS_PROD = 384;                 // producer threads of k_line_strea
 
 // forward half-chain that takes its right-hand sides from the LDS ring, for B right-hand sides
 // LFR: the coupling entries come from the coupling ring (lfring), not from the lfac records
-template <class T, int HALF, int RD, int B, bool LFR>
+// FT / WT: storage types of the T records / the w records (T, or emg::compact_of<T>); vec: the w records of the
+// group's first source as WT, source b's b * vstride elements (of WT) behind them
+template <class T, int HALF, int RD, int B, bool LFR, class FT = T, class WT = T>
 __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
-                                                      const T *fac, const double *lfac, T *vec, size_t vstride,
-                                                      const T *ringbase, int lpw, int R, int nchunks,
+                                                      const FT *fac, const double *lfac, WT *vec, size_t vstride,
+                                                      size_t dummy_off, const T *ringbase, int lpw, int R, int nchunks,
                                                       const double *lfring)
 {
     const HalfWalk<HALF> W(n0, n0p);
     const bool active = qline < qend;
     const int line = min(qline, qend - 1);
     const int ll = line - line0;
-    const VecRef<T> V = VecRef<T>::global(vec, nlines);
-    T *const dummy = vec + (vstride - emg::LINE_DUMMY);          // (every source's scratch ends with its dummy slots)
-    T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
-    QuadRow<T> ring[RD];
-    const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
-    auto fetch = [&](QuadRow<T> &q, int i) { q.template load<LaneAddr<T, HALF, false>, false, !LFR>(LA, W.fwd(W.clampi(i))); };
+    const VecRef<WT> V = VecRef<WT>::global(vec, nlines);
+    WT *const dummy = vec + dummy_off;                           // (every source's scratch has its dummy slots)
+    WT *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
+    QuadRow<T, FT> ring[RD];
+    using LAddr = LaneAddr<T, HALF, false, FT, WT>;
+    const LAddr LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T, FT> &q, int i) { q.template load<LAddr, false, !LFR>(LA, W.fwd(W.clampi(i))); };
 #pragma unroll
     for (int d = 0; d < RD; ++d) fetch(ring[d], d);
     __syncthreads();                                          // chunk 0 of the rings and the middle rows are there
@@ -1490,20 +1523,20 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
 #pragma unroll
             for (int d = 0; d < RD; ++d) {
                 const int k = W.fwd(i0 + d);
-                QuadRow<T> &q = ring[d];
+                QuadRow<T, FT> &q = ring[d];
                 const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
                 if constexpr (LFR)
                     q.take_b(lfring + (size_t)(c & 1) * ((size_t)2 * R * lpw * 8) +
                              ((size_t)(HALF * R + (i0 + d - c * R)) * lpw + ll) * 8, j);
-                T *const o4 = active ? LA.pv4(k) : dslot + 4;
-                T *const oj = active ? LA.pvj(k) : dslot + j;
+                WT *const o4 = active ? LA.pv4(k) : dslot + 4;
+                WT *const oj = active ? LA.pvj(k) : dslot + j;
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
                     const T v = it[b * srcelems + j], v4 = it[b * srcelems + 4];
                     T wn, w4;
                     quad_forward_step(q, v, v4, nz, is0, wsel[b], w4p[b], wn, w4);
-                    oj[b * vstride] = wn;
-                    o4[b * vstride] = w4;
+                    oj[b * vstride] = emg::narrow<WT>(wn);
+                    o4[b * vstride] = emg::narrow<WT>(w4);
                 }
                 fetch(ring[d], i0 + d + RD);
             }
@@ -1517,8 +1550,8 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
 // row k - 1 for a mirrored block) -- sixteen lines x 80 B are contiguous in the scratch, so the idle
 // producer waves fetch them as wide coalesced loads and the chain quads need neither a register ring
 // nor four scattered 16-byte loads per step for them.
-template <class T, int DIR>
-__device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n0, int n0p, int line0, int nl, int lpw,
+template <class T, int DIR, class WT = T>
+__device__ __forceinline__ void stream_produce_w(const WT *vec, int nlines, int n0, int n0p, int line0, int nl, int lpw,
                                                  T *buf, int R, int chunk, int pt, int np,
                                                  const emg::Axes<T, DIR> *A = nullptr, int colour = 0, int cntp = 0,
                                                  int cntq = 0, double *lfo = nullptr)
@@ -1531,11 +1564,11 @@ __device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n
         const int ic = max(min(chunk * R + row, steps - 1), 0);
         const int k = min(max(half ? mk + 2 + ic : mk - 1 - ic, half), n0p - 1);     // HalfWalk::bwd
         const int lid = line0 + min(ll, nl - 1);
-        const T *const r0 = vec + ((size_t)k * nlines + lid) * 5;
-        const T *const rt = vec + ((size_t)(half ? k - 1 : k) * nlines + lid) * 5;
-        const T a0 = r0[0], a1 = rt[1], a2 = rt[2], a3 = rt[3], a4 = rt[4];
+        const WT *const r0 = vec + ((size_t)k * nlines + lid) * 5;
+        const WT *const rt = vec + ((size_t)(half ? k - 1 : k) * nlines + lid) * 5;
+        const WT a0 = r0[0], a1 = rt[1], a2 = rt[2], a3 = rt[3], a4 = rt[4];
         T *o = buf + ((size_t)(half * R + row) * lpw + ll) * 5;
-        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+        o[0] = emg::widen(a0); o[1] = emg::widen(a1); o[2] = emg::widen(a2); o[3] = emg::widen(a3); o[4] = emg::widen(a4);
         if (lfo) {
             // the coupling entries of block k from four zeta values (32 B) instead of its lfac record (64 B)
             int i1, i2, l2;
@@ -1551,10 +1584,12 @@ __device__ __forceinline__ void stream_produce_w(const T *vec, int nlines, int n
 
 // backward substitution of one half for B right-hand sides (quad_backward, MIDFIRST form, per source);
 // the w records come from the LDS ring (stream_produce_w)
-template <class T, int DIR, int HALF, int RD, int B, bool PAIR, bool LFR>
+// vec / vstride as in quad_forward_stream (WT); fdummy: dummy store targets of FIELD type for surplus quads and
+// padding blocks (global memory, like the field)
+template <class T, int DIR, int HALF, int RD, int B, bool PAIR, bool LFR, class FT = T, class WT = T>
 __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p, int qline,
-                                                int qend, int line0, int j, const T *fac, const double *lfac, T *vec,
-                                                size_t vstride, size_t boff0, const T *ringbase, int lpw, int R,
+                                                int qend, int line0, int j, const FT *fac, const double *lfac, WT *vec,
+                                                size_t vstride, T *fdummy, size_t boff0, const T *ringbase, int lpw, int R,
                                                 int nchunks, const double *lfring)
 {
     const emg::Axes<T, DIR> A(L, boff0);
@@ -1575,15 +1610,16 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
     T *const e4 = A.E(2) + A.idx(2, dk4, i1, i2);
     const long s4 = (long)A.idx(2, dk4 + 1, i1, i2) - (long)A.idx(2, dk4, i1, i2);
     // dummy store targets: the dummy slots of the group's first scratch (global memory, like the field)
-    T *const dslot = vec + (vstride - emg::LINE_DUMMY) + ((threadIdx.x & 63) >> 2) * 5;
+    T *const dslot = fdummy + ((threadIdx.x & 63) >> 2) * 5;
     T *const dj = dslot + j, *const d4 = dslot + 4;
     const size_t fstep = active ? bs : 0;                     // per-source step of the field pointers
 
-    const VecRef<T> V = VecRef<T>::global(vec, nlines);
-    QuadRow<T> ring[RD];
-    const LaneAddr<T, HALF, false> LA(fac, lfac, nlines, line, j, V);
-    auto fetch = [&](QuadRow<T> &q, int i) {
-        q.template load<LaneAddr<T, HALF, false>, false, !LFR>(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));
+    const VecRef<WT> V = VecRef<WT>::global(vec, nlines);
+    QuadRow<T, FT> ring[RD];
+    using LAddr = LaneAddr<T, HALF, false, FT, WT>;
+    const LAddr LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T, FT> &q, int i) {
+        q.template load<LAddr, false, !LFR>(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));
     };
     // coupling to the middle: B_m (top) / U_{m+1} (bottom)
     QuadRow<T> qm;
@@ -1592,9 +1628,9 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
     const double own0 = j == 0 ? 1.0 : 0.0;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const VecRef<T> Vb = VecRef<T>::global(vec + b * vstride, nlines);
+        const VecRef<WT> Vb = VecRef<WT>::global(vec + b * vstride, nlines);
         T xa, xb;
-        quad_middle<T>(n0, n0p, nlines, line, j, fac, lfac, Vb, xa, xb);
+        quad_middle<T, FT, WT>(n0, n0p, nlines, line, j, fac, lfac, Vb, xa, xb);
         const T xq0 = quad_bcast<0>(xa), xq4 = quad_bcast<0>(xb), xq5 = quad_bcast<1>(xb);
         if (HALF == 0) {
             const int dkm = j == 0 ? 0 : 1;
@@ -1629,7 +1665,7 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
 #pragma unroll
             for (int d = 0; d < RD; ++d) {
                 const int k = W.bwd(i0 + d);
-                QuadRow<T> &q = ring[d];
+                QuadRow<T, FT> &q = ring[d];
                 const T *const it = items + (size_t)(i0 + d - c * R) * lpw * 5;
                 if constexpr (LFR)
                     q.take_b(lfring + (size_t)(c & 1) * ((size_t)2 * R * lpw * 8) +
@@ -1677,13 +1713,24 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
 // LFR: the coupling entries (the 8 reals of a block's lfac record) are recomputed by the producers and handed
 // over through a second ring [2 buffers][2 halves][R][lpw][8] behind the first: 64 B per block less to fetch in
 // the forward pass (the producers hold the zeta values already), 32 B less in the backward pass.
-template <class T, int DIR, int B, int RD, int NPROD, bool PAIR, bool LFR>
-__global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                                    int lpw, int R, const T *fac, const double *lfac,
-                                                                    T *vec, size_t vstride, size_t boff0)
+// COMPACT: the T records (`facv`) and the w records (in the scratch) are stored as emg::compact_of<T> -- single
+// precision, rounded once when the set-up / the forward pass stores them and widened when they are loaded; the
+// right-hand sides, the rings, every operation and the solution stay in T. 120 + 2 x 40 instead of 240 + 2 x 80
+// of the ~1 210 B a block costs per colour pass on the levels that live in HBM.
+template <class T, int DIR, int B, int RD, int NPROD, bool PAIR, bool LFR, bool COMPACT = false>
+__global__ __launch_bounds__(128 + NPROD, NPROD == 128 ? 2 : 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+                                                                    int lpw, int R, const void *facv, const double *lfac,
+                                                                    T *vecT, size_t vstrideT, size_t boff0)
 {
-    // vec: the scratch of the group's first right-hand side (source b's: b * vstride behind it);
+    // vecT: the scratch of the group's first right-hand side (source b's: b * vstrideT elements of T behind it);
     // boff0: element offset of the group's first source in the field / source buffers
+    using FT = typename std::conditional<COMPACT, typename emg::compact_of<T>::type, T>::type;
+    using WT = FT;
+    const FT *const fac = reinterpret_cast<const FT *>(facv);
+    WT *const vec = reinterpret_cast<WT *>(vecT);
+    const size_t vstride = vstrideT * (sizeof(T) / sizeof(WT));          // in elements of WT
+    const size_t dummy_off = vstrideT - emg::LINE_DUMMY;                  // behind a source's records (either type)
+    T *const fdummy = vecT + dummy_off;
     extern __shared__ double2 ls_smem[];
     const int nlines = cntp * cntq;
     const int line0 = blockIdx.x * lpw;
@@ -1703,7 +1750,7 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
             const emg::Axes<T, DIR> A(L, boff0 + b * L.bstride);
-            const VecRef<T> V = VecRef<T>::global(vec + b * vstride, nlines);
+            const VecRef<WT> V = VecRef<WT>::global(vec + b * vstride, nlines);
             for (int ll = pt; ll < nl; ll += NPROD) {
                 const int lid = line0 + ll;
                 int i1, i2, l2;
@@ -1711,9 +1758,9 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
                 T rhs[5];
                 emg::line_rhs<T, DIR>(A, mk, i1, i2, rhs);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) *V.p(mk, lid, r) = rhs[r];
-                *V.p4(mk, lid) = rhs[4];
-                *V.p(mk + 1, lid, 0) = emg::line_rhs_e0<T, DIR>(A, min(mk + 1, n0 - 1), i1, i2);
+                for (int r = 0; r < 4; ++r) *V.p(mk, lid, r) = emg::narrow<WT>(rhs[r]);
+                *V.p4(mk, lid) = emg::narrow<WT>(rhs[4]);
+                *V.p(mk + 1, lid, 0) = emg::narrow<WT>(emg::line_rhs_e0<T, DIR>(A, min(mk + 1, n0 - 1), i1, i2));
             }
             stream_produce<T, DIR>(A, colour, cntp, cntq, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD,
                                    (LFR && b == 0) ? lfring : nullptr);
@@ -1735,17 +1782,17 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
         const emg::Axes<T, DIR> A0(L, boff0);
 #pragma unroll 1
         for (int b = 0; b < B; ++b)
-            stream_produce_w<T, DIR>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD,
-                                     &A0, colour, cntp, cntq, (LFR && b == 0) ? lfring : nullptr);
+            stream_produce_w<T, DIR, WT>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD,
+                                         &A0, colour, cntp, cntq, (LFR && b == 0) ? lfring : nullptr);
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
             if (c + 1 < nchunks) {
 #pragma unroll 1
                 for (int b = 0; b < B; ++b)
-                    stream_produce_w<T, DIR>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
-                                             ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD,
-                                             &A0, colour, cntp, cntq,
-                                             (LFR && b == 0) ? lfring + (size_t)((c + 1) & 1) * lfelems : nullptr);
+                    stream_produce_w<T, DIR, WT>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
+                                                 ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD,
+                                                 &A0, colour, cntp, cntq,
+                                                 (LFR && b == 0) ? lfring + (size_t)((c + 1) & 1) * lfelems : nullptr);
             }
             lds_barrier();
         }
@@ -1754,11 +1801,11 @@ __global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L,
     const int half = wave & 1;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
-    if (half == 0) quad_forward_stream<T, 0, RD, B, LFR>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks, lfring);
-    else quad_forward_stream<T, 1, RD, B, LFR>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, ringbase, lpw, R, nchunks, lfring);
+    if (half == 0) quad_forward_stream<T, 0, RD, B, LFR, FT, WT>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, dummy_off, ringbase, lpw, R, nchunks, lfring);
+    else quad_forward_stream<T, 1, RD, B, LFR, FT, WT>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, dummy_off, ringbase, lpw, R, nchunks, lfring);
     __syncthreads();
-    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR, LFR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks, lfring);
-    else quad_backward_stream<T, DIR, 1, RD, B, PAIR, LFR>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, boff0, ringbase, lpw, R, nchunks, lfring);
+    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR, LFR, FT, WT>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, fdummy, boff0, ringbase, lpw, R, nchunks, lfring);
+    else quad_backward_stream<T, DIR, 1, RD, B, PAIR, LFR, FT, WT>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, fdummy, boff0, ringbase, lpw, R, nchunks, lfring);
 }
 
 #pragma clang fp contract(fast)      // (end of the spelled-out section: the compiler's default again)
@@ -1973,14 +2020,32 @@ inline bool line_wide_used(int dir, int nx, int ny, int nz)
     return g_line_wide > 0 && emg::line_n0(dir, nx, ny, nz) <= g_line_wide && emg::line_nfac_elems(dir, nx, ny, nz) > 0;
 }
 
+// Does direction `dir` of this level keep COMPACT line factors (k_line_stream<.., COMPACT>)? The level asks for it
+// (emg3d_level::flags, or option line_compact = 1), and every colour class of the direction runs the streamed kernel
+// for one source -- the set-up (which stores the T records in that form), the size query and the launcher all decide
+// with this one function of the level and the options.
+template <class T> bool line_compact_used(const emg::Level<T> &L, int dir)
+{
+    if (g_line_compact < 0 || !(g_line_compact > 0 || (L.flags & emg::LEVEL_LINE_COMPACT))) return false;
+    if (L.batch > 1 || line_wide_used(dir, L.nx, L.ny, L.nz)) return false;
+    bool any = false;
+    for (int c = 0; c < 4; ++c) {
+        const emg::LineClass lc = emg::line_class(dir, L.nx, L.ny, L.nz, c);
+        if (lc.lines <= 0) continue;
+        if (line_plan<T>(lc, L.batch).kind != LK_STREAM) return false;
+        any = true;
+    }
+    return any;
+}
+
 template <class T, int DIR, int B>
-void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const T *f, const double *lf, T *vec,
-                         size_t vstride, int b0, int lpw, hipStream_t st)
+void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc, const void *f, const double *lf, T *vec,
+                         size_t vstride, int b0, int lpw, hipStream_t st, bool compact = false)
 {
     // one source: the coupling entries through a second ring (option line_stream_lf, default 1)
     // (for groups of two the second ring leaves room for 8 rows per chunk only: y / z lines 0.83 -> 0.79-0.82 x per
     // source, x-lines 0.82 -> 0.93 x -- measured, not adopted)
-    const bool lfr = B == 1 && g_line_stream_lf != 0;
+    const bool lfr = B == 1 && (g_line_stream_lf != 0 || compact);
     int R = stream_rows(B, sizeof(T), lfr);
     const size_t smem = (size_t)2 * B * 2 * R * lpw * 5 * sizeof(T) + (lfr ? (size_t)2 * 2 * R * lpw * 8 * sizeof(double) : 0);
     // one source: four producer waves and unpaired stores (in a config-3 cycle six waves / paired x-line stores
@@ -1989,13 +2054,32 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
     constexpr int NPROD = B >= 2 ? LS_PROD : 256;
     const void *kern = lfr ? (const void *)&k_line_stream<T, DIR, B, RD, NPROD, (B >= 2), (B == 1)>
                            : (const void *)&k_line_stream<T, DIR, B, RD, NPROD, (B >= 2), false>;
+    int nprod = NPROD;
+    size_t smem_c = smem;
+    if constexpr (B == 1) {
+        const bool rd8 = g_line_compact_rd == 8 || (g_line_compact_rd == 0 && DIR == 0);
+        if (compact) kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, NPROD, false, true, true>
+                                : (const void *)&k_line_stream<T, DIR, 1, RD, NPROD, false, true, true>;
+        if (compact && g_line_compact_np == 384) {
+            kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, 384, false, true, true>
+                       : (const void *)&k_line_stream<T, DIR, 1, RD, 384, false, true, true>;
+            nprod = 384;
+        }
+        if (compact && g_line_compact_occ == 2) {
+            kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, 128, false, true, true>
+                       : (const void *)&k_line_stream<T, DIR, 1, RD, 128, false, true, true>;
+            nprod = 128;
+            R = R > 8 ? 8 : R;
+            smem_c = (size_t)2 * 2 * R * lpw * 5 * sizeof(T) + (size_t)2 * 2 * R * lpw * 8 * sizeof(double);
+        }
+    }
     (void)allow_lds(kern, 160 * 1024);
     T *v0 = vec + (size_t)b0 * vstride;
     size_t boff0 = (size_t)b0 * L.bstride;
     const unsigned nwg = cdiv(lc.lines, lpw);
     void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
                     (void *)&f, (void *)&lf, (void *)&v0, (void *)&vstride, (void *)&boff0};
-    (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + NPROD), args, smem, st);
+    (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + nprod), args, smem_c, st);
 }
 
 template <class T, int DIR>
@@ -2007,6 +2091,10 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
     const dim3 bgp = d3(emg::lineblk_grid(lc, true));
     const T *f = fac + lc.fac_off;
     const double *lf = lfac + lc.lfac_off;
+    // compact T records (line_compact_used): the class offset counts records, whatever their element type
+    using FT = typename emg::compact_of<T>::type;
+    const bool compact = line_compact_used<T>(L, DIR);
+    const void *fv = compact ? (const void *)(reinterpret_cast<const FT *>(fac) + lc.fac_off) : (const void *)f;
     const dim3 qb = d3(emg::linequad_block());
     const emg::Dim3 q1 = emg::linequad_grid(lc);
     const dim3 qg2(q1.x, 2, 1);                      // x: 16 lines per wave, y: top / bottom half
@@ -2031,10 +2119,10 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         int b0 = 0;
         for (int g = 0; g < ng; ++g) {
             const int gs = L.batch / ng + (g < L.batch % ng ? 1 : 0);
-            if (gs == 4) launch_stream_group<T, DIR, 4>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
-            else if (gs == 3) launch_stream_group<T, DIR, 3>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
-            else if (gs == 2) launch_stream_group<T, DIR, 2>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
-            else launch_stream_group<T, DIR, 1>(L, c, lc, f, lf, vec, vstride, b0, P.lpw, st);
+            if (gs == 4) launch_stream_group<T, DIR, 4>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st);
+            else if (gs == 3) launch_stream_group<T, DIR, 3>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st);
+            else if (gs == 2) launch_stream_group<T, DIR, 2>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st);
+            else launch_stream_group<T, DIR, 1>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st, compact);
             b0 += gs;
         }
         return;
@@ -2219,6 +2307,13 @@ void launch_line_setup_dir(const emg::Level<T> &L, T *fac, double *lfac, hipStre
             gx = g.x > gx ? g.x : gx; gy = g.y > gy ? g.y : gy;
         }
     }
+    if (line_compact_used<T>(L, DIR)) {
+        // the T records in compact form (single precision, rounded as they are stored); no N records on such levels
+        using FT = typename emg::compact_of<T>::type;
+        if (gx > 0 && gy > 0)
+            hipLaunchKernelGGL((k_line_setup<T, DIR, FT>), dim3(gx, gy, 4), dim3(128), 0, st, L, S, reinterpret_cast<FT *>(fac), lfac);
+        return;
+    }
     if (gx > 0 && gy > 0) hipLaunchKernelGGL((k_line_setup<T, DIR>), dim3(gx, gy, 4), dim3(128), 0, st, L, S, fac, lfac);
     // the N records of the wide form, behind the T records (one per block record, from its T and coupling entries)
     const size_t nrec = emg::line_records(DIR, L.nx, L.ny, L.nz);
@@ -2390,8 +2485,9 @@ static const OptionEntry g_options[] = {
     {"line_debug", &g_line_debug},       {"line_stream", &g_line_stream},       {"line_stream_r", &g_line_stream_r},
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
-    {"line_wide", &g_line_wide},         {"line_wide_bt", &g_line_wide_bt},
-   
+    {"line_wide", &g_line_wide},         {"line_wide_bt", &g_line_wide_bt},     {"line_compact", &g_line_compact},
+    {"line_compact_rd", &g_line_compact_rd}, {"line_compact_occ", &g_line_compact_occ},
+    {"line_compact_np", &g_line_compact_np},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value
@@ -2413,6 +2509,8 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "line_stream_r") && value != 0 && (value < 4 || value > 32 || value % emg::LINE_PAD != 0))
         return fail(EMG3D_ERR_BADARG, "line_stream_r: 0 (= 16) or a multiple of 4 in 4..32");
     if (!std::strcmp(name, "line_wide_bt") && value != 0 && value != 192 && value != 256) return fail(EMG3D_ERR_BADARG, "line_wide_bt: 0, 192 or 256");
+    if (!std::strcmp(name, "line_compact_rd") && value != 0 && value != 4 && value != 8) return fail(EMG3D_ERR_BADARG, "line_compact_rd: 0, 4 or 8");
+    if (!std::strcmp(name, "line_compact") && (value < -1 || value > 1)) return fail(EMG3D_ERR_BADARG, "line_compact: -1, 0 or 1");
     if (!std::strcmp(name, "line_order") && (value < 0 || value > 2)) return fail(EMG3D_ERR_BADARG, "line_order: 0, 1 or 2");
     if (!std::strcmp(name, "point_order") && (value < 0 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_order: 0 or 1");
     for (const OptionEntry &o : g_options)
@@ -2473,6 +2571,22 @@ size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex)
 {
     if (lr < 1 || lr > 3) return 0;
     return (emg::line_fac_elems(lr - 1, nx, ny, nz) + emg::line_nfac_elems(lr - 1, nx, ny, nz)) * (is_complex ? 16 : 8);
+}
+
+size_t emg3d_line_fac_bytes_lv(const emg3d_level *lv, int lr)
+{
+    if (!lv || lr < 1 || lr > 3) return 0;
+    const bool compact = lv->is_complex ? line_compact_used<cplx>(to_level<cplx>(lv), lr - 1)
+                                        : line_compact_used<double>(to_level<double>(lv), lr - 1);
+    if (compact) return emg::line_fac_elems(lr - 1, lv->nx, lv->ny, lv->nz) * (lv->is_complex ? 8 : 4);
+    return emg3d_line_fac_bytes(lr, lv->nx, lv->ny, lv->nz, lv->is_complex);
+}
+
+int emg3d_line_compact_used(const emg3d_level *lv, int lr)
+{
+    if (!lv || lr < 1 || lr > 3) return 0;
+    return lv->is_complex ? (int)line_compact_used<cplx>(to_level<cplx>(lv), lr - 1)
+                          : (int)line_compact_used<double>(to_level<double>(lv), lr - 1);
 }
 
 size_t emg3d_line_lfac_bytes(int lr, int nx, int ny, int nz)

@@ -631,13 +631,13 @@ EMG_HD bool line_of_thread(int colour, int cntp, int cntq, int tp, int tq, int &
     return true;
 }
 
-template <class T, int DIR>
-EMG_HD void line_setup_thread(const Level<T> &L, int colour, int cntp, int cntq, int tp, int tq, T *fac,
+template <class T, int DIR, class FT = T>
+EMG_HD void line_setup_thread(const Level<T> &L, int colour, int cntp, int cntq, int tp, int tq, FT *fac,
                               double *lfac)
 {
     int i1, i2, lid;
     if (!line_of_thread<DIR>(colour, cntp, cntq, tp, tq, i1, i2, lid)) return;
-    line_setup<T, DIR>(L, i1, i2, fac, lfac, cntp * cntq, lid, line_padded(Axes<T, DIR>(L).n0()));
+    line_setup<T, DIR, FT>(L, i1, i2, fac, lfac, cntp * cntq, lid, line_padded(Axes<T, DIR>(L).n0()));
 }
 
 template <class T, int DIR>

@@ -38,6 +38,10 @@ template <class T> struct Level {
 // all eta values have a real part of exactly zero (diffusive approximation at a real
 // frequency: eta = -i omega mu0 sigma V): the eta edge sums are then stored as 8-byte doubles
 constexpr int LEVEL_ETA_IMAG = 1;
+// the level solves a CORRECTION equation (its right-hand side is a residual, its result is added to a field that is
+// kept in full precision elsewhere): the streamed line passes may keep their T and w records in single precision
+// (kernels.hip: line_compact_used, k_line_stream<.., COMPACT>)
+constexpr int LEVEL_LINE_COMPACT = 2;
 template <class T> EMG_HD Level<T> source_level(Level<T> L, int b)
 {
     size_t o = (size_t)b * L.bstride;
@@ -1194,15 +1198,17 @@ EMG_HD void line_matrix_mirrored(const Axes<T, DIR> &A, int k, int i1, int i2, T
 // and direction. The two chains are independent (line_setup_top / line_setup_bottom: the HIP
 // kernel runs them in two waves) and meet in line_setup_middle, which needs the LDL^T
 // factors (C, dinv) of the last block of either chain.
-template <class T> struct LineStore {
-    T *fac;
+// FT: the storage type of the T records -- T itself, or compact_of<T> (cplx.h: rounded to single precision when
+// stored, "compact line factors"); the factorisation itself is carried in T whatever the storage
+template <class T, class FT = T> struct LineStore {
+    FT *fac;
     double *lfac;
     int nlines, lid;
     EMG_HD void put_T(int k, const T (&Tp)[15]) const
     {
-        T *f = fac + ((size_t)k * nlines + lid) * 15;
+        FT *f = fac + ((size_t)k * nlines + lid) * 15;
 #pragma unroll
-        for (int j = 0; j < 15; ++j) f[j] = Tp[j];
+        for (int j = 0; j < 15; ++j) f[j] = narrow<FT>(Tp[j]);
     }
     EMG_HD void put_B(int k, const double (&b0)[5], const double (&bd)[5], bool any) const
     {
@@ -1225,8 +1231,8 @@ template <class T> EMG_HD void std_block(const T (&dg)[5], const double (&mid)[5
 }
 
 // top chain: standard blocks k = 0 .. m-1; (C, dinv) = factors of S_{m-1} (untouched if m = 0)
-template <class T, int DIR>
-EMG_HD void line_setup_top(const Level<T> &L, int i1, int i2, const LineStore<T> &st, T (&C)[10], T (&dinv)[5])
+template <class T, int DIR, class FT = T>
+EMG_HD void line_setup_top(const Level<T> &L, int i1, int i2, const LineStore<T, FT> &st, T (&C)[10], T (&dinv)[5])
 {
     const Axes<T, DIR> A(L);
     const int mk = line_mid(A.n0());
@@ -1246,8 +1252,8 @@ EMG_HD void line_setup_top(const Level<T> &L, int i1, int i2, const LineStore<T>
 }
 // bottom chain: mirrored blocks k = n0-1 .. m+2; (Cb, db) = factors of S_{m+2} (untouched if
 // the chain is empty); also writes the identity padding blocks behind block n0-1
-template <class T, int DIR>
-EMG_HD void line_setup_bottom(const Level<T> &L, int i1, int i2, const LineStore<T> &st, int n0p, T (&Cb)[10],
+template <class T, int DIR, class FT = T>
+EMG_HD void line_setup_bottom(const Level<T> &L, int i1, int i2, const LineStore<T, FT> &st, int n0p, T (&Cb)[10],
                               T (&db)[5])
 {
     const Axes<T, DIR> A(L);
@@ -1265,16 +1271,16 @@ EMG_HD void line_setup_bottom(const Level<T> &L, int i1, int i2, const LineStore
         st.put_B(k, u0, ud, true);
     }
     for (int k = n0; k < n0p; ++k) {
-        T *f = st.fac + ((size_t)k * st.nlines + st.lid) * 15;
+        FT *f = st.fac + ((size_t)k * st.nlines + st.lid) * 15;
         double *lf = st.lfac + ((size_t)k * st.nlines + st.lid) * 8;
         for (int r = 0; r < 5; ++r)
-            for (int m = 0; m <= r; ++m) f[tri(r + 1, m)] = (r == m) ? T(1.0) : zero<T>();
+            for (int m = 0; m <= r; ++m) f[tri(r + 1, m)] = narrow<FT>((r == m) ? T(1.0) : zero<T>());
         for (int j = 0; j < 8; ++j) lf[j] = 0.0;
     }
 }
 // middle block Q = {E0(m), t(m+1), E0(m+1)}
-template <class T, int DIR>
-EMG_HD void line_setup_middle(const Level<T> &L, int i1, int i2, const LineStore<T> &st, const T (&C)[10],
+template <class T, int DIR, class FT = T>
+EMG_HD void line_setup_middle(const Level<T> &L, int i1, int i2, const LineStore<T, FT> &st, const T (&C)[10],
                               const T (&dinv)[5], const T (&Cb)[10], const T (&db)[5])
 {
     const Axes<T, DIR> A(L);
@@ -1320,28 +1326,28 @@ EMG_HD void line_setup_middle(const Level<T> &L, int i1, int i2, const LineStore
     }
     T Tq[21];
     invert6<T>(SQ, Tq);
-    T *f = st.fac + ((size_t)mk * st.nlines + st.lid) * 15;
-    T *g = st.fac + ((size_t)(mk + 1) * st.nlines + st.lid) * 15;
+    FT *f = st.fac + ((size_t)mk * st.nlines + st.lid) * 15;
+    FT *g = st.fac + ((size_t)(mk + 1) * st.nlines + st.lid) * 15;
 #pragma unroll
-    for (int j = 0; j < 15; ++j) f[j] = Tq[j];
+    for (int j = 0; j < 15; ++j) f[j] = narrow<FT>(Tq[j]);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) g[j] = Tq[15 + j];
+    for (int j = 0; j < 6; ++j) g[j] = narrow<FT>(Tq[15 + j]);
 #pragma unroll
-    for (int j = 6; j < 15; ++j) g[j] = zero<T>();
+    for (int j = 6; j < 15; ++j) g[j] = narrow<FT>(zero<T>());
 }
 // all of it by one thread (CPU emulation of the unit tests)
-template <class T, int DIR>
-EMG_HD void line_setup(const Level<T> &L, int i1, int i2, T *fac, double *lfac, int nlines, int lid, int n0p)
+template <class T, int DIR, class FT = T>
+EMG_HD void line_setup(const Level<T> &L, int i1, int i2, FT *fac, double *lfac, int nlines, int lid, int n0p)
 {
-    const LineStore<T> st{fac, lfac, nlines, lid};
+    const LineStore<T, FT> st{fac, lfac, nlines, lid};
     T C[10], dinv[5], Cb[10], db[5];
 #pragma unroll
     for (int j = 0; j < 10; ++j) C[j] = Cb[j] = zero<T>();
 #pragma unroll
     for (int j = 0; j < 5; ++j) dinv[j] = db[j] = T(1.0);
-    line_setup_top<T, DIR>(L, i1, i2, st, C, dinv);
-    line_setup_bottom<T, DIR>(L, i1, i2, st, n0p, Cb, db);
-    line_setup_middle<T, DIR>(L, i1, i2, st, C, dinv, Cb, db);
+    line_setup_top<T, DIR, FT>(L, i1, i2, st, C, dinv);
+    line_setup_bottom<T, DIR, FT>(L, i1, i2, st, n0p, Cb, db);
+    line_setup_middle<T, DIR, FT>(L, i1, i2, st, C, dinv, Cb, db);
 }
 
 // q = B y  /  q = B^T y  for B = e0 l0^T + diag(0, ld)
@@ -1374,24 +1380,38 @@ template <class T> EMG_HD void sym_matvec(const T (&Tk)[15], const T (&z)[5], T 
 // Reference walks of one line (one thread per line): used by the CPU emulation of the unit
 // tests and as the specification of what the quad kernels in kernels.hip compute.
 // vec slots of a block: standard block k -> (k,0..4); mirrored block k -> (k,0), (k-1,1..4).
-template <class T> struct LineRef {
+// FT / WT: storage types of the T records / of the w records (T, or compact_of<T>: the compact form, in which the
+// forward pass reads its right-hand sides from `rhs` (T) and stores w rounded to WT, and the backward pass writes
+// the solution, which never exists in WT, to `xout` (T). Plain form: rhs = xout = vec.)
+template <class T, class FT = T, class WT = T> struct LineRef {
     int nlines, lid;
-    const T *fac;
+    const FT *fac;
     const double *lfac;
-    T *vec;
+    WT *vec;
+    const T *rhs;
+    T *xout;
     EMG_HD size_t rec(int k) const { return (size_t)k * nlines + lid; }
-    EMG_HD T &slot(int k, int r, bool mirrored) const { return vec[rec(mirrored && r > 0 ? k - 1 : k) * 5 + r]; }
+    EMG_HD size_t at(int k, int r, bool mirrored) const { return rec(mirrored && r > 0 ? k - 1 : k) * 5 + r; }
+    EMG_HD T slot(int k, int r, bool mirrored) const { return widen(vec[at(k, r, mirrored)]); }
     EMG_HD void get(int k, bool mirrored, T (&v)[5]) const
     {
         for (int r = 0; r < 5; ++r) v[r] = slot(k, r, mirrored);
     }
+    EMG_HD void get_rhs(int k, bool mirrored, T (&v)[5]) const
+    {
+        for (int r = 0; r < 5; ++r) v[r] = rhs[at(k, r, mirrored)];
+    }
     EMG_HD void put(int k, bool mirrored, const T (&v)[5]) const
     {
-        for (int r = 0; r < 5; ++r) slot(k, r, mirrored) = v[r];
+        for (int r = 0; r < 5; ++r) vec[at(k, r, mirrored)] = narrow<WT>(v[r]);
+    }
+    EMG_HD void put_x(int k, bool mirrored, const T (&v)[5]) const
+    {
+        for (int r = 0; r < 5; ++r) xout[at(k, r, mirrored)] = v[r];
     }
     EMG_HD void T15(int k, T (&Tk)[15]) const
     {
-        for (int j = 0; j < 15; ++j) Tk[j] = fac[rec(k) * 15 + j];
+        for (int j = 0; j < 15; ++j) Tk[j] = widen(fac[rec(k) * 15 + j]);
     }
     EMG_HD void B(int k, double (&l0)[4], double (&ld)[4]) const
     {
@@ -1399,10 +1419,12 @@ template <class T> struct LineRef {
     }
 };
 // forward: both half-chains; n0 = real blocks, n0p = padded records
-template <class T>
-EMG_HD void line_forward_ref(int n0, int n0p, int nlines, int lid, const T *fac, const double *lfac, T *vec)
+template <class T, class FT = T, class WT = T>
+EMG_HD void line_forward_ref(int n0, int n0p, int nlines, int lid, const FT *fac, const double *lfac, WT *vec,
+                             const T *rhs = nullptr)
 {
-    const LineRef<T> R{nlines, lid, fac, lfac, vec};
+    // (rhs == nullptr: the plain form, right-hand sides and w records in one buffer -- FT = WT = T)
+    const LineRef<T, FT, WT> R{nlines, lid, fac, lfac, vec, rhs ? rhs : reinterpret_cast<const T *>(vec), nullptr};
     const int mk = line_mid(n0);
     T w[5], q[5], z[5], v[5], Tk[15];
     double l0[4], ld[4];
@@ -1412,7 +1434,7 @@ EMG_HD void line_forward_ref(int n0, int n0p, int nlines, int lid, const T *fac,
         // top: k = 0 .. m-1 (w_k = T_k (r_k - B_k w_{k-1})); bottom: k = n0p-1 .. m+2 with U_k
         for (int i = 0; i < (mir ? n0p - 2 - mk : mk); ++i) {
             const int k = mir ? n0p - 1 - i : i;
-            R.T15(k, Tk); R.B(k, l0, ld); R.get(k, mir, v);
+            R.T15(k, Tk); R.B(k, l0, ld); R.get_rhs(k, mir, v);
             couple_lower<T>(l0, ld, w, q);
             for (int r = 0; r < 5; ++r) z[r] = v[r] - q[r];
             sym_matvec<T>(Tk, z, w);
@@ -1421,11 +1443,11 @@ EMG_HD void line_forward_ref(int n0, int n0p, int nlines, int lid, const T *fac,
     }
 }
 // middle: x_Q = T_Q (r_Q - [B_m w_{m-1}] - [U_{m+1} w_{m+2}]), Q = {E0(m), t(m+1), E0(m+1)}
-template <class T>
-EMG_HD void line_middle(int n0, int n0p, int nlines, int lid, const T *fac, const double *lfac, T *vec,
+template <class T, class FT = T, class WT = T>
+EMG_HD void line_middle(int n0, int n0p, int nlines, int lid, const FT *fac, const double *lfac, WT *vec,
                         T (&xq)[6])
 {
-    const LineRef<T> R{nlines, lid, fac, lfac, vec};
+    const LineRef<T, FT, WT> R{nlines, lid, fac, lfac, vec, nullptr, nullptr};
     const int mk = line_mid(n0);
     T z[6], q[5], y[5];
     double l0[4], ld[4];
@@ -1443,22 +1465,24 @@ EMG_HD void line_middle(int n0, int n0p, int nlines, int lid, const T *fac, cons
         for (int r = 1; r < 5; ++r) z[r] -= q[r];
     }
     T Tq[21];
-    for (int j = 0; j < 15; ++j) Tq[j] = fac[R.rec(mk) * 15 + j];
-    for (int j = 0; j < 6; ++j) Tq[15 + j] = fac[R.rec(mk + 1) * 15 + j];
+    for (int j = 0; j < 15; ++j) Tq[j] = widen(fac[R.rec(mk) * 15 + j]);
+    for (int j = 0; j < 6; ++j) Tq[15 + j] = widen(fac[R.rec(mk + 1) * 15 + j]);
     for (int r = 0; r < 6; ++r) {
         T acc = zero<T>();
         for (int m = 0; m < 6; ++m) acc += Tq[sym(r, m)] * z[m];
         xq[r] = acc;
     }
 }
-template <class T>
-EMG_HD void line_backward_ref(int n0, int n0p, int nlines, int lid, const T *fac, const double *lfac, T *vec)
+template <class T, class FT = T, class WT = T>
+EMG_HD void line_backward_ref(int n0, int n0p, int nlines, int lid, const FT *fac, const double *lfac, WT *vec,
+                              T *xout = nullptr)
 {
-    const LineRef<T> R{nlines, lid, fac, lfac, vec};
+    // (xout == nullptr: the plain form, the solution overwrites the w records -- FT = WT = T)
+    const LineRef<T, FT, WT> R{nlines, lid, fac, lfac, vec, nullptr, xout ? xout : reinterpret_cast<T *>(vec)};
     const int mk = line_mid(n0);
     T xq[6], x[5], q[5], tq[5], v[5], Tk[15];
     double l0[4], ld[4];
-    line_middle<T>(n0, n0p, nlines, lid, fac, lfac, vec, xq);
+    line_middle<T, FT, WT>(n0, n0p, nlines, lid, fac, lfac, vec, xq);
     for (int half = 0; half < 2; ++half) {
         const bool mir = half == 1;
         // the part of x_Q the half couples to: standard block m / mirrored block m+1
@@ -1471,12 +1495,12 @@ EMG_HD void line_backward_ref(int n0, int n0p, int nlines, int lid, const T *fac
             couple_upper<T>(l0, ld, x, q);
             sym_matvec<T>(Tk, q, tq);
             for (int r = 0; r < 5; ++r) x[r] = v[r] - tq[r];
-            R.put(k, mir, x);
+            R.put_x(k, mir, x);
             kprev = k;
         }
     }
-    for (int r = 0; r < 5; ++r) R.slot(mk, r, false) = xq[r];
-    R.slot(mk + 1, 0, false) = xq[5];
+    for (int r = 0; r < 5; ++r) R.xout[R.at(mk, r, false)] = xq[r];
+    R.xout[R.at(mk + 1, 0, false)] = xq[5];
 }
 
 // Scatter block k of the solution into the field (core.py:775-783).

@@ -529,11 +529,51 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+# largest block condition estimate under which 'auto' stores the streamed line records in single precision:
+# eps32 x 1e5 = 6e-3 relative perturbation of a line solve (tools/compact_cycles.py: cycle counts unchanged up to
+# there; an air layer of 1e8 Ohm m is 1e10 and keeps fp64 records)
+COMPACT_COND_MAX = 1e5
+
+
+def block_condition(vmodel):
+    """Estimate of the condition of the line smoothers' 5 x 5 blocks, 1 / (|s| mu0 sigma_min h_min^2): the ratio of
+    the curl-curl part to the conduction part of a block in the most resistive cell if it had the smallest width
+    (cheap on purpose, like ``_residual_form``: two reductions per property array)."""
+    hmin = min(float(np.min(h)) for h in vmodel.grid.h)
+    model = getattr(vmodel, '_model', None)
+    with np.errstate(divide='ignore', over='ignore', invalid='ignore'):
+        if model is not None:
+            sig = np.inf
+            for name in ('property_x', 'property_y', 'property_z'):
+                prop = getattr(model, name)
+                if prop is not None:
+                    ends = models._MAPS[model.mapping](np.array([np.min(prop), np.max(prop)], dtype=float))
+                    sig = min(sig, float(np.min(ends)))
+            smu_sig = abs(complex(vmodel._sval)) * fields.MU_0 * sig
+        else:
+            # eta / zeta holders (tests, tools): |eta| / V = |s| mu0 sigma
+            vol = np.asarray(vmodel.grid.cell_volumes).reshape(vmodel.grid.shape_cells, order='F')
+            smu_sig = min(float(np.min(np.abs(np.asarray(e)) / vol)) for e in (vmodel.eta_x, vmodel.eta_y, vmodel.eta_z))
+        cond = 1.0 / (smu_sig * hmin ** 2)
+    return float(cond) if np.isfinite(cond) else np.inf
+
+
 class Hierarchy:
     """Level 0 on the device for one (model, frequency): upload once, cycle many times."""
 
-    def __init__(self, vmodel, device=None, batch=1, line_factors=None):
-        """line_factors: 'resident' (default; or the environment's EMG3D_AMD_LINE_FACTORS) keeps the line
+    def __init__(self, vmodel, device=None, batch=1, line_factors=None, line_compact=None):
+        """line_compact: True / False / 'auto' (default; or the environment's EMG3D_AMD_LINE_COMPACT) -- COMPACT line
+        records: on the levels whose line passes stream their records through HBM (lines of ~128 blocks and more) the
+        inverse blocks of the stored line factorisation and the forward pass's w records are kept in single precision
+        (all arithmetic, right-hand sides and solutions stay fp64): 890 instead of 1 210 B per block and colour pass,
+        184 instead of 304 B of factor memory per cell and direction. The line solve is then a PERTURBED smoother
+        (relative eps32 x cond of the 5 x 5 blocks), so every level must solve a correction equation: the coarse levels
+        always do, the finest runs in residual form (``_cycle.run_cycles`` does that by itself on such a hierarchy; as
+        a Krylov preconditioner it is in that form anyway). 'auto': where the block condition estimate
+        1 / (|s| mu0 sigma_min h_min^2) is at most ``COMPACT_COND_MAX`` and batch == 1. Same converged field, same
+        cycle counts (tools/compact_cycles.py, tests).
+
+        line_factors: 'resident' (default; or the environment's EMG3D_AMD_LINE_FACTORS) keeps the line
         factorisation of every direction a level has used in HBM -- 304 B per cell and direction, ~2.0 kB per
         finest-level cell for a whole semicoarsened hierarchy with three directions; 'rebuild' keeps two directions
         per level and re-factorises on change (``DeviceLevel._line_factor_slots``): ~1.7 kB per cell, one more
@@ -545,6 +585,16 @@ class Hierarchy:
         self.top = DeviceLevel.from_host(vmodel, self.device, batch=batch, line_factors=line_factors)
         self.shape = tuple(vmodel.grid.shape_cells)
         self.sval = complex(vmodel._sval)
+        if line_compact is None:
+            line_compact = os.environ.get('EMG3D_AMD_LINE_COMPACT', 'auto')
+            line_compact = {'0': False, 'false': False, '1': True, 'true': True}.get(str(line_compact).lower(), 'auto')
+        if line_compact not in (True, False, 'auto'):
+            raise ValueError(f"`line_compact` must be True, False or 'auto'. Provided: {line_compact!r}.")
+        if line_compact == 'auto':
+            line_compact = batch == 1 and block_condition(vmodel) <= COMPACT_COND_MAX
+        self.line_compact = bool(line_compact)
+        if self.line_compact:
+            self.top.set_line_compact(True)
 
     def check(self, vmodel):
         """A hierarchy handed to ``solve`` must belong to the same grid shape and frequency

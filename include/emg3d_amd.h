@@ -95,6 +95,19 @@ typedef struct emg3d_level {
  * values (half the bytes, identical results). Never required; a caller that does not know
  * leaves it 0 or asks emg3d_dev_eta_is_imaginary. */
 #define EMG3D_LEVEL_ETA_IMAG 1
+/* LINE_COMPACT: the caller's promise that this level solves a CORRECTION equation -- its right-hand side is a
+ * residual and its result is added to a field kept in full precision elsewhere (every coarse level of a cycle;
+ * the finest level in residual form or as a Krylov preconditioner). The line passes that stream their records
+ * through HBM (k_line_stream: lines of ~128 blocks and more) may then keep the inverse blocks T_k of the stored
+ * factorisation and the forward pass's w records in SINGLE precision: values are rounded once when they are stored
+ * and widened when they are loaded, every operation, every right-hand side and the solution stay fp64. The line
+ * solve becomes (A_line (1 + O(eps32 cond(S_k))))^-1 -- a perturbation of the smoother, not of the equation: the
+ * iteration converges to the same field at the same rate as long as eps32 x cond of the 5 x 5 blocks (~ 1 / (omega mu
+ * sigma h^2)) stays well below the smoothing factor, which is the caller's to check (emg3d_amd.solver: cond <= 1e5).
+ * What it buys: 120 + 2 x 40 instead of 240 + 2 x 80 B per block and colour pass of the ~1 210 B such a pass moves,
+ * and 184 instead of 304 B per cell and direction of factor memory. Set it BEFORE emg3d_dev_line_setup and keep it:
+ * set-up, emg3d_line_fac_bytes_lv and the smoother read it from the level. Unset (0): everything fp64. */
+#define EMG3D_LEVEL_LINE_COMPACT 2
 
 int emg3d_version(void);
 const char *emg3d_last_error(void);
@@ -136,6 +149,9 @@ int emg3d_device_count(void);
  * right-hand side, alone or in a batch, so batched and separate solves stay bit-identical under any value.
  * "line_order" and "point_order" DO select the order of the sweeps (see above), like
  * "point_tile_min".
+ * "line_compact": 0 (default) compact line records where the level asks for them (EMG3D_LEVEL_LINE_COMPACT), 1 on
+ * every level whose direction streams (tests, timing), -1 never (the flag is ignored). CHANGES the rounding of the
+ * streamed line solves (see EMG3D_LEVEL_LINE_COMPACT).
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
  * results); a non-zero value is refused unless the environment variable EMG3D_AMD_ALLOW_DEBUG is set.
  * Out-of-range values of "line_order" (0..2) and "point_order" (0..1) are refused (EMG3D_ERR_BADARG). */
@@ -206,6 +222,10 @@ int emg3d_core_solve(void *amat, void *bvec, int n, int is_complex);
  * Sizes of the two factor buffers (complex/real part `fac`, real coupling part `lfac`)
  * and of the per-call scratch (right-hand sides / solutions of one colour class): */
 size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex);
+/* ... of `fac` for THIS level: smaller where its direction lr keeps compact records (EMG3D_LEVEL_LINE_COMPACT and the
+ * direction streams; emg3d_line_compact_used says whether), else emg3d_line_fac_bytes -- which is always enough */
+size_t emg3d_line_fac_bytes_lv(const emg3d_level *lv, int lr);
+int emg3d_line_compact_used(const emg3d_level *lv, int lr);
 size_t emg3d_line_lfac_bytes(int lr, int nx, int ny, int nz);
 size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex); /* 0 for lr = 0 */
 

@@ -31,7 +31,8 @@ struct LevelArgs {
 int g_point_slab = 0;
 int g_point_tile_min = 1 << 20;
 int g_line_order = 1;
-int g_line_wide = 0;          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
+int g_line_wide = 0;
+int g_line_compact = 0;       // 1: T and w records of the line passes stored in single precision (kernels.hip: compact k_line_stream)          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
 // kernels.hip (k_gs_point_tile), each workgroup's phases separated like its barriers
@@ -123,6 +124,35 @@ void line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac
     });
 }
 
+// one colour pass with COMPACT records (kernels.hip: k_line_stream<.., COMPACT>): the T records rounded to single
+// precision by the set-up, the w records rounded when the forward pass stores them -- and with them the raw right-hand
+// sides of the rows the middle block reads, which the producer waves put into the same records --, all arithmetic
+// and the solution in T
+template <class T, int DIR>
+void line_colour_compact(const emg::Level<T> &L, int c, const typename emg::compact_of<T>::type *fac, const double *lfac,
+                         T *rhs, T *xout)
+{
+    using FT = typename emg::compact_of<T>::type;
+    const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
+    if (lc.lines <= 0) return;
+    const FT *f = fac + lc.fac_off;
+    const double *lf = lfac + lc.lfac_off;
+    for_threads(emg::lineblk_grid(lc, true), emg::lineblk_block(), [&](int gx, int gy, int gz) {
+        emg::line_rhs_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, rhs);
+    });
+    std::vector<FT> w((size_t)5 * lc.n0p * lc.lines);
+    const int mk = emg::line_mid(lc.n0);
+    for (int lid = 0; lid < lc.lines; ++lid) {
+        for (int r = 0; r < 5; ++r) w[((size_t)mk * lc.lines + lid) * 5 + r] = emg::narrow<FT>(rhs[((size_t)mk * lc.lines + lid) * 5 + r]);
+        w[((size_t)(mk + 1) * lc.lines + lid) * 5] = emg::narrow<FT>(rhs[((size_t)(mk + 1) * lc.lines + lid) * 5]);
+    }
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_forward_ref<T, FT, FT>(lc.n0, lc.n0p, lc.lines, lid, f, lf, w.data(), (const T *)rhs);
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_backward_ref<T, FT, FT>(lc.n0, lc.n0p, lc.lines, lid, f, lf, w.data(), xout);
+    for_threads(emg::lineblk_grid(lc, false), emg::lineblk_block(), [&](int gx, int gy, int gz) {
+        emg::line_scatter_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, (const T *)xout);
+    });
+}
+
 // one colour pass in the wide form (kernels.hip: k_line_wide): one walk per line, in place on the field
 template <class T, int DIR>
 void line_colour_wide(const emg::Level<T> &L, int c, const T *fac, const double *lfac, const T *nfac)
@@ -138,27 +168,42 @@ void line_colour_wide(const emg::Level<T> &L, int c, const T *fac, const double 
     }
 }
 
-template <class T, int DIR> void line_setup_all(const emg::Level<T> &L, T *fac, double *lfac)
+template <class T, int DIR, class FT = T> void line_setup_all(const emg::Level<T> &L, FT *fac, double *lfac)
 {
     for (int c = 0; c < 4; ++c) {
         const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
         if (lc.lines <= 0) continue;
         for_threads(emg::line_grid(lc), emg::line_block(), [&](int gx, int gy, int) {
-            emg::line_setup_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, fac + lc.fac_off, lfac + lc.lfac_off);
+            emg::line_setup_thread<T, DIR, FT>(L, c, lc.cntp, lc.cntq, gx, gy, fac + lc.fac_off, lfac + lc.lfac_off);
         });
     }
 }
 
-template <class T> void gs(const LevelArgs *lv, int lr, int nu)
+// xfac / xlfac != nullptr: line factors given by the caller (e.g. the records the HIP set-up kernel wrote, copied to the
+// host: T records as T, or as compact_of<T> when g_line_compact is set) instead of the CPU set-up's
+template <class T> void gs(const LevelArgs *lv, int lr, int nu, const void *xfac = nullptr, const double *xlfac = nullptr)
 {
     emg::Level<T> L = to_level<T>(lv);
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     std::vector<T> vec(lr ? emg::line_vec_elems(lr - 1, nx, ny, nz) : 1);
     std::vector<T> fac(lr ? emg::line_fac_elems(lr - 1, nx, ny, nz) : 1);
     std::vector<double> lfac(lr ? emg::line_lfac_elems(lr - 1, nx, ny, nz) : 1);
-    if (lr == 1) line_setup_all<T, 0>(L, fac.data(), lfac.data());
-    if (lr == 2) line_setup_all<T, 1>(L, fac.data(), lfac.data());
-    if (lr == 3) line_setup_all<T, 2>(L, fac.data(), lfac.data());
+    if (!xfac && lr == 1) line_setup_all<T, 0>(L, fac.data(), lfac.data());
+    if (!xfac && lr == 2) line_setup_all<T, 1>(L, fac.data(), lfac.data());
+    if (!xfac && lr == 3) line_setup_all<T, 2>(L, fac.data(), lfac.data());
+    // compact form: the same factorisation, its T records rounded to single precision as they are stored
+    using FT = typename emg::compact_of<T>::type;
+    const bool compact = lr && g_line_compact;
+    std::vector<FT> facc(compact ? fac.size() : 1);
+    std::vector<T> xvec(compact ? vec.size() : 1);
+    if (compact && !xfac && lr == 1) line_setup_all<T, 0, FT>(L, facc.data(), lfac.data());
+    if (compact && !xfac && lr == 2) line_setup_all<T, 1, FT>(L, facc.data(), lfac.data());
+    if (compact && !xfac && lr == 3) line_setup_all<T, 2, FT>(L, facc.data(), lfac.data());
+    if (xfac && lr) {
+        if (compact) std::memcpy(facc.data(), xfac, facc.size() * sizeof(FT));
+        else std::memcpy(fac.data(), xfac, fac.size() * sizeof(T));
+        std::memcpy(lfac.data(), xlfac, lfac.size() * sizeof(double));
+    }
     // the N records of the wide form (k_line_wide_setup): one per block record, from its T and coupling entries
     const size_t nrec = lr ? fac.size() / 15 : 0;
     const bool wide = lr && g_line_wide && emg::line_wide_capable(emg::line_n0(lr - 1, nx, ny, nz), nrec);
@@ -219,6 +264,12 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu)
         }
         for (int cc = 0; cc < 4; ++cc) {
             const int c = emg::line_sweep_colour(g_line_order, it, cc);
+            if (compact) {
+                if (lr == 1) line_colour_compact<T, 0>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                else if (lr == 2) line_colour_compact<T, 1>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                else line_colour_compact<T, 2>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                continue;
+            }
             if (wide) {
                 if (lr == 1) line_colour_wide<T, 0>(L, c, fac.data(), lfac.data(), nfac.data());
                 else if (lr == 2) line_colour_wide<T, 1>(L, c, fac.data(), lfac.data(), nfac.data());
@@ -250,11 +301,17 @@ void emu_set_point_slab(int t) { g_point_slab = t; }
 void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
 void emu_set_line_order(int o) { g_line_order = o; }
 void emu_set_line_wide(int w) { g_line_wide = w; }
+void emu_set_line_compact(int c) { g_line_compact = c; }
 void emu_set_point_order(int o) { emg::point_order_ref() = o; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)
 {
     if (lv->is_complex) gs<cplx>(lv, lr, nu); else gs<double>(lv, lr, nu);
+}
+// line sweeps with the caller's factor records (layout of emg3d_dev_line_setup; compact records if emu_set_line_compact(1))
+void emu_gauss_seidel_fac(const LevelArgs *lv, int lr, int nu, const void *fac, const double *lfac)
+{
+    if (lv->is_complex) gs<cplx>(lv, lr, nu, fac, lfac); else gs<double>(lv, lr, nu, fac, lfac);
 }
 
 double emu_residual(const LevelArgs *lv, void *rx, void *ry, void *rz)

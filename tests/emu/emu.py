@@ -70,6 +70,14 @@ def gauss_seidel(e, s, vm, lr, nu):
     lib().emu_gauss_seidel(ctypes.byref(lv), int(lr), int(nu))
 
 
+def gauss_seidel_fac(e, s, vm, lr, nu, fac, lfac):
+    """Line sweeps with given factor records (numpy uint8 / float64 buffers in the layout of emg3d_dev_line_setup)."""
+    keep = []
+    lv = make_level(e, s, vm, keep)
+    fac, lfac = np.ascontiguousarray(fac), np.ascontiguousarray(lfac)
+    lib().emu_gauss_seidel_fac(ctypes.byref(lv), int(lr), int(nu), _ptr(fac), _ptr(lfac))
+
+
 def residual(e, s, vm, r=None):
     """Returns sum |r|^2; fills r (object with fx/fy/fz) if given."""
     keep = []

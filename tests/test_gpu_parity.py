@@ -649,6 +649,72 @@ def test_short_lines_vs_oracle(shape, lr, dtype):
     assert relerr(b.field, a.field) < 1e-11
 
 
+def _random_long_line_level(shape, lr, dtype):
+    rng = np.random.default_rng(sum(shape) + lr)
+    h = [rng.uniform(5., 15., n) * 1.02 ** np.abs(np.arange(n) - n // 2) for n in shape]
+    grid = mg_ref.Grid(h, (0., 0., 0.))
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    vm = mg_ref.volume_model(grid, 0.7 if dtype is complex else -0.7, *sig)
+    s, e0 = mg_ref.Field(grid, dtype=dtype), mg_ref.Field(grid, dtype=dtype)
+    for f in (s, e0):
+        f.field[:] = rng.standard_normal(f.field.size)
+        if dtype is complex:
+            f.field[:] += 1j * rng.standard_normal(f.field.size)
+    for f in (e0.fx[:, 0, :], e0.fx[:, -1, :], e0.fx[:, :, 0], e0.fx[:, :, -1], e0.fy[0], e0.fy[-1],
+              e0.fy[:, :, 0], e0.fy[:, :, -1], e0.fz[0], e0.fz[-1], e0.fz[:, 0], e0.fz[:, -1]):
+        f[...] = 0
+    return grid, vm, s, e0
+
+
+@pytest.mark.parametrize('shape,lr,lpw', [((258, 96, 96), 1, 0), ((96, 130, 96), 2, 0), ((24, 20, 257), 3, 16), ((130, 9, 30), 1, 16),
+                                          ((20, 384, 22), 2, 16), ((40, 40, 260), 3, 16)])
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_compact_streamed_line_kernel_vs_cpu_walk(shape, lr, lpw, dtype):
+    """COMPACT line records (k_line_stream<.., COMPACT>; emg3d_level flag LINE_COMPACT): the inverse blocks T_k and the
+    forward pass's w records stored in SINGLE precision, every operation in fp64. Per sweep (nu = 3) against the CPU
+    walk of the same solve with the same two roundings (tests/emu: stencil.h line_forward_ref / line_backward_ref with
+    FT = WT = compact_of<T>), run on the very T records the HIP set-up kernel stored (copied back from HBM): what is left
+    between the two are the w values that lie within the fp64 differences of the two evaluations (1e-13) of a
+    single-precision rounding boundary -- a few in a million, each worth one ordinary rounding error. And against the
+    CPU walk's own compact set-up (the same T up to such flips) and the fp64 records (different: the storage is
+    really narrower; close: eps32 x cond of the blocks). 130 ... 384-block lines in all three directions, 16-line
+    workgroups forced on levels with few lines (surplus quads, part-filled workgroups), real and complex."""
+    from emu import emu
+    lib = _lib.lib()
+    grid, vm, s, e0 = _random_long_line_level(shape, lr, dtype)
+    dev = torch.device('cuda')
+    out = {}
+    with _option('line_lpw', lpw):
+        if lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), 1) != b'k_line_stream':
+            pytest.skip('the records of these lines fit in LDS: k_line_colour, no compact form')
+        for compact in (0, 1):
+            lv = DeviceLevel.from_host(vm, dev)
+            if compact:
+                lv.set_line_compact(True)
+            assert lib.emg3d_line_compact_used(lv._cref, lr) == compact
+            lv.s.copy_(torch.from_numpy(s.field))
+            lv.e.copy_(torch.from_numpy(e0.field))
+            lv.smooth(lr, 3)
+            out[compact] = lv.e.cpu().numpy()
+            fac, lfac = (t.cpu().numpy() for t in lv.line_factors(lr))
+        assert fac.size * 2 == lib.emg3d_line_fac_bytes(lr, *shape, int(dtype is complex))     # half the bytes
+    emu.lib().emu_set_line_compact(1)
+    try:
+        ref, ref2 = e0.copy(), e0.copy()
+        emu.gauss_seidel_fac(ref, s, vm, lr, 3, fac, lfac.view(np.float64))
+        emu.gauss_seidel(ref2, s, vm, lr, 3)
+    finally:
+        emu.lib().emu_set_line_compact(0)
+    assert np.any(out[1] != e0.field)
+    d = relerr(out[1], out[0])                 # what the narrower storage changes: ~ eps32 x cond of the blocks
+    dc = relerr(out[1], ref.field)             # kernel against the CPU walk on the kernel's own T records
+    ds = relerr(out[1], ref2.field)            # ... on the CPU set-up's (rounding flips of T entries included)
+    print(f"compact {shape} lr={lr} {dtype.__name__}: vs fp64 records {d:.2e}, vs CPU walk (same T) {dc:.2e}, (own T) {ds:.2e}")
+    assert 1e-9 < d < 3e-2, d
+    # (measured: 5e-14 ... 1e-9 on the levels with few lines, 0.5 ... 4 % of d on those with millions of values)
+    assert dc < 0.1 * d, (dc, d)
+
+
 class _option:
     """Set a run-time option of the library for the duration of a with-block."""
 

@@ -76,7 +76,9 @@ def report(name, ms, ncells, nsweeps, case):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['point', 'lines', 'residual', 'around', 'all', 'batchcmp'])
+    ap.add_argument('what', choices=['point', 'lines', 'residual', 'around', 'all', 'batchcmp', 'optcmp'])
+    ap.add_argument('--variant', action='append', default=[], help="optcmp: option set 'name=value,name=value' ('' = defaults); repeatable")
+    ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--n', type=int, default=256)
     ap.add_argument('--case', default='triaxial')
     ap.add_argument('--slabs', default='0,2,4,8,16,32')
@@ -94,6 +96,8 @@ def main():
     shape = tuple(int(x) for x in args.shape.split(',')) if args.shape else None
     if args.what == 'batchcmp':
         return batchcmp(args, shape)
+    if args.what == 'optcmp':
+        return optcmp(args, shape)
     lv, grid = make_level(args.n, args.case, shape=shape, eta_real=args.eta_real, batch=args.batch)
     nc = grid.n_cells
     print(f"# {shape or args.n} {args.case}, nu={args.nu}, batch={args.batch}")
@@ -154,6 +158,47 @@ def batchcmp(args, shape):
             v = np.array(res[(b, lr)])
             kn = lib.emg3d_line_kernel_name(lr, *grid.shape_cells, 1, b).decode()
             line += f"  B={b} {kn} {np.median(v):.3f} ms ({np.median(v / base):.3f} x)"
+        print(line, flush=True)
+
+
+def optcmp(args, shape):
+    """Line passes under several option sets on ONE box in ONE process, interleaved over several rounds (consecutive
+    processes differ by up to 8 %): every variant gets its own level (its factors are built under its options), the
+    options are set before each timed call. ms per call of 4 nu - (nu - 1) launches, median over the rounds, and the
+    median of the per-round ratios to the first variant."""
+    lib = _lib.lib()
+    variants = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in v.split(',') if kv) for v in (args.variant or [''])]
+    names = sorted({k for v in variants for k in v})
+    defaults = {k: lib.emg3d_get_option(k.encode()) for k in names}
+
+    def apply(v):
+        for k in names:
+            assert lib.emg3d_set_option(k.encode(), v.get(k, defaults[k])) == 0, k
+    levels = []
+    for v in variants:
+        apply(v)
+        lv, grid = make_level(args.n, args.case, shape=shape)
+        for lr in (1, 2, 3):
+            lv.smooth(lr, args.nu)
+        levels.append(lv)
+    res = {(i, lr): [] for i in range(len(variants)) for lr in (1, 2, 3)}
+    for r in range(args.rounds):
+        for lr in (1, 2, 3):
+            for i, (v, lv) in enumerate(zip(variants, levels)):
+                apply(v)
+                med, _ = timeit(lambda: lv.smooth(lr, args.nu), reps=3, warm=1)
+                res[(i, lr)].append(med)
+    apply({})
+    nl = 4 * args.nu - (args.nu - 1)
+    print(f"# {grid.shape_cells} {args.case}, nu={args.nu}: ms per call of {nl} launches (ms per launch; % of the 8 TB/s roofline per "
+          f"launch on {BYTES_PER_CELL_SWEEP[args.case]} B per cell-sweep), median of {args.rounds} interleaved rounds")
+    for i, v in enumerate(variants):
+        line = f"{str(v):60s}"
+        for lr in (1, 2, 3):
+            t = np.array(res[(i, lr)])
+            base = np.array(res[(0, lr)])
+            frac = BYTES_PER_CELL_SWEEP[args.case] * grid.n_cells / 4 / (np.median(t) / nl * 1e-3) / 8e12
+            line += f"  {'xyz'[lr - 1]} {np.median(t):6.3f} ({np.median(t) / nl:.3f}; {100 * frac:4.1f} %; {np.median(t / base):.3f} x)"
         print(line, flush=True)
 
 
