@@ -576,11 +576,13 @@ def run_gpu(args):
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin_ = tt.clone()
+        dist.all_reduce(tmin_, op=dist.ReduceOp.MIN)
         tsum = tt.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, work_all = tmax[0].item(), tsum[1].item()
+        dt_max, dt_min, work_all = tmax[0].item(), tmin_[0].item(), tsum[1].item()
     else:
-        dt_max, work_all = dt, float(work)
+        dt_max, dt_min, work_all = dt, dt, float(work)
 
     out = None
     if rank == 0:
@@ -606,6 +608,10 @@ def run_gpu(args):
             'unit': 'Mcell-sweeps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt_max / args.steps * 1e3,
+            # the ranks' own clocks around the same timed region (scalars, for whoever computes the scaling curve):
+            # slowest (= ms_per_step) and fastest rank, and the model broadcast that precedes the timed region
+            'ms_per_step_rank_max': dt_max / args.steps * 1e3, 'ms_per_step_rank_min': dt_min / args.steps * 1e3,
+            'broadcast_ms': broadcast_ms, 'backend': backend if world > 1 else None,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'c128 (complex fp64)' if b.hier.top.is_complex else 'f64',
             'data': 'synthetic',
@@ -614,6 +620,12 @@ def run_gpu(args):
                        'cell_sweeps_per_step': work / args.steps,
                        'rel_error_after_run': l2,
                        'line_factors': b.hier.line_factors,
+                       # single-precision STORAGE of the streamed line passes' T and w records (all arithmetic fp64;
+                       # solver.Hierarchy(line_compact=), 'auto' by the model's block condition); where it is on the
+                       # finest level cycles in residual form, as the solver itself does
+                       'line_factor_storage': 'compact (fp32 T and w records on the streamed levels)'
+                       if b.hier.line_compact else 'fp64',
+                       'residual_form': bool(getattr(b.var, 'residual_form', False)),
                        'hbm_allocated_gb': torch.cuda.max_memory_allocated() / 1e9,
                        'parallelism': f'{world} independent sources, 1 per GPU', 'pair_of_rank_0': pair,
                        'model_distribution': None if world == 1 else
@@ -623,6 +635,9 @@ def run_gpu(args):
                 'bound': 'hbm', 'kernel': names[dom], 'hip_kernel': hip_names[dom],
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
+                # (scalars next to the nested entries, for parsers that keep scalars only)
+                'traffic_ratio': (traffic / bytes_per_launch) if traffic else None,
+                'traffic_stale': bool(traffic_source['stale']) if traffic_source else None,
                 'bytes_per_launch': bytes_per_launch, 'ms_per_launch': ms_launch,
                 'launches_timed': stats[dom]['launches'],
                 'gcell_sweeps_per_s': n0 / 4.0 / (ms_launch * 1e-3) / 1e9,
@@ -648,6 +663,16 @@ def run_gpu(args):
             'frac_delivered': pt['frac_delivered'], 'ms_per_launch': pt['ms_per_launch'],
             'traffic': pmc_traffic('smoothers_256', 'k_gs_point_tile')[0],
             'traffic_source': pmc_traffic('smoothers_256', 'k_gs_point_tile')[1]}
+        # ... and as scalars of the roofline object itself: per launch, per delivered sweep
+        out['roofline']['north_star_frac'] = pt['frac']
+        out['roofline']['north_star_ms_per_launch'] = pt['ms_per_launch']
+        out['roofline']['north_star_ms_per_sweep'] = pt['ms_per_delivered_sweep']
+        out['roofline']['north_star_traffic_ratio'] = (
+            out['roofline']['north_star_kernel']['traffic'] / (pt['achieved'] * 1e9 * pt['ms_per_launch'] * 1e-3)
+            if out['roofline']['north_star_kernel']['traffic'] else None)
+        for lab, v in sm['smoothers'].items():
+            if lab.startswith('gauss_seidel_'):
+                out['roofline'][f'line_{lab[13]}_256_frac'] = v['frac']
     if rank == 0 and world == 1 and not args.no_survey:
         try:
             out['survey_8_sources'] = survey_8(device)

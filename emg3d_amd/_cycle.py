@@ -205,8 +205,12 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None, top=None):
                 for k in stale:
                     del cache[k]
                 # (from the finest level on, where the caller names it: its eta-sum buffer is the largest of them, and
-                #  the subtrees of the other semicoarsening directions hang off it)
-                _drop_stale_point_factors(top if top is not None else clv)
+                #  the subtrees of the other semicoarsening directions hang off it. Their graph caches go first: a
+                #  sibling's graph captured under the old options holds the addresses of the buffers freed here, and its
+                #  key would match again as soon as the options return to their old values)
+                root = top if top is not None else clv
+                _purge_stale_graphs(root, key[-1])
+                _drop_stale_point_factors(root)
             entry = cache[key] = {'work': None, 'graph': None, 'seen': 0}
         if entry['seen'] < GRAPH_AFTER:
             before = var.smoother_cell_sweeps
@@ -225,6 +229,20 @@ def coarse_correction(clv, var, budget, first_level=1, graphed=None, top=None):
         entry['graph'] = graph
     entry['graph'].replay()
     var.smoother_cell_sweeps += entry['work']
+
+
+def _purge_stale_graphs(lv, fingerprint, seen=None):
+    """Delete every captured graph below `lv` that was captured under another option set than `fingerprint`."""
+    seen = set() if seen is None else seen
+    if id(lv) in seen:
+        return
+    seen.add(id(lv))
+    cache = lv.__dict__.get('_graphs')
+    if cache:
+        for k in [k for k in cache if k[-1] != fingerprint]:
+            del cache[k]
+    for link in lv.children.values():
+        _purge_stale_graphs(link['level'], fingerprint, seen)
 
 
 def _drop_stale_point_factors(lv, seen=None):
@@ -322,7 +340,7 @@ def run_cycles(top, var):
     # cond of a block, relative to the right-hand side they are given -- then scale with the
     # residual, not with the field, and the iteration converges to round-off.
     resform = bool(getattr(var, 'residual_form', False)) and not var.sslsolver and top.batch == 1
-    if getattr(getattr(top, 'work', None), 'line_compact', False) and not var.sslsolver and top.batch == 1 and not resform:
+    if not resform and not var.sslsolver and top.batch == 1 and getattr(top, 'uses_line_compact', lambda: False)():
         # compact line records (solver.Hierarchy(line_compact=...)): the streamed line solves are perturbed by
         # eps32 x cond, the finest level must see residuals, not the field
         resform = var.residual_form = True

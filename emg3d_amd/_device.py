@@ -200,6 +200,14 @@ class DeviceLevel:
         self._c.flags = self.flags
         self.work.line_compact = bool(on)
 
+    def uses_line_compact(self):
+        """Does a line direction of THIS level keep compact records (the flag is set and the direction streams)? The
+        finest level of such a hierarchy runs in residual form (_cycle.run_cycles)."""
+        if not self.flags & _lib.LEVEL_LINE_COMPACT:
+            return False
+        lib = _lib.lib()
+        return any(lib.emg3d_line_compact_used(self._cref, lr) for lr in (1, 2, 3))
+
     @property
     def r(self):
         if self._r is None:

@@ -14,7 +14,10 @@ LIBPATH = os.path.join(LIBDIR, 'libemg3d_amd.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'emg3d_amd.h')
 SOURCES = [os.path.join(CSRC, f) for f in ('kernels.hip', 'stencil.h', 'launch.h', 'cplx.h', 'receivers.h', 'krylov.h', 'adjoint.h')] + [HEADER]
 
-HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
+# -ffp-contract: hipcc's own default for HIP, spelled out because csrc/kernels.hip switches contraction off for its
+# line-kernel section and back to THIS mode behind it (`#pragma clang fp contract(fast)`: the pragma can name a mode,
+# not "whatever it was"; clang has no push / pop for it on this target -- `#pragma float_control` is ignored on amdgcn)
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast-honor-pragmas']
 
 
 class Emg3dAmdError(RuntimeError):

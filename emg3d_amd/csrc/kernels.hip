@@ -150,7 +150,9 @@ int g_line_compact_rd = 0;
 // producer waves, 8 rows per chunk: 74 KB -- two workgroups of four waves share a CU and fill each other's start-up,
 // middle-block and drain phases)
 int g_line_compact_occ = 1;
-int g_line_compact_np = 256;       // producer threads of the compact kernel: 256 or 384 (experiment)
+// producer threads of the compact kernel: 384 (default; six waves) or 256 -- same-box A/B at 256^3, ms per launch
+// x / y / z: 0.732 / 0.780 / 0.770 with four producer waves, 0.697 / 0.766 / 0.764 with six
+int g_line_compact_np = 384;
 
 // eta edge sums of the tiled point smoother: 8-byte storage (launch.h: tile_pst_*) for real
 // fields and for complex fields whose eta are purely imaginary (emg3d_level::flags)
@@ -1115,6 +1117,10 @@ constexpr int LW_BLOCK_THREADS = 192;      // waves 0..2: one thread per top / b
 constexpr int LW_ROW = 6;                  // entries of an LDS row: values 1..4, a zero, a dummy
 // lines per workgroup: at most 8 (two chain waves per half), and every block of them needs a thread
 inline int wide_lpw(int n0, int nbthr = LW_BLOCK_THREADS) { return std::max(1, std::min(8, nbthr / std::max(n0 - 2, 1))); }
+// an invariant of the k_line_wide launch (launch_line_colour): a line's blocks fit the block threads even with one line
+// per workgroup -- it holds because line_wide_capable stops at WIDE_N0_MAX (the dynamic LDS, ~55 KB at most, is checked
+// against the opt-in limit at the launch)
+static_assert(emg::WIDE_N0_MAX - 2 <= LW_BLOCK_THREADS, "k_line_wide: one thread per block of a line");
 
 template <class T> __global__ __launch_bounds__(256) void k_line_wide_setup(const T *fac, const double *lfac, T *nfac, size_t nrec)
 {
@@ -1808,7 +1814,11 @@ __global__ __launch_bounds__(128 + NPROD, NPROD == 128 ? 2 : 1) void k_line_stre
     else quad_backward_stream<T, DIR, 1, RD, B, PAIR, LFR, FT, WT>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, fdummy, boff0, ringbase, lpw, R, nchunks, lfring);
 }
 
-#pragma clang fp contract(fast)      // (end of the spelled-out section: the compiler's default again)
+// End of the spelled-out section: back to the mode the translation unit is compiled with -- -ffp-contract=fast-honor-
+// pragmas, which emg3d_amd/_lib.py (HIPCC_FLAGS) passes explicitly, so that this line and the command line cannot
+// drift apart. (The pragma can only name a mode; a push / pop of the previous one does not exist on this target:
+// `#pragma float_control(push)` is "not supported on this target - ignored" by amdgcn clang, checked with hipcc 7.2.)
+#pragma clang fp contract(fast)
 
 // Residual + per-block partial sums of |r|^2. A workgroup walks `zb` consecutive planes: the plane
 // above the current one, fetched for the curl, is the next iteration's own plane and is still in
@@ -2022,12 +2032,12 @@ inline bool line_wide_used(int dir, int nx, int ny, int nz)
 
 // Does direction `dir` of this level keep COMPACT line factors (k_line_stream<.., COMPACT>)? The level asks for it
 // (emg3d_level::flags, or option line_compact = 1), and every colour class of the direction runs the streamed kernel
-// for one source -- the set-up (which stores the T records in that form), the size query and the launcher all decide
-// with this one function of the level and the options.
+// for the level's number of right-hand sides (one source, or groups of them) -- the set-up (which stores the T records
+// in that form), the size query and the launcher all decide with this one function of the level and the options.
 template <class T> bool line_compact_used(const emg::Level<T> &L, int dir)
 {
     if (g_line_compact < 0 || !(g_line_compact > 0 || (L.flags & emg::LEVEL_LINE_COMPACT))) return false;
-    if (L.batch > 1 || line_wide_used(dir, L.nx, L.ny, L.nz)) return false;
+    if (line_wide_used(dir, L.nx, L.ny, L.nz)) return false;
     bool any = false;
     for (int c = 0; c < 4; ++c) {
         const emg::LineClass lc = emg::line_class(dir, L.nx, L.ny, L.nz, c);
@@ -2056,6 +2066,9 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
                            : (const void *)&k_line_stream<T, DIR, B, RD, NPROD, (B >= 2), false>;
     int nprod = NPROD;
     size_t smem_c = smem;
+    if constexpr (B >= 2) {
+        if (compact) kern = (const void *)&k_line_stream<T, DIR, B, RD, NPROD, true, false, true>;
+    }
     if constexpr (B == 1) {
         const bool rd8 = g_line_compact_rd == 8 || (g_line_compact_rd == 0 && DIR == 0);
         if (compact) kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, NPROD, false, true, true>
@@ -2106,6 +2119,10 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         const size_t smem = ((size_t)2 * lpw * (lc.n0 + 1) + 2 * lpw) * LW_ROW * sizeof(T);
         const T *nf = fac + emg::line_fac_elems(DIR, L.nx, L.ny, L.nz) + lc.fac_off / 15 * 16;
         const dim3 grid(cdiv(lc.lines, lpw), L.batch);
+        if (smem > (size_t)64 * 1024) {
+            (void)allow_lds((const void *)&k_line_wide<T, DIR, true>, smem);
+            (void)allow_lds((const void *)&k_line_wide<T, DIR, false>, smem);
+        }
         if (L.batch > 1)
             hipLaunchKernelGGL((k_line_wide<T, DIR, true>), grid, dim3(nbthr + 64), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf, nbthr);
         else
@@ -2119,9 +2136,9 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
         int b0 = 0;
         for (int g = 0; g < ng; ++g) {
             const int gs = L.batch / ng + (g < L.batch % ng ? 1 : 0);
-            if (gs == 4) launch_stream_group<T, DIR, 4>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st);
-            else if (gs == 3) launch_stream_group<T, DIR, 3>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st);
-            else if (gs == 2) launch_stream_group<T, DIR, 2>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st);
+            if (gs == 4) launch_stream_group<T, DIR, 4>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st, compact);
+            else if (gs == 3) launch_stream_group<T, DIR, 3>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st, compact);
+            else if (gs == 2) launch_stream_group<T, DIR, 2>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st, compact);
             else launch_stream_group<T, DIR, 1>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st, compact);
             b0 += gs;
         }
@@ -2508,6 +2525,8 @@ int emg3d_set_option(const char *name, int value)
     // ring pass would be read past its end), and two chunks x two halves x 16 lines must fit the LDS of a CU
     if (!std::strcmp(name, "line_stream_r") && value != 0 && (value < 4 || value > 32 || value % emg::LINE_PAD != 0))
         return fail(EMG3D_ERR_BADARG, "line_stream_r: 0 (= 16) or a multiple of 4 in 4..32");
+    // (lines longer than WIDE_N0_MAX hold no N records: a larger value would be a silent no-op)
+    if (!std::strcmp(name, "line_wide") && (value < 0 || value > emg::WIDE_N0_MAX)) return fail(EMG3D_ERR_BADARG, "line_wide: 0 .. 64");
     if (!std::strcmp(name, "line_wide_bt") && value != 0 && value != 192 && value != 256) return fail(EMG3D_ERR_BADARG, "line_wide_bt: 0, 192 or 256");
     if (!std::strcmp(name, "line_compact_rd") && value != 0 && value != 4 && value != 8) return fail(EMG3D_ERR_BADARG, "line_compact_rd: 0, 4 or 8");
     if (!std::strcmp(name, "line_compact") && (value < -1 || value > 1)) return fail(EMG3D_ERR_BADARG, "line_compact: -1, 0 or 1");

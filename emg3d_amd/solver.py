@@ -44,7 +44,8 @@ _SOLVE_EXTRAS = {'always_return': False, 'plain': False, 'efield': None, 'hierar
                  '_download': True,           # False: the result stays in hierarchy.top.e only
                  '_sparse_source': False,     # the source goes up as its few non-zeros
                  'smoother_omega': 1.0,       # != 1: extrapolated smoothing calls (_cycle.smooth_level)
-                 'residual_form': 'auto'}     # finest level in residual form (_cycle.run_cycles)
+                 'residual_form': 'auto',     # finest level in residual form (_cycle.run_cycles)
+                 'line_compact': None}        # Hierarchy(line_compact=): compact records of the streamed line passes
 
 
 def _residual_form(choice, var, model, sfield):
@@ -109,8 +110,10 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     ``maxit=50``, ``nu_init=0``, ``nu_pre=2``, ``nu_coarse=1``, ``nu_post=2``,
     ``clevel=-1``, ``return_info=False``, ``log=1``, ``plain=False``.
 
-    Not in the reference: ``hierarchy=`` (a ``Hierarchy`` built for the same model, grid and
-    frequency) reuses the device-resident levels, line factorisations and captured graphs of
+    Not in the reference: ``line_compact=None`` (True / False / 'auto', see ``Hierarchy``: the streamed line
+    passes keep their factor records in single precision where the model allows it -- same converged field and
+    cycle counts, per-cycle values differ by eps32 x cond of the blocks); ``hierarchy=`` (a ``Hierarchy`` built for
+    the same model, grid and frequency) reuses the device-resident levels, line factorisations and captured graphs of
     an earlier solve -- what several sources at one frequency share; ``smoother_omega=1.0``: a
     value != 1 extrapolates every smoothing call, e <- e_before + omega (e_after - e_before) --
     same solution, and on models where the four-colour ordering costs cycles against the
@@ -163,6 +166,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
             # field must still be THIS solve's result -- receivers and the gradient read it from
             # HBM, where the previous pair's field would otherwise linger
             extra['hierarchy'].upload_field(efield)
+    var.line_compact = extra['line_compact']
     if var.sslsolver:
         krylov(vmodel, sfield, efield, var, hierarchy=extra['hierarchy'])
     elif var.cycle:
@@ -292,6 +296,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     hierarchy = kwargs.pop('hierarchy', None)            # a Hierarchy(vmodel, batch=len(sfields)) to reuse
     omega = _check_omega(kwargs.pop('smoother_omega', 1.0))     # extrapolated smoothing calls, as in solve()
     resform = kwargs.pop('residual_form', 'auto')               # finest level in residual form, as in solve()
+    line_compact = kwargs.pop('line_compact', None)             # Hierarchy(line_compact=), as in solve()
     sfields = list(sfields)
     nb = len(sfields)
     if nb == 0:
@@ -326,7 +331,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         for b, sf in enumerate(sfields):
             ef, info = solve(model, sf, sslsolver=sslsolver, semicoarsening=semicoarsening,
                              linerelaxation=linerelaxation, verb=verb, return_info=True, always_return=True,
-                             smoother_omega=omega, residual_form=resform, **kwargs)
+                             smoother_omega=omega, residual_form=resform, line_compact=line_compact, **kwargs)
             if rec_of(b) is not None:
                 info['responses'] = fields.get_receiver(ef, rec_of(b), receiver_method)
             out.append((ef if keep_fields else None, info))
@@ -335,7 +340,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         hierarchy.check(vmodel)
         hier = hierarchy
     else:
-        hier = Hierarchy(vmodel, batch=nb)
+        hier = Hierarchy(vmodel, batch=nb, line_compact=line_compact)
     top = hier.top
     n = top.grid.n_edges
     efields = []
@@ -381,6 +386,11 @@ def _multigrid_batch(lv, svar, vars_, active=None):
     # (finest level in residual form, as _cycle.run_cycles does it for one source)
     resform = bool(getattr(svar, 'residual_form', False)) and not svar.sslsolver
     may_switch = bool(getattr(svar, 'residual_form_auto', False)) and not svar.sslsolver
+    if not resform and not svar.sslsolver and lv.uses_line_compact():
+        # (compact line records on this level: it must see residuals, as in _cycle.run_cycles)
+        resform = svar.residual_form = True
+        for v in vars_:
+            v.residual_form = True
     if resform:
         lv._b_valid = False
     l2_last = lv.residual(store=resform, norm=True)
@@ -554,7 +564,7 @@ def block_condition(vmodel):
             # eta / zeta holders (tests, tools): |eta| / V = |s| mu0 sigma
             vol = np.asarray(vmodel.grid.cell_volumes).reshape(vmodel.grid.shape_cells, order='F')
             smu_sig = min(float(np.min(np.abs(np.asarray(e)) / vol)) for e in (vmodel.eta_x, vmodel.eta_y, vmodel.eta_z))
-        cond = 1.0 / (smu_sig * hmin ** 2)
+        cond = np.float64(1.0) / (np.float64(smu_sig) * np.float64(hmin) ** 2)
     return float(cond) if np.isfinite(cond) else np.inf
 
 
@@ -570,8 +580,8 @@ class Hierarchy:
         (relative eps32 x cond of the 5 x 5 blocks), so every level must solve a correction equation: the coarse levels
         always do, the finest runs in residual form (``_cycle.run_cycles`` does that by itself on such a hierarchy; as
         a Krylov preconditioner it is in that form anyway). 'auto': where the block condition estimate
-        1 / (|s| mu0 sigma_min h_min^2) is at most ``COMPACT_COND_MAX`` and batch == 1. Same converged field, same
-        cycle counts (tools/compact_cycles.py, tests).
+        1 / (|s| mu0 sigma_min h_min^2) is at most ``COMPACT_COND_MAX``. Same converged field, same cycle counts
+        (tools/compact_cycles.py, tests); batches stay bit-identical to separate solves on such a hierarchy.
 
         line_factors: 'resident' (default; or the environment's EMG3D_AMD_LINE_FACTORS) keeps the line
         factorisation of every direction a level has used in HBM -- 304 B per cell and direction, ~2.0 kB per
@@ -591,7 +601,7 @@ class Hierarchy:
         if line_compact not in (True, False, 'auto'):
             raise ValueError(f"`line_compact` must be True, False or 'auto'. Provided: {line_compact!r}.")
         if line_compact == 'auto':
-            line_compact = batch == 1 and block_condition(vmodel) <= COMPACT_COND_MAX
+            line_compact = block_condition(vmodel) <= COMPACT_COND_MAX
         self.line_compact = bool(line_compact)
         if self.line_compact:
             self.top.set_line_compact(True)
@@ -646,7 +656,7 @@ def multigrid(model, sfield, efield, var, **kwargs):
     count in ``var.it``, final error in ``var.l2``. The level hierarchy lives in HBM for the
     duration of the call; pass ``hierarchy=`` (a ``Hierarchy``) to reuse one.
     """
-    hier = kwargs.get('hierarchy') or Hierarchy(model)
+    hier = kwargs.get('hierarchy') or Hierarchy(model, line_compact=getattr(var, 'line_compact', None))
     hier.upload(sfield, efield, getattr(var, 'sparse_source', False))
     try:
         _multigrid(hier.top, var, 0, 0)
@@ -684,7 +694,7 @@ def krylov(model, sfield, efield, var, hierarchy=None):
     routines.
     """
     from emg3d_amd import _krylov
-    hier = hierarchy or Hierarchy(model)
+    hier = hierarchy or Hierarchy(model, line_compact=getattr(var, 'line_compact', None))
     device_solver = {'bicgstab': _krylov.bicgstab, 'cgs': _krylov.cgs, 'gcrotmk': _krylov.gcrotmk}[var.sslsolver]
     try:
         status = _krylov_on_device(device_solver, hier, sfield, efield, var)
