@@ -192,21 +192,23 @@ class DeviceLevel:
 
     def set_line_compact(self, on=True):
         """Mark this level (and the coarse levels made from it afterwards) as solving correction equations only:
-        the streamed line passes keep their T and w records in single precision (include/emg3d_amd.h:
-        EMG3D_LEVEL_LINE_COMPACT). Before the first line factorisation of the level."""
+        the streamed line passes keep their T and w records, the tiled point smoother its eta sums in single precision
+        (include/emg3d_amd.h: EMG3D_LEVEL_LINE_COMPACT, _POINT_COMPACT). Before the first factorisation of the level."""
         if self._factors or self.__dict__.get('_slots') or self.children:
             raise RuntimeError("set_line_compact: the level already has factors or coarse levels")
-        self.flags = (self.flags | _lib.LEVEL_LINE_COMPACT) if on else (self.flags & ~_lib.LEVEL_LINE_COMPACT)
+        bits = _lib.LEVEL_LINE_COMPACT | _lib.LEVEL_POINT_COMPACT
+        self.flags = (self.flags | bits) if on else (self.flags & ~bits)
         self._c.flags = self.flags
         self.work.line_compact = bool(on)
 
     def uses_line_compact(self):
         """Does a line direction of THIS level keep compact records (the flag is set and the direction streams)? The
         finest level of such a hierarchy runs in residual form (_cycle.run_cycles)."""
-        if not self.flags & _lib.LEVEL_LINE_COMPACT:
+        if not self.flags & (_lib.LEVEL_LINE_COMPACT | _lib.LEVEL_POINT_COMPACT):
             return False
         lib = _lib.lib()
-        return any(lib.emg3d_line_compact_used(self._cref, lr) for lr in (1, 2, 3))
+        return (any(lib.emg3d_line_compact_used(self._cref, lr) for lr in (1, 2, 3)) or
+                bool(lib.emg3d_point_compact_used(self._cref)))
 
     @property
     def r(self):

@@ -72,6 +72,7 @@ SIGNATURES = {
     'emg3d_line_fac_bytes': (_sz, [_ci] * 5),
     'emg3d_line_fac_bytes_lv': (_sz, [ctypes.POINTER(Level), _ci]),
     'emg3d_line_compact_used': (_ci, [ctypes.POINTER(Level), _ci]),
+    'emg3d_point_compact_used': (_ci, [ctypes.POINTER(Level)]),
     'emg3d_line_lfac_bytes': (_sz, [_ci] * 4),
     'emg3d_dev_line_setup': (_ci, [ctypes.POINTER(Level), _ci, _vp, _vp, _vp]),
     'emg3d_point_fac_bytes': (_sz, [_ci] * 4),
@@ -105,6 +106,7 @@ SIGNATURES = {
 
 LEVEL_ETA_IMAG = 1      # emg3d_level.flags (include/emg3d_amd.h)
 LEVEL_LINE_COMPACT = 2  # ... the level solves a correction equation: streamed line records may be single precision
+LEVEL_POINT_COMPACT = 4  # ... and so may the eta edge sums of the tiled point smoother
 
 _lib = None
 

@@ -159,6 +159,15 @@ int g_line_compact_np = 384;
 template <class T> bool pst_stored_half(int flags);
 template <> bool pst_stored_half<double>(int) { return true; }
 template <> bool pst_stored_half<cplx>(int flags) { return (flags & emg::LEVEL_ETA_IMAG) != 0; }
+// ... and the storage mode of the buffer (launch.h: PST_*): single precision on levels flagged LEVEL_POINT_COMPACT
+// (option point_compact: 0 by the flag, 1 always, -1 never)
+int g_point_compact = 0;
+template <class T> int pst_mode(int flags)
+{
+    const bool compact = g_point_compact > 0 || (g_point_compact == 0 && (flags & emg::LEVEL_POINT_COMPACT));
+    if (pst_stored_half<T>(flags)) return compact ? emg::PST_HALF_F32 : emg::PST_HALF;
+    return compact ? emg::PST_FULL_F32 : emg::PST_FULL;
+}
 
 // Opt a kernel in to more than 64 KB of dynamic LDS. The attribute belongs to the (kernel,
 // device) pair: remembered per device ordinal, so a process that drives several GPUs sets it on
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
     };
     auto load_eta = [&](int ix, int iy, int iz, int colour, emg::PointIn<T> &in) {
         if (ST == 0) emg::point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
-        else emg::tile_pst_load<T, TB, ST == 3>(pst, ntx, nty, tx, ty, tz, colour, t, in);
+        else emg::tile_pst_load<T, TB, ST>(pst, ntx, nty, tx, ty, tz, colour, t, in);
     };
     // PFV = 3: paired source loads. A thread's four nodes (one per node colour) are the 2 x 2
     // patch (x0 + 2 jx + {0,1}, y0 + 2 jy + {0,1}) of its plane; the two nodes of a row differ
@@ -361,10 +370,10 @@ __global__ __launch_bounds__(TB::THREADS, 2) void k_gs_point_tile(emg::Level<T> 
 }
 
 // eta edge sums in tile-major order (launch.h: tile_pst_setup), one workgroup per tile
-template <class T, class TB, bool IMAG>
+template <class T, class TB, int MODE>
 __global__ __launch_bounds__(TB::THREADS) void k_point_setup_tile(emg::Level<T> L, void *pst)
 {
-    emg::tile_pst_setup<T, TB, IMAG>(L, pst, gridDim.x, gridDim.y, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
+    emg::tile_pst_setup<T, TB, MODE>(L, pst, gridDim.x, gridDim.y, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
 }
 
 // does any of n complex values have a non-zero real part? (sets *flag)
@@ -2042,7 +2051,10 @@ template <class T> bool line_compact_used(const emg::Level<T> &L, int dir)
     for (int c = 0; c < 4; ++c) {
         const emg::LineClass lc = emg::line_class(dir, L.nx, L.ny, L.nz, c);
         if (lc.lines <= 0) continue;
-        if (line_plan<T>(lc, L.batch).kind != LK_STREAM) return false;
+        // decided on the plan of ONE source (a level that streams for one source streams for groups as well: more
+        // right-hand sides never mean fewer lines per workgroup), so that a source sees the same records -- and gives
+        // the same bits -- alone and in a batch
+        if (line_plan<T>(lc, 1).kind != LK_STREAM || line_plan<T>(lc, L.batch).kind != LK_STREAM) return false;
         any = true;
     }
     return any;
@@ -2225,7 +2237,7 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             const size_t smem = E::LDS_BYTES;
             // eta sums: tile-major buffer (stored halves when the level's eta are purely imaginary
             // or the field is real), or formed on the fly when fac == NULL
-            const int st = !fac ? 0 : (pst_stored_half<T>(L.flags) ? 3 : 2);
+            const int st = !fac ? 0 : pst_mode<T>(L.flags);
             int pf = (g_point_prefetch >= 0 && g_point_prefetch <= 3) ? g_point_prefetch : 0;
             if (st == 0 && pf == 2) pf = 1;      // 24 eta loads per node in flight twice do not fit the registers
 #define PT_ROW(B, PF_)                                                                                         \
@@ -2235,6 +2247,13 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
                                         {PT_ROW(true, 0), PT_ROW(true, 1), PT_ROW(true, 2), PT_ROW(true, 3)}};
 #undef PT_ROW
             const void *kern = kfn[L.batch > 1 ? 1 : 0][pf][st == 0 ? 0 : st - 1];
+            // single-precision eta sums: the instantiations without software prefetch (the default) only
+            if (st == emg::PST_HALF_F32)
+                kern = L.batch > 1 ? (const void *)&k_gs_point_tile<T, TB, emg::PST_HALF_F32, true, 0>
+                                   : (const void *)&k_gs_point_tile<T, TB, emg::PST_HALF_F32, false, 0>;
+            if (st == emg::PST_FULL_F32)
+                kern = L.batch > 1 ? (const void *)&k_gs_point_tile<T, TB, emg::PST_FULL_F32, true, 0>
+                                   : (const void *)&k_gs_point_tile<T, TB, emg::PST_FULL_F32, false, 0>;
             HIP_TRY(allow_lds(kern, smem));
             // A sweep ends with the pair of tile colours the next sweep (opposite direction) starts
             // with, and nothing else runs in between: those tiles do the node colours of BOTH sweeps
@@ -2504,7 +2523,7 @@ static const OptionEntry g_options[] = {
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
     {"line_wide", &g_line_wide},         {"line_wide_bt", &g_line_wide_bt},     {"line_compact", &g_line_compact},
     {"line_compact_rd", &g_line_compact_rd}, {"line_compact_occ", &g_line_compact_occ},
-    {"line_compact_np", &g_line_compact_np},
+    {"line_compact_np", &g_line_compact_np}, {"point_compact", &g_point_compact},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value
@@ -2529,6 +2548,7 @@ int emg3d_set_option(const char *name, int value)
     if (!std::strcmp(name, "line_wide") && (value < 0 || value > emg::WIDE_N0_MAX)) return fail(EMG3D_ERR_BADARG, "line_wide: 0 .. 64");
     if (!std::strcmp(name, "line_wide_bt") && value != 0 && value != 192 && value != 256) return fail(EMG3D_ERR_BADARG, "line_wide_bt: 0, 192 or 256");
     if (!std::strcmp(name, "line_compact_rd") && value != 0 && value != 4 && value != 8) return fail(EMG3D_ERR_BADARG, "line_compact_rd: 0, 4 or 8");
+    if (!std::strcmp(name, "point_compact") && (value < -1 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_compact: -1, 0 or 1");
     if (!std::strcmp(name, "line_compact") && (value < -1 || value > 1)) return fail(EMG3D_ERR_BADARG, "line_compact: -1, 0 or 1");
     if (!std::strcmp(name, "line_order") && (value < 0 || value > 2)) return fail(EMG3D_ERR_BADARG, "line_order: 0, 1 or 2");
     if (!std::strcmp(name, "point_order") && (value < 0 || value > 1)) return fail(EMG3D_ERR_BADARG, "point_order: 0 or 1");
@@ -2625,8 +2645,8 @@ static size_t point_fac_bytes(int nx, int ny, int nz, int is_complex, int flags)
 {
     using TB = emg::PointTile;
     if (emg::point_tiled(nx, ny, nz, g_point_tile_min)) {
-        const bool half = is_complex ? pst_stored_half<cplx>(flags) : true;
-        return emg::tile_pst_elems(nx, ny, nz, TB::BX, TB::BY, TB::BZ) * (half ? 8 : 16);
+        const int mode = is_complex ? pst_mode<cplx>(flags) : pst_mode<double>(flags);
+        return emg::tile_pst_elems(nx, ny, nz, TB::BX, TB::BY, TB::BZ) * emg::tile_pst_bytes(mode);
     }
     const Sizes S(nx, ny, nz, is_complex);
     return (S.nex + S.ney + S.nez) * S.esz;
@@ -2634,6 +2654,12 @@ static size_t point_fac_bytes(int nx, int ny, int nz, int is_complex, int flags)
 size_t emg3d_point_fac_bytes(int nx, int ny, int nz, int is_complex)
 {
     return point_fac_bytes(nx, ny, nz, is_complex, 0);      // flags = 0: the larger layout
+}
+int emg3d_point_compact_used(const emg3d_level *lv)
+{
+    if (!lv || !emg::point_tiled(lv->nx, lv->ny, lv->nz, g_point_tile_min)) return 0;
+    const int mode = lv->is_complex ? pst_mode<cplx>(lv->flags) : pst_mode<double>(lv->flags);
+    return mode == emg::PST_HALF_F32 || mode == emg::PST_FULL_F32;
 }
 size_t emg3d_point_fac_bytes_lv(const emg3d_level *lv)
 {
@@ -2648,12 +2674,19 @@ int emg3d_dev_point_setup(const emg3d_level *lv, void *fac, void *stream)
         using TB = emg::PointTile;
         const emg::TileCount n = emg::tile_count<TB>(lv->nx, lv->ny, lv->nz);
         const dim3 g(n.x, n.y, n.z), b(TB::THREADS);
-        if (!lv->is_complex)
-            hipLaunchKernelGGL((k_point_setup_tile<double, TB, true>), g, b, 0, st, to_level<double>(lv), fac);
-        else if (pst_stored_half<cplx>(lv->flags))
-            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, true>), g, b, 0, st, to_level<cplx>(lv), fac);
+        const int mode = lv->is_complex ? pst_mode<cplx>(lv->flags) : pst_mode<double>(lv->flags);
+        if (!lv->is_complex && mode == emg::PST_HALF_F32)
+            hipLaunchKernelGGL((k_point_setup_tile<double, TB, emg::PST_HALF_F32>), g, b, 0, st, to_level<double>(lv), fac);
+        else if (!lv->is_complex)
+            hipLaunchKernelGGL((k_point_setup_tile<double, TB, emg::PST_HALF>), g, b, 0, st, to_level<double>(lv), fac);
+        else if (mode == emg::PST_HALF_F32)
+            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, emg::PST_HALF_F32>), g, b, 0, st, to_level<cplx>(lv), fac);
+        else if (mode == emg::PST_HALF)
+            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, emg::PST_HALF>), g, b, 0, st, to_level<cplx>(lv), fac);
+        else if (mode == emg::PST_FULL_F32)
+            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, emg::PST_FULL_F32>), g, b, 0, st, to_level<cplx>(lv), fac);
         else
-            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, false>), g, b, 0, st, to_level<cplx>(lv), fac);
+            hipLaunchKernelGGL((k_point_setup_tile<cplx, TB, emg::PST_FULL>), g, b, 0, st, to_level<cplx>(lv), fac);
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -297,8 +297,16 @@ inline size_t tile_pst_elems(int nx, int ny, int nz, int bx, int by, int bz)
 {
     return (size_t)cdiv(nx - 1, bx) * cdiv(ny - 1, by) * cdiv(nz - 1, bz) * 6 * (size_t)(bx * by * bz);
 }
+// MODE (the ST of k_gs_point_tile): 2 full values (T); 3 stored halves (double); and, on levels that solve a correction
+// equation (LEVEL_POINT_COMPACT: the sums are coefficients of the smoother's local systems -- rounded to single precision
+// they perturb the smoother by 6e-8 relative, not the equation), 4 stored halves as float, 5 full values as compact_of<T>
+constexpr int PST_FULL = 2, PST_HALF = 3, PST_HALF_F32 = 4, PST_FULL_F32 = 5;
+EMG_HD constexpr size_t tile_pst_bytes(int mode)
+{
+    return mode == PST_FULL ? 16 : mode == PST_HALF_F32 ? 4 : 8;      // (per COMPLEX value; real fields: halves only)
+}
 // setup: thread t of the workgroup of tile (tx,ty,tz) writes the sums of its four nodes
-template <class T, class TB, bool IMAG>
+template <class T, class TB, int MODE>
 EMG_HD void tile_pst_setup(const Level<T> &L, void *pst, int ntx, int nty, int tx, int ty, int tz, int t)
 {
     const int x0 = 1 + tx * TB::BX, y0 = 1 + ty * TB::BY, z0 = 1 + tz * TB::BZ;
@@ -310,13 +318,16 @@ EMG_HD void tile_pst_setup(const Level<T> &L, void *pst, int ntx, int nty, int t
         for (int r = 0; r < 6; ++r) {
             const size_t o = tile_pst_index<TB>(ntx, nty, tx, ty, tz, c, r, t);
             const T v = ok ? in.st[r] : zero<T>();
-            if (IMAG) reinterpret_cast<double *>(pst)[o] = imag_of(v);
+            using CT = typename compact_of<T>::type;
+            if (MODE == PST_HALF) reinterpret_cast<double *>(pst)[o] = imag_of(v);
+            else if (MODE == PST_HALF_F32) reinterpret_cast<float *>(pst)[o] = (float)imag_of(v);
+            else if (MODE == PST_FULL_F32) reinterpret_cast<CT *>(pst)[o] = narrow<CT>(v);
             else reinterpret_cast<T *>(pst)[o] = v;
         }
     }
 }
 // smoother: the six sums of thread t's node of colour class `colour` in tile (tx,ty,tz)
-template <class T, class TB, bool IMAG>
+template <class T, class TB, int MODE>
 EMG_HD void tile_pst_load(const void *pst, int ntx, int nty, int tx, int ty, int tz, int colour, int t, PointIn<T> &in)
 {
     const size_t o = tile_pst_index<TB>(ntx, nty, tx, ty, tz, colour, 0, t);
@@ -327,7 +338,10 @@ EMG_HD void tile_pst_load(const void *pst, int ntx, int nty, int tx, int ty, int
     for (int r = 0; r < 6; ++r)
 #endif
     {
-        if (IMAG) in.st[r] = from_stored<T>(reinterpret_cast<const double *>(pst)[o + (size_t)r * TB::THREADS]);
+        using CT = typename compact_of<T>::type;
+        if (MODE == PST_HALF) in.st[r] = from_stored<T>(reinterpret_cast<const double *>(pst)[o + (size_t)r * TB::THREADS]);
+        else if (MODE == PST_HALF_F32) in.st[r] = from_stored<T>((double)reinterpret_cast<const float *>(pst)[o + (size_t)r * TB::THREADS]);
+        else if (MODE == PST_FULL_F32) in.st[r] = widen(reinterpret_cast<const CT *>(pst)[o + (size_t)r * TB::THREADS]);
         else in.st[r] = reinterpret_cast<const T *>(pst)[o + (size_t)r * TB::THREADS];
     }
 }

@@ -42,6 +42,8 @@ constexpr int LEVEL_ETA_IMAG = 1;
 // kept in full precision elsewhere): the streamed line passes may keep their T and w records in single precision
 // (kernels.hip: line_compact_used, k_line_stream<.., COMPACT>)
 constexpr int LEVEL_LINE_COMPACT = 2;
+// ... and the tiled point smoother may keep its eta edge sums (coefficients of its 6 x 6 systems) in single precision
+constexpr int LEVEL_POINT_COMPACT = 4;
 template <class T> EMG_HD Level<T> source_level(Level<T> L, int b)
 {
     size_t o = (size_t)b * L.bstride;

@@ -51,15 +51,47 @@ class Field:
             self._shapes = (grid.shape_faces_x, grid.shape_faces_y, grid.shape_faces_z)
         self._sizes = tuple(int(np.prod(sh)) for sh in self._shapes)
         n = sum(self._sizes)
-        if data is None:
-            self._field = np.zeros(n, dtype=dtype)
-        else:
-            self._field = np.asarray(data, dtype=dtype)
-            if self._field.shape != (n,):
+        self._n, self._dtype = n, np.dtype(dtype)
+        # The dense buffer exists from the first time somebody looks at it (``field``, ``fx`` ...). Until then a
+        # field without data is zero, or zero except for the few entries a source routine deposited
+        # (``_deposit``): a dipole source on 384 x 256 x 256 cells is a dozen numbers, its dense form 1.2 GB --
+        # whose norm and whose way to the GPU cost a solve ~100 ms each (solver.solve reads ``_untouched``).
+        self._dense = None
+        self._lazy = None
+        if data is not None:
+            self._dense = np.asarray(data, dtype=dtype)
+            if self._dense.shape != (n,):
                 raise ValueError(f"Field data must have shape ({n},); "
-                                 f"provided: {self._field.shape}.")
+                                 f"provided: {self._dense.shape}.")
         self._sval = None
         self._smu0 = None
+
+    @property
+    def _field(self):
+        if self._dense is None:
+            self._dense = np.zeros(self._n, dtype=self._dtype)
+            if self._lazy is not None:
+                self._dense[self._lazy[0]] = self._lazy[1]
+                self._lazy = None
+        return self._dense
+
+    @property
+    def _untouched(self):
+        """True while no dense buffer exists: the field IS its deposited entries (or zero) -- nobody can have
+        modified what was never handed out."""
+        return self._dense is None
+
+    def _deposit(self, index, values):
+        """Entries of a field that is zero elsewhere (unique indices), without creating the dense buffer."""
+        if self._dense is None and self._lazy is None:
+            self._lazy = (index, values)
+        else:
+            self._field[index] = values
+        self._sparse = (index, values)      # (kept for callers that vouch for an unmodified field: parallel.solve)
+
+    @property
+    def dtype(self):
+        return self._dtype
 
     def __repr__(self):
         return (f"{self.__class__.__name__}: {['magnetic', 'electric'][self.electric]}; {self.grid.shape_cells[0]} x "
@@ -260,11 +292,10 @@ def get_point_source_field(grid, coordinates, frequency, strength=1.0):
                     values.append(wi * wj * wk * direction[comp])
         offset += sfield._sizes[comp]
     index = np.array(index, dtype=np.int64)
-    values = (np.array(values) * scale).astype(sfield._field.dtype)
+    values = (np.array(values) * scale).astype(sfield.dtype)
     keep = values != 0
     index, values = index[keep], values[keep]
-    sfield._field[index] = values
-    sfield._sparse = (index, values)
+    sfield._deposit(index, values)
     return sfield
 
 
@@ -338,9 +369,8 @@ def get_magnetic_point_source_field(grid, coordinates, frequency, strength=1.0):
     index = np.array(sorted(acc), dtype=np.int64)
     # H = curl E * zeta / (s mu0): the 1 / (s mu0) of the operator, then strength * (-s mu0) as for every source
     values = np.array([acc[i] for i in index], dtype=complex) / sfield.smu0 * strength * -sfield.smu0
-    values = values.astype(sfield._field.dtype)
-    sfield._field[index] = values
-    sfield._sparse = (index, values)
+    values = values.astype(sfield.dtype)
+    sfield._deposit(index, values)
     return sfield
 
 
@@ -404,12 +434,11 @@ def get_source_field(grid, source, frequency, strength=1.0, length=1.0, **kwargs
     # (100 MB for 128^3) is written once -- zero pages of a fresh allocation stay untouched.
     sfield = Field(grid, frequency=frequency, dtype=None if frequency is not None else np.float64)
     index = np.fromiter(moments.keys(), dtype=np.int64, count=len(moments))
-    values = np.fromiter(moments.values(), dtype=np.float64, count=len(moments)).astype(sfield._field.dtype)
+    values = np.fromiter(moments.values(), dtype=np.float64, count=len(moments)).astype(sfield.dtype)
     values = values * strength
     if frequency is not None:
         values = values * -sfield.smu0
-    sfield._field[index] = values
-    sfield._sparse = (index, values)     # valid only while the field is not modified (parallel.solve)
+    sfield._deposit(index, values)       # (no dense buffer until somebody asks for it: Field._untouched)
     sfield._segments = (pts, complex(strength) if np.iscomplexobj(strength) else float(strength))
     return sfield
 

@@ -146,7 +146,13 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     var.smoother_omega = _check_omega(extra['smoother_omega'])
     var.residual_form = _residual_form(extra['residual_form'], var, model, sfield)
     var.residual_form_auto = isinstance(extra['residual_form'], str)      # 'auto': may still switch on a stall
-    var.sparse_source = bool(extra['_sparse_source']) and getattr(sfield, '_sparse', None) is not None
+    # the source as its few non-zero entries: when the caller vouches for an unmodified field (parallel.solve), or when
+    # the field's dense buffer has never been handed out (fields.Field._untouched: a source straight from
+    # get_source_field) -- its norm and its upload are then a dozen numbers instead of two passes over 1.2 GB
+    var.sparse_source = ((bool(extra['_sparse_source']) or getattr(sfield, '_untouched', False))
+                         and getattr(sfield, '_sparse', None) is not None)
+    if var.sparse_source and not extra['_sparse_source']:
+        sfield._assemble_on_device = False
     var.download = bool(extra['_download'])
     var.l2_refe = _host_norm(sfield._sparse[1] if var.sparse_source else sfield.field)
     var.error_at_cycle[0] = var.l2_refe
@@ -156,7 +162,7 @@ def solve(model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=Tru
     if var.l2_refe < 100 * np.finfo(float).tiny:         # zero source: zero field
         var.l2_refe = np.nan
         note = _nothing_to_do(var, "   > RETURN ZERO E-FIELD (provided sfield is zero)\n")
-        efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
+        efield = fields.Field(model.grid, dtype=sfield.dtype, frequency=sfield._frequency)
 
     _log_table_head(var)
     if extra['hierarchy'] is not None:
@@ -192,15 +198,15 @@ def _start_field(model, vmodel, sfield, efield, always_return, var):
     at the end; or the caller's, updated in place after its PEC faces were zeroed -- and left
     alone if it already satisfies the tolerance. Returns (efield, note for the log)."""
     if efield is None:
-        efield = fields.Field(model.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
+        efield = fields.Field(model.grid, dtype=sfield.dtype, frequency=sfield._frequency)
         efield._is_zero = True
         var.do_return = True
         return efield, ""
-    if sfield.field.dtype != efield.field.dtype:
+    if sfield.dtype != efield.dtype:
         raise ValueError(
             "Source field and electric field must have the same "
             "dtype; complex (f-domain) or real (s-domain). Provided:"
-            f"sfield: {sfield.field.dtype}; efield: {efield.field.dtype}.")
+            f"sfield: {sfield.dtype}; efield: {efield.dtype}.")
     if efield.frequency is None:
         efield._frequency = sfield._frequency
     # tangential components on the six boundary faces (PEC)
@@ -305,7 +311,7 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     for sf in sfields:
         if sf.frequency is None:
             raise ValueError("Source field is missing frequency information.")
-        if sf.grid != first.grid or sf._frequency != first._frequency or sf.field.dtype != first.field.dtype:
+        if sf.grid != first.grid or sf._frequency != first._frequency or sf.dtype != first.dtype:
             raise ValueError("solve_batch: all sources must share grid and frequency.")
     vmodel = models.VolumeModel(model, first)
     def new_var():
@@ -345,11 +351,14 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
     n = top.grid.n_edges
     efields = []
     for b, (sf, v) in enumerate(zip(sfields, vars_)):
-        sparse = getattr(sf, '_sparse', None) is not None and bool(getattr(sf, '_trust_sparse', False))
+        sparse = getattr(sf, '_sparse', None) is not None and (bool(getattr(sf, '_trust_sparse', False)) or
+                                                               getattr(sf, '_untouched', False))
+        if sparse and not getattr(sf, '_trust_sparse', False):
+            sf._assemble_on_device = False
         v.l2_refe = _host_norm(sf._sparse[1] if sparse else sf.field)
         v.error_at_cycle[0] = v.l2_refe
         hier.put_source(sf, top.s[b * n:(b + 1) * n], sparse)
-        efields.append(fields.Field(model.grid, dtype=sf.field.dtype, frequency=sf._frequency))
+        efields.append(fields.Field(model.grid, dtype=sf.dtype, frequency=sf._frequency))
     top.zero_field()
     nonzero = [v.l2_refe >= 100 * np.finfo(float).tiny for v in vars_]
     if var.sslsolver:
@@ -618,7 +627,9 @@ class Hierarchy:
         ``parallel.solve``, which makes the field itself, asks for it) -- a dipole touches a
         handful of edges, the dense field is 100 MB at 128^3."""
         sp = getattr(sfield, '_sparse', None) if sparse else None
-        seg = getattr(sfield, '_segments', None) if sparse else None
+        # (the device assembly rounds differently from the host routine, 1e-13: only for callers that ask for it by
+        #  `_sparse_source`; an untouched field goes up as the host routine's own values)
+        seg = getattr(sfield, '_segments', None) if (sparse and getattr(sfield, '_assemble_on_device', True)) else None
         if seg is not None and out.device.type == 'cuda':
             # a dipole / wire made by get_source_field and not modified since: assembled on the
             # device from its few points (csrc/adjoint.h), nothing field-sized crosses PCIe
@@ -809,7 +820,7 @@ def restriction(model, sfield, residual, sc_dir):
     lv.r.copy_(torch.from_numpy(np.ascontiguousarray(residual.field)))
     c = lv.restrict_to(sc_dir)
     cs = fields.Field(c.grid, c.s.cpu().numpy(), frequency=sfield._frequency)
-    ce = fields.Field(c.grid, dtype=sfield.field.dtype, frequency=sfield._frequency)
+    ce = fields.Field(c.grid, dtype=sfield.dtype, frequency=sfield._frequency)
     return _CoarseModel(c), cs, ce
 
 
@@ -821,7 +832,7 @@ def prolongation(efield, cefield, sc_dir):
     m = _M()
     m.grid, m.case = efield.grid, 'isotropic'
     one = np.ones(efield.grid.shape_cells, order='F')
-    m.eta_x = m.eta_y = m.eta_z = one.astype(efield.field.dtype)
+    m.eta_x = m.eta_y = m.eta_z = one.astype(efield.dtype)
     m.zeta = one
     lv = _level_for(m, efield, efield)
     c = lv.child(sc_dir)['level']

@@ -108,6 +108,13 @@ typedef struct emg3d_level {
  * and 184 instead of 304 B per cell and direction of factor memory. Set it BEFORE emg3d_dev_line_setup and keep it:
  * set-up, emg3d_line_fac_bytes_lv and the smoother read it from the level. Unset (0): everything fp64. */
 #define EMG3D_LEVEL_LINE_COMPACT 2
+/* POINT_COMPACT: the same promise (the level solves a correction equation) for the tiled point smoother: its eta edge
+ * sums -- the imaginary (conduction) part of the diagonals of its 6 x 6 systems, emg3d/core.py:377-412, stored per
+ * (tile, node colour, entry, thread) -- are kept in single precision: 24 instead of 48 B per node of the ~360 a sweep
+ * moves (full values, with epsilon_r: 48 instead of 96). A relative perturbation of 6e-8 of those diagonal parts, i.e.
+ * of the smoother, never of the residual the iteration is driven by. emg3d_point_compact_used says whether a level's
+ * point smoother runs that way (flag set and the level large enough for the tiled schedule). */
+#define EMG3D_LEVEL_POINT_COMPACT 4
 
 int emg3d_version(void);
 const char *emg3d_last_error(void);
@@ -152,6 +159,10 @@ int emg3d_device_count(void);
  * "line_compact": 0 (default) compact line records where the level asks for them (EMG3D_LEVEL_LINE_COMPACT), 1 on
  * every level whose direction streams (tests, timing), -1 never (the flag is ignored). CHANGES the rounding of the
  * streamed line solves (see EMG3D_LEVEL_LINE_COMPACT).
+ * "point_compact": the same three values for the eta sums of the tiled point smoother (EMG3D_LEVEL_POINT_COMPACT).
+ * "line_compact_rd" (0 = 8 for x-lines, 4 else), "line_compact_np" (384 | 256), "line_compact_occ" (1 | 2): launch
+ * shape of the compact streamed kernel (prefetch depth of the chain waves, producer threads, workgroups per CU); no
+ * influence on results.
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
  * results); a non-zero value is refused unless the environment variable EMG3D_AMD_ALLOW_DEBUG is set.
  * Out-of-range values of "line_order" (0..2) and "point_order" (0..1) are refused (EMG3D_ERR_BADARG). */
@@ -226,6 +237,7 @@ size_t emg3d_line_fac_bytes(int lr, int nx, int ny, int nz, int is_complex);
  * direction streams; emg3d_line_compact_used says whether), else emg3d_line_fac_bytes -- which is always enough */
 size_t emg3d_line_fac_bytes_lv(const emg3d_level *lv, int lr);
 int emg3d_line_compact_used(const emg3d_level *lv, int lr);
+int emg3d_point_compact_used(const emg3d_level *lv);
 size_t emg3d_line_lfac_bytes(int lr, int nx, int ny, int nz);
 size_t emg3d_gs_scratch_bytes(int lr, int nx, int ny, int nz, int is_complex); /* 0 for lr = 0 */
 

@@ -32,6 +32,7 @@ int g_point_slab = 0;
 int g_point_tile_min = 1 << 20;
 int g_line_order = 1;
 int g_line_wide = 0;
+int g_point_compact = 0;      // 1: the tile-major eta sums stored in single precision (kernels.hip: option point_compact)
 int g_line_compact = 0;       // 1: T and w records of the line passes stored in single precision (kernels.hip: compact k_line_stream)          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
@@ -64,8 +65,10 @@ template <class T> void gs_point_tiled(const emg::Level<T> &L, const void *pst, 
                             emg::point_load_zeta<T>(emg::ZetaTile<E>{ed}, ix, iy, iz, in);
                             emg::point_load_source<T>(L, ix, iy, iz, in);
                             if (pmode == 0) emg::point_load_eta<T, false>(L, nullptr, ix, iy, iz, in);
-                            else if (pmode == 3) emg::tile_pst_load<T, TB, true>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
-                            else emg::tile_pst_load<T, TB, false>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
+                            else if (pmode == 3) emg::tile_pst_load<T, TB, emg::PST_HALF>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
+                            else if (pmode == 4) emg::tile_pst_load<T, TB, emg::PST_HALF_F32>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
+                            else if (pmode == 5) emg::tile_pst_load<T, TB, emg::PST_FULL_F32>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
+                            else emg::tile_pst_load<T, TB, emg::PST_FULL>(pst, n.x, n.y, tx, ty, tz, colour, t, in);
                             if (ok) emg::point_update<T, E>(L, in, ed, ix, iy, iz);
                         }
                     for (int t = 0; t < TB::THREADS; ++t) emg::tile_store<T, TB>(L, lds.data(), x0, y0, z0, t);
@@ -237,15 +240,17 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu, const void *xfac
     if (tiled && (nu & 1)) {
         using TB = emg::PointTile;
         const bool half = std::is_same<T, double>::value || ((nu & 3) == 1 && eta_purely_imaginary<T>(L));
-        pmode = half ? 3 : 2;
+        pmode = half ? (g_point_compact ? 4 : 3) : (g_point_compact ? 5 : 2);
         const emg::TileCount n = emg::tile_count<TB>(nx, ny, nz);
         tpst.assign(emg::tile_pst_elems(nx, ny, nz, TB::BX, TB::BY, TB::BZ) * (half ? 1 : 2), 0.0);
         for (int tz = 0; tz < n.z; ++tz)
             for (int ty = 0; ty < n.y; ++ty)
                 for (int tx = 0; tx < n.x; ++tx)
                     for (int t = 0; t < TB::THREADS; ++t) {
-                        if (half) emg::tile_pst_setup<T, TB, true>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
-                        else emg::tile_pst_setup<T, TB, false>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
+                        if (pmode == 3) emg::tile_pst_setup<T, TB, emg::PST_HALF>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
+                        else if (pmode == 4) emg::tile_pst_setup<T, TB, emg::PST_HALF_F32>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
+                        else if (pmode == 5) emg::tile_pst_setup<T, TB, emg::PST_FULL_F32>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
+                        else emg::tile_pst_setup<T, TB, emg::PST_FULL>(L, tpst.data(), n.x, n.y, tx, ty, tz, t);
                     }
     }
     int iback = 0;
@@ -302,6 +307,7 @@ void emu_set_point_tile_min(int n) { g_point_tile_min = n; }
 void emu_set_line_order(int o) { g_line_order = o; }
 void emu_set_line_wide(int w) { g_line_wide = w; }
 void emu_set_line_compact(int c) { g_line_compact = c; }
+void emu_set_point_compact(int c) { g_point_compact = c; }
 void emu_set_point_order(int o) { emg::point_order_ref() = o; }
 
 void emu_gauss_seidel(const LevelArgs *lv, int lr, int nu)

@@ -878,22 +878,23 @@ def test_batched_compact_line_kernel_equals_single_source(shape, lr, batch):
     n = e0.field.size
     srcs = [s0.field * (1 + b) + (0.3 * b) * rng.standard_normal(n) for b in range(batch)]
     starts = [e0.field * (1.0 - 0.2 * b) for b in range(batch)]
-    single = DeviceLevel.from_host(vm, dev)
-    single.set_line_compact(True)
-    assert lib.emg3d_line_compact_used(single._cref, lr) == 1
-    want = []
-    for b in range(batch):
-        single.s.copy_(torch.from_numpy(srcs[b]))
-        single.e.copy_(torch.from_numpy(starts[b]))
-        single.smooth(lr, 3)
-        want.append(single.e.cpu().numpy())
-    many = DeviceLevel.from_host(vm, dev, batch=batch)
-    many.set_line_compact(True)
-    assert lib.emg3d_line_compact_used(many._cref, lr) == 1
-    many.s.copy_(torch.from_numpy(np.concatenate(srcs)))
-    many.e.copy_(torch.from_numpy(np.concatenate(starts)))
-    many.smooth(lr, 3)
-    got = many.e.cpu().numpy().reshape(batch, n)
+    with _option('line_lpw', 16):     # (16-line workgroups for the single source too: its ~1 250 lines per class would get 8)
+        single = DeviceLevel.from_host(vm, dev)
+        single.set_line_compact(True)
+        assert lib.emg3d_line_compact_used(single._cref, lr) == 1
+        want = []
+        for b in range(batch):
+            single.s.copy_(torch.from_numpy(srcs[b]))
+            single.e.copy_(torch.from_numpy(starts[b]))
+            single.smooth(lr, 3)
+            want.append(single.e.cpu().numpy())
+        many = DeviceLevel.from_host(vm, dev, batch=batch)
+        many.set_line_compact(True)
+        assert lib.emg3d_line_compact_used(many._cref, lr) == 1
+        many.s.copy_(torch.from_numpy(np.concatenate(srcs)))
+        many.e.copy_(torch.from_numpy(np.concatenate(starts)))
+        many.smooth(lr, 3)
+        got = many.e.cpu().numpy().reshape(batch, n)
     for b in range(batch):
         assert np.any(want[b] != starts[b])
         assert np.array_equal(got[b], want[b]), (b, relerr(got[b], want[b]))
@@ -970,6 +971,46 @@ def test_solve_ragged_grids_vs_oracle(shape, kw):
     eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, **kw)
     assert io['exit'] == 0
     assert relerr(e.field, eo.field) < 1e-8
+
+
+@pytest.mark.parametrize('shape', [(36, 20, 18), (40, 24, 33)])
+@pytest.mark.parametrize('dtype,extras', [(complex, False), (float, False), (complex, True)])
+def test_point_tiled_compact_eta_sums_vs_cpu_walk(shape, dtype, extras):
+    """The tiled point smoother with its eta edge sums stored in SINGLE precision (emg3d_level flag POINT_COMPACT:
+    levels that solve a correction equation; 4-byte halves where eta is purely imaginary or the field real, 8-byte
+    pairs with epsilon_r): per sweep against the CPU walk of the same kernel bodies with the same storage (tests/emu,
+    launch.h tile_pst_setup / tile_pst_load: the sums are plain additions, both sides round the same doubles) at the
+    per-sweep tolerance, and against the fp64 sums: different (the storage is narrower), close (6e-8 of the diagonals'
+    conduction parts)."""
+    from emu import emu
+    lib = _lib.lib()
+    grid, vm, s, e0 = _random_level_fields(shape, dtype, sum(shape) + 3, freq=3e6 if extras else 1.3, extras=extras)
+    dev = torch.device('cuda')
+    nu = 3 if (extras and dtype is complex) else 1      # (the CPU walk's rule: full values for nu = 3, 7, ..., halves for 1, 5, ...)
+    out = {}
+    with _option('point_tile_min', 1):
+        for compact in (False, True):
+            lv = DeviceLevel.from_host(vm, dev)
+            if compact:
+                lv.set_line_compact(True)
+            assert bool(lib.emg3d_point_compact_used(lv._cref)) == compact
+            lv.s.copy_(torch.from_numpy(s.field))
+            lv.e.copy_(torch.from_numpy(e0.field))
+            lv.smooth(0, nu)
+            out[compact] = lv.e.cpu().numpy()
+            nbytes = lv.point_factors().numel()
+        assert nbytes * 2 == lib.emg3d_point_fac_bytes(*shape, int(dtype is complex)) // (1 if extras or dtype is float else 2)
+    ref = e0.copy()
+    emu.lib().emu_set_point_tile_min(1)
+    emu.lib().emu_set_point_compact(1)
+    try:
+        emu.gauss_seidel(ref, s, vm, 0, nu)
+    finally:
+        emu.lib().emu_set_point_compact(0)
+        emu.lib().emu_set_point_tile_min(1 << 20)
+    d = relerr(out[True], out[False])
+    assert relerr(out[True], ref.field) < 5e-10, relerr(out[True], ref.field)      # (tolerance of the fp64 test below)
+    assert 1e-12 < d < 1e-5, d
 
 
 @pytest.mark.parametrize('shape', [(36, 20, 18), (16, 8, 8), (18, 34, 10), (40, 24, 33)])
@@ -1862,8 +1903,36 @@ def test_salt384_pair0_one_cycle_vs_oracle_same_order():
     """Config 5's longest pair at full size -- pair 0 (0.25 Hz, the source at x = -2000 m: 9 cycles to 1e-6, 22 to
     1e-10) --: one F-cycle against the oracle in the same ordering, next to pair 7 above. (The pair converged to
     1e-10 against the oracle costs 5.5 min of oracle time on 16 threads, which the suite's time limit does not
-    hold beside the converged configs 2 and 3; builder-run: tools/full_size_converged.py, profiles/.)"""
+    hold beside the converged configs 2 and 3 and pair 7 below; builder-run: tools/full_size_converged.py salt384:0 ->
+    profiles/r06_full_size_converged.txt.)"""
     _one_cycle_vs_oracle('salt384', source_index=0)
+
+
+@pytest.mark.slow
+def test_salt384_pair7_converged_vs_oracle_same_order():
+    """BASELINE.json config 5 at FULL size (384 x 256 x 256), its cheapest pair -- pair 7: 2 Hz, the source at
+    x = +2000 m -- solved to tol 1e-10 with the solver's defaults (compact line records on the 384- and 256-block
+    lines, finest level in residual form) and by the oracle's driver in the same smoother ordering (fp64 throughout):
+    same cycle count, same exit state, converged fields within 1e-8 (BASELINE.json's tolerance; measured ~1e-12).
+    The longest pair (pair 0, 0.25 Hz: 22 cycles, ~5.5 min of oracle time) is builder-run with the same code:
+    tools/full_size_converged.py -> profiles/r06_full_size_converged.txt."""
+    from bench import workload
+    wl = workload('salt384', source_index=7)
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    model = emg3d.Model(grid, **wl['res'])
+    sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    e, info = emg3d.solve(model, sfield, sslsolver=False, tol=1e-10, return_info=True, **wl['opts'])
+    field = e.field.copy()
+    del e, model
+    torch.cuda.empty_cache()
+    ogrid = mg_ref.Grid(grid.h, grid.origin)
+    cond = {k: 1.0 / np.asarray(v, dtype=float) for k, v in wl['res'].items()}
+    vm = mg_ref.volume_model(ogrid, wl['frequency'], cond['property_x'], cond.get('property_y'), cond.get('property_z'))
+    eo, io = mg_ref.solve(vm, mg_ref.Field(ogrid, sfield.field.copy()), tol=1e-10, order=1, **wl['opts'])
+    assert info['exit'] == io['exit'] == 0, (info['exit_message'], io)
+    assert info['it_mg'] == io['it_mg']
+    assert info['rel_error'] == pytest.approx(io['rel_error'], rel=1e-2)
+    assert relerr(field, eo.field) < 1e-8
 
 
 @pytest.mark.parametrize('pair', [3, 5, 6])

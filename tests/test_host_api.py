@@ -98,6 +98,31 @@ def test_source_field_and_volume_model_match_reference_fixtures(golden_solves):
         emg3d.get_source_field(grid, (1e9, 0, 0, 0, 0), 1.0)
 
 
+def test_source_field_has_no_dense_buffer_until_somebody_looks():
+    """A source from get_source_field is its few deposited entries until its dense buffer is asked for
+    (Field._untouched): solve() then takes norm and upload from those entries; once `field` / `fx` ... has been handed
+    out the dense buffer is the truth (it may have been modified), and the deposited entries are exactly what it held."""
+    grid = emg3d.TensorMesh([np.full(12, 10.)] * 3, (-60., -60., -60.))
+    sf = emg3d.get_source_field(grid, (1., 2., 3., 20., 10.), 1.0)
+    assert sf._untouched and sf.dtype == np.complex128 and sf._dense is None
+    idx, val = sf._sparse
+    assert np.unique(idx).size == idx.size
+    e = emg3d.Field(grid, frequency=1.0)
+    assert e._untouched and e.dtype == np.complex128
+    dense = sf.field                        # first look: zeros + the entries
+    assert not sf._untouched and sf._lazy is None
+    assert np.count_nonzero(dense) == idx.size and np.array_equal(dense[idx], val)
+    assert np.linalg.norm(dense) == pytest.approx(np.linalg.norm(val), rel=1e-15)
+    assert sf.fx.base is not None and sf.fx.shape == grid.shape_edges_x
+    # deposits into a field that already has its buffer land in it
+    g = emg3d.Field(grid, frequency=1.0)
+    g.field[3] = 7.
+    g._deposit(np.array([5]), np.array([2. + 0j]))
+    assert g.field[3] == 7. and g.field[5] == 2. and not g._untouched
+    # a Laplace-domain source is real
+    assert emg3d.get_source_field(grid, (1., 2., 3., 20., 10.), -1.0).dtype == np.float64
+
+
 def test_source_field_moment_and_finite_dipole():
     grid = emg3d.TensorMesh([widths(4, 2, 10, 1.5)] * 3, (-50, -50, -50))
     vec = emg3d.get_source_field(grid, (1.3, -2.2, 4.1, 30, 10), None)
