@@ -346,6 +346,8 @@ def run_cycles(top, var):
         resform = var.residual_form = True
     if resform:
         top._b_valid = False
+    if getattr(top, '_resmode', None) is not None:      # (left behind by a solve that was interrupted: this solve's
+        top._resmode = None                             #  field and source are in the level's own buffers)
     l2_last = top.residual(store=resform, norm=True)
     ring = np.full(var.maxcycle, l2_last)           # errors one round of the schedule ago
     var.cprint("     it cycmax               error", 4)
@@ -360,6 +362,13 @@ def run_cycles(top, var):
         if resform:
             top.residual(store=True, norm=False)
     fixed = getattr(var, 'fixed_cycles', None)
+    try:
+        _finest_level_loop(top, var, resform, l2_last, ring, fixed, loud)
+    finally:
+        _leave(top)             # (residual form: the field and the source back into the level's own buffers)
+
+
+def _finest_level_loop(top, var, resform, l2_last, ring, fixed, loud):
     it = 0
     while True:
         l2_prev = l2_last
@@ -412,6 +421,12 @@ def run_cycles(top, var):
         if terminate(var, l2_last, l2_stag, it):
             break
     var.l2 = l2_last
+
+
+def _leave(top):
+    leave = getattr(top, 'leave_residual_form', None)
+    if leave is not None:
+        leave()
 
 
 def _can_switch(top):

@@ -354,45 +354,76 @@ class DeviceLevel:
             self._b_valid = False
         _ = self.r
 
+    # Residual form without per-cycle copies. While it lasts the solve's field and source live in `_x_kept` /
+    # `_b_kept`; a cycle runs on (e, s) = (d, r): the residual buffer becomes the source by SWAPPING the two tensors
+    # (and the pointers of the level struct), the correction is accumulated into `_x_kept`, and between cycles
+    # `residual` works on (_x_kept, _b_kept). `_resmode`: None direct form, 'idle' between cycles, 'cycle' inside one.
+    # Per cycle: one fill and one fused update (round 5: three copies more, ~1 ms of a 256^3 cycle).
+    def _swap_s_r(self):
+        _ = self.r
+        self.s, self._r = self._r, self.s
+        self._c.sx, self._c.sy, self._c.sz = (ctypes.c_void_p(p) if not isinstance(p, ctypes.c_void_p) else p
+                                                for p in self.parts(self.s))
+
     def to_residual_equation(self):
-        """Before a cycle: r = s - A e is in ``self.r`` (residual(store=True)). Keeps e and s aside,
-        then s <- r, e <- 0."""
+        """Before a cycle: r = s - A x is in ``self.r`` (residual(store=True)). First time: keeps the field and the
+        source aside. Then s <- r (tensor swap), e <- 0."""
         nbytes = self.e.numel() * self.e.element_size()
         self.reserve_residual_equation()
         cp = _lib.lib().emg3d_dev_copy
-        _lib.check(cp(_ptr(self._x_kept), _ptr(self.e), nbytes, _stream()), 'emg3d_dev_copy')
-        if not self._b_valid:                     # the source of a solve does not change between its cycles
-            _lib.check(cp(_ptr(self._b_kept), _ptr(self.s), nbytes, _stream()), 'emg3d_dev_copy')
-            self._b_valid = True
-        _lib.check(cp(_ptr(self.s), _ptr(self.r), nbytes, _stream()), 'emg3d_dev_copy')
+        if self.__dict__.get('_resmode') is None:
+            _lib.check(cp(_ptr(self._x_kept), _ptr(self.e), nbytes, _stream()), 'emg3d_dev_copy')
+            if not self._b_valid:                 # the source of a solve does not change between its cycles
+                _lib.check(cp(_ptr(self._b_kept), _ptr(self.s), nbytes, _stream()), 'emg3d_dev_copy')
+                self._b_valid = True
+        self._swap_s_r()
         self.zero_field()
+        self._resmode = 'cycle'
 
     def from_residual_equation(self):
-        """After the cycle: e <- e_kept + d (one fused update), s <- the solve's source."""
+        """After the cycle: x_kept += d (one fused update); the residual buffer is free again."""
         xs = (ctypes.c_void_p * 2)(self._x_kept.data_ptr(), self.e.data_ptr())
         slots = (ctypes.c_int * 2)(-1, -1)
         scales = (ctypes.c_double * 2)(1.0, 1.0)
         none_p, none_i = (ctypes.c_void_p * 1)(), (ctypes.c_int * 1)()
         w = self.work
         _lib.check(_lib.lib().emg3d_dev_krylov_step(
-            self.e.numel(), int(self.is_complex), _ptr(self.e), 2, xs, slots, scales, 0, none_p, none_p, none_i, 0, none_i,
-            _ptr(w.ws), _ptr(w.ws), w.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
-        _lib.check(_lib.lib().emg3d_dev_copy(_ptr(self.s), _ptr(self._b_kept), self.s.numel() * self.s.element_size(),
-                                             _stream()), 'emg3d_dev_copy')
+            self.e.numel(), int(self.is_complex), _ptr(self._x_kept), 2, xs, slots, scales, 0, none_p, none_p, none_i, 0,
+            none_i, _ptr(w.ws), _ptr(w.ws), w.ws.numel(), _stream()), 'emg3d_dev_krylov_step')
+        self._swap_s_r()
+        self._resmode = 'idle'
 
-    def abandon_residual_equation(self):
-        """A cycle in residual form was interrupted: e <- e_kept, s <- the solve's source."""
+    def solution(self):
+        """The tensor that holds the solve's field right now (between the cycles of a residual-form solve: the
+        accumulated ``_x_kept``; ``e`` otherwise)."""
+        return self._x_kept if self.__dict__.get('_resmode') == 'idle' else self.e
+
+    def leave_residual_form(self):
+        """End of a residual-form solve: e <- the accumulated field, s <- the solve's source."""
+        mode = self.__dict__.get('_resmode')
+        if mode is None:
+            return
+        if mode == 'cycle':
+            self._swap_s_r()
         nbytes = self.e.numel() * self.e.element_size()
         cp = _lib.lib().emg3d_dev_copy
         _lib.check(cp(_ptr(self.e), _ptr(self._x_kept), nbytes, _stream()), 'emg3d_dev_copy')
         _lib.check(cp(_ptr(self.s), _ptr(self._b_kept), nbytes, _stream()), 'emg3d_dev_copy')
+        self._resmode = None
+
+    def abandon_residual_equation(self):
+        """A cycle in residual form was interrupted: e <- the field before it, s <- the solve's source."""
+        self.leave_residual_form()
 
     def residual(self, store=True, norm=False):
         """r = s - A e into self.r (store) and/or its l2-norm (norm; synchronises)."""
         lib = _lib.lib()
         rx, ry, rz = self.parts(self.r) if store else (None, None, None)
         w = self.work
-        _lib.check(lib.emg3d_dev_residual(self._cref, rx, ry, rz, _ptr(w.ws), w.ws.numel(),
+        cref = self._cref
+        if self.__dict__.get('_resmode') == 'idle':      # between the cycles of a residual-form solve: the true equation
+            cref = ctypes.byref(self._level_on(self._x_kept, self._b_kept))
+        _lib.check(lib.emg3d_dev_residual(cref, rx, ry, rz, _ptr(w.ws), w.ws.numel(),
                                           _ptr(w.sumsq) if norm else None, _stream()),
                    'emg3d_dev_residual')
         if norm and self.batch > 1:

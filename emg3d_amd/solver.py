@@ -402,6 +402,8 @@ def _multigrid_batch(lv, svar, vars_, active=None):
             v.residual_form = True
     if resform:
         lv._b_valid = False
+    if getattr(lv, '_resmode', None) is not None:      # (left behind by an interrupted solve)
+        lv._resmode = None
     l2_last = lv.residual(store=resform, norm=True)
     l2_stag = np.ones((nb, svar.maxcycle)) * l2_last[:, None]
     active = [True] * nb if active is None else list(active)
@@ -461,7 +463,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
             if finished:
                 active[b] = False
                 v.l2 = float(l2_last[b])
-                done[b] = lv.e[b * n:(b + 1) * n].clone()
+                done[b] = lv.solution()[b * n:(b + 1) * n].clone()      # (residual form: the accumulated field)
         if switch and any(active):
             # From the next cycle on the WHOLE batch cycles on the residual equation (one set of launches serves
             # all right-hand sides): after a switch a source's arithmetic depends on its batch-mates -- every
@@ -476,6 +478,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
             for b, v in enumerate(vars_):
                 if active[b]:
                     v.residual_form_switched = True
+    lv.leave_residual_form()
     return done, failed
 
 

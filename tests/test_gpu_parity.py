@@ -1446,7 +1446,7 @@ def test_solve_batch_equals_separate_solves(kw):
     srcs = [(-120., 20., -40., 0., 0.), (30., -60., 10., 45., 10.), (0., 0., 0., 90., 0.),
             ([-200., 150.], [-100., 90.], [-30., 60.])]
     sfields = [emg3d.get_source_field(grid, s if len(s) == 5 else np.array(s).T, 0.9) for s in srcs]
-    sfields[2]._field *= 1e-3          # a weaker source: same relative tolerance, other history
+    sfields[2].field *= 1e-3           # a weaker source: same relative tolerance, other history
     sfields[2]._sparse = None
     sep = [emg3d.solve(model, sf, sslsolver=False, tol=1e-7, return_info=True, **kw) for sf in sfields]
     bat = emg3d.solve_batch(model, sfields, tol=1e-7, **kw)
