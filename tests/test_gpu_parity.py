@@ -2332,8 +2332,10 @@ def test_bench_two_ranks_through_its_own_launcher(backend):
 
 
 @pytest.mark.slow
-def test_bench_eight_ranks_dry_run_on_one_gpu():
-    """`python bench.py --gpus 8 --workload marine128` -- BASELINE.json config 4 at its real rank count -- as the
+@pytest.mark.parametrize('wlname', ['marine128', 'salt384'])
+def test_bench_eight_ranks_dry_run_on_one_gpu(wlname):
+    """`python bench.py --gpus 8 --workload marine128` (and `salt384`: config 5, eight (source, frequency) pairs shared
+    out longest-first, 8 x ~24 GB of hierarchies on the one GPU) -- BASELINE.json configs 4 / 5 at their real rank count -- as the
     driver's scaling run calls it, with the eight ranks sharing this box's one GPU and their collectives over gloo
     (EMG3D_BENCH_BACKEND): process-group setup, the model broadcast to seven receiving ranks, one source per rank,
     barrier, MAX / SUM reductions, the rank-0 JSON line. So that the first 8-GPU run is not the first execution of
@@ -2344,7 +2346,7 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     env = dict(os.environ, EMG3D_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--workload', 'marine128',
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--workload', wlname,
                         '--steps', '2', '--warmup', '1', '--no-256', '--no-survey', '--no-cpu-baseline'],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -2352,8 +2354,11 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 8 and out['steps'] == 2 and out['scaling'] == 'weak'
-    assert out['config']['workload'] == 'marine128' and out['value'] > 0
+    assert out['config']['workload'] == wlname and out['value'] > 0
     assert out['config']['broadcast_ms'] > 0 and 'gloo' in out['config']['model_distribution']
+    # the scalars a scaling run reads: rank count, slowest / fastest rank's clock, the broadcast
+    assert out['broadcast_ms'] == out['config']['broadcast_ms'] and out['backend'] == 'gloo'
+    assert 0 < out['ms_per_step_rank_min'] <= out['ms_per_step_rank_max'] == out['ms_per_step']
     # eight independent sources: the aggregate is the sum over the ranks
     assert out['value'] == pytest.approx(8 * out['config']['cell_sweeps_per_step'] * 2 / (out['ms_per_step'] * 2e-3) / 1e6, rel=0.02)
 

@@ -373,6 +373,45 @@ def test_residual_form_auto_rule():
         rule(benign, 'yes', tol=1e-6)
 
 
+def test_line_compact_auto_rule():
+    """solver.block_condition / COMPACT_COND_MAX: 'auto' keeps the streamed line records in single precision where the
+    block condition estimate 1 / (|s| mu0 sigma_min h_min^2) is at most 1e5 -- the bench workloads are (configs 2, 3,
+    5: 4e2, 1.6e4, 2e4), an air layer of 1e8 Ohm m is not (2e10), nor is a model with a zero conductivity -- from a
+    Model (property arrays + mapping) and from a bare eta / zeta holder alike."""
+    from emg3d_amd import solver, models
+    import bench
+    for name, lo, hi in (('marine64', 1e2, 1e3), ('triaxial64', 5e3, 5e4), ('salt96', 1e2, 1e5)):
+        wl = bench.workload(name)
+        grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+        model = emg3d.Model(grid, **wl['res'])
+        sf = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+        vm = models.VolumeModel(model, sf)
+        c = solver.block_condition(vm)
+        assert lo < c < hi and c <= solver.COMPACT_COND_MAX, (name, c)
+        assert sf._untouched            # (the rule never looks at the source's dense buffer)
+    # air: 1e8 Ohm m on top
+    wl = bench.workload('marine32')
+    grid = emg3d.TensorMesh(wl['h'], wl['origin'])
+    res = {k: np.array(v, dtype=float) for k, v in wl['res'].items()}
+    for v in res.values():
+        v[:, :, -3:] = 1e8
+    sf = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
+    vm = models.VolumeModel(emg3d.Model(grid, **res), sf)
+    assert solver.block_condition(vm) > 1e9
+    # the same number from eta / zeta alone
+    class Holder:
+        pass
+    h = Holder()
+    h.grid, h._sval = vm.grid, vm._sval
+    h.eta_x, h.eta_y, h.eta_z, h.zeta = vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta
+    assert solver.block_condition(h) == pytest.approx(solver.block_condition(vm), rel=1e-12)
+    # a cell that does not conduct at all: beyond any bound, never compact
+    res0 = {k: np.array(v, dtype=float) for k, v in wl['res'].items()}
+    for v in res0.values():
+        v[0, 0, 0] = 1e300
+    assert solver.block_condition(models.VolumeModel(emg3d.Model(grid, **res0), sf)) > 1e200
+
+
 def test_option_table_and_fingerprint():
     """The run-time options of the library: enumerable, settable by name, unknown names refused; the
     fingerprint that keys captured graphs follows a change."""

@@ -55,6 +55,39 @@ def test_smoothers_match_oracle_four_colour(golden_kernels):
                 assert relerr(b.field, a.field) < 2e-12, (name, fn, nu)
 
 
+def test_compact_line_walk_is_a_small_perturbation_of_the_fp64_walk(golden_kernels):
+    """The CPU walk of the line solve with COMPACT records (tests/emu: T records rounded to single precision by the
+    set-up, w records rounded as the forward pass stores them, all arithmetic fp64 -- the definition the HIP kernel
+    k_line_stream<.., COMPACT> is checked against on the GPU) against the fp64 walk: different, and within eps32 x cond
+    of the blocks; the fp64 walk itself is untouched by the option."""
+    g = golden_kernels
+    lib = emu.lib()
+    seen = 0
+    for name in g['meta_cases']:
+        name = str(name)
+        p = name + '_'
+        grid, vm = _case(g, name)
+        s = mg_ref.Field(grid, g[p + 'gs_s'].copy())
+        for fn, lr in LR.items():
+            if lr == 0:
+                continue
+            a = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
+            b = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
+            c = mg_ref.Field(grid, g[p + 'gs_e_in'].copy())
+            emu.gauss_seidel(a, s, vm, lr, 2)
+            lib.emu_set_line_compact(1)
+            try:
+                emu.gauss_seidel(b, s, vm, lr, 2)
+            finally:
+                lib.emu_set_line_compact(0)
+            emu.gauss_seidel(c, s, vm, lr, 2)
+            assert np.array_equal(a.field, c.field)
+            d = relerr(b.field, a.field)
+            assert 1e-10 < d < 1e-3, (name, fn, d)
+            seen += 1
+    assert seen >= 3
+
+
 def test_residual_matches_reference_vectors(golden_kernels):
     g = golden_kernels
     for name in g['meta_cases']:
