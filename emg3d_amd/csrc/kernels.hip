@@ -150,6 +150,8 @@ int g_line_compact_rd = 0;
 // producer waves, 8 rows per chunk: 74 KB -- two workgroups of four waves share a CU and fill each other's start-up,
 // middle-block and drain phases)
 int g_line_compact_occ = 1;
+// ... also on the levels that run k_line_colour with lines of more than LINE_SHORT blocks (1, default; 0: streamed levels only)
+int g_line_compact_colour = 1;
 // producer threads of the compact kernel: 384 (default; six waves) or 256 -- same-box A/B at 256^3, ms per launch
 // x / y / z: 0.732 / 0.780 / 0.770 with four producer waves, 0.697 / 0.766 / 0.764 with six
 int g_line_compact_np = 384;
@@ -747,8 +749,8 @@ __device__ __forceinline__ void quad_forward_step(const Q &q, const T v, const T
     w4p = w4;
 }
 
-template <class T, int HALF, int QD, bool SPLIT = false>
-__device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int qend, int j, const T *fac,
+template <class T, int HALF, int QD, bool SPLIT = false, class FT = T>
+__device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int qline, int qend, int j, const FT *fac,
                                              const double *lfac, const VecRef<T> V, T *dummy, T *dummy4)
 {
     // dummy / dummy4: store targets of surplus quads, in the address spaces of V.base / V.base4
@@ -759,9 +761,9 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
     const int line = min(qline, qend - 1);
     T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
     T *const dslot4 = dummy4 + ((threadIdx.x & 63) >> 2) * 5;
-    QuadRow<T> ring[QD];
-    const LaneAddr<T, HALF, SPLIT> LA(fac, lfac, nlines, line, j, V);
-    auto fetch = [&](QuadRow<T> &q, int i) { q.load(LA, W.fwd(W.clampi(i))); };
+    QuadRow<T, FT> ring[QD];
+    const LaneAddr<T, HALF, SPLIT, FT, T> LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T, FT> &q, int i) { q.load(LA, W.fwd(W.clampi(i))); };
 #pragma unroll
     for (int d = 0; d < QD; ++d) fetch(ring[d], d);
     // Of w_{k-1} the coupling needs: lane j >= 1 its own entry (B(j,j) w_j), everybody w_4,
@@ -774,7 +776,7 @@ __device__ __forceinline__ void quad_forward(int n0, int n0p, int nlines, int ql
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = W.fwd(i0 + d);
-            const QuadRow<T> &q = ring[d];
+            const QuadRow<T, FT> &q = ring[d];
             T wn, w4;
             quad_forward_step(q, q.v, q.v4, nz, is0, wsel, w4p, wn, w4);
             T *const o4 = active ? LA.pv4(k) : dslot4 + 4;
@@ -871,9 +873,9 @@ __device__ __forceinline__ void quad_middle(int n0, int n0p, int nlines, int lin
 // and the ring's 160 are then not live together: the batched kernel must stay under 256
 // registers so that two workgroups share a CU); otherwise the ring fetch is in flight while
 // the middle block is solved.
-template <class T, int DIR, int HALF, int QD, bool MIDFIRST = false, bool SPLIT = false>
+template <class T, int DIR, int HALF, int QD, bool MIDFIRST = false, bool SPLIT = false, class FT = T>
 __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p,
-                                              int qline, int qend, int j, const T *fac, const double *lfac,
+                                              int qline, int qend, int j, const FT *fac, const double *lfac,
                                               const VecRef<T> V, T *dummy, size_t boff = 0)
 {
     const emg::Axes<T, DIR> A(L, boff);
@@ -896,9 +898,9 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
     T *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
     T *const dj = dslot + j, *const d4 = dslot + 4;
 
-    QuadRow<T> ring[QD];
-    const LaneAddr<T, HALF, SPLIT> LA(fac, lfac, nlines, line, j, V);
-    auto fetch = [&](QuadRow<T> &q, int i) {
+    QuadRow<T, FT> ring[QD];
+    const LaneAddr<T, HALF, SPLIT, FT, T> LA(fac, lfac, nlines, line, j, V);
+    auto fetch = [&](QuadRow<T, FT> &q, int i) {
         q.load(LA, min(max(W.bwd(W.clampi(i)), HALF), n0p - 1));   // a half without blocks still prefetches
     };
     if (!MIDFIRST) {
@@ -911,7 +913,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
 
     // x_Q: this lane's entry j (xa) and entry 4 (even lanes) / 5 (odd lanes) (xb)
     T xa, xb;
-    quad_middle<T>(n0, n0p, nlines, line, j, fac, lfac, V, xa, xb);
+    quad_middle<T, FT, T>(n0, n0p, nlines, line, j, fac, lfac, V, xa, xb);
     if (MIDFIRST) {
         asm volatile("" ::: "memory");       // keep the ring fetch behind the middle block
 #pragma unroll
@@ -945,7 +947,7 @@ __device__ __forceinline__ void quad_backward(const emg::Level<T> &L, int colour
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
             const int k = W.bwd(i0 + d);
-            const QuadRow<T> &q = ring[d];
+            const QuadRow<T, FT> &q = ring[d];
             T xn, x4;
             quad_backward_step(q, q.v, q.v4, nz, upA, upD, up04, up44, x[0], x[4], xmine, xn, x4);
             upA = q.bA; upD = q.bD; up04 = q.b04; up44 = q.d4;
@@ -1006,9 +1008,11 @@ constexpr int LC_THREADS = 256;   // workgroup of k_line_colour: 2 chain waves +
 // (16 x n0p x 64 B), slot 4 in the global scratch -- for lines too long for mode 1 (128
 // blocks: 166 KB). The launcher picks the first mode that fits. In LDS the records never leave
 // the CU: no HBM/L2 round trips between the three phases.
-template <class T, int DIR, int VMODE, bool BATCH, int QD = emg::LINE_PAD>
+// FT: storage type of the T records (T, or emg::compact_of<T> on levels with compact line records: the ring holds
+// them as loaded, the steps widen them; the right-hand-side / solution records stay T here -- they live in LDS)
+template <class T, int DIR, int VMODE, bool BATCH, int QD = emg::LINE_PAD, class FT = T>
 __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
-                                                            int lpw, const T *fac, const double *lfac, T *vec,
+                                                            int lpw, const FT *fac, const double *lfac, T *vec,
                                                             T *dummy, size_t vstride)
 {
     // BATCH: grid.y = right-hand side (Level::batch): same factors, own field / source / scratch
@@ -1093,13 +1097,13 @@ __global__ __launch_bounds__(LC_THREADS, BATCH ? 2 : 1) void k_line_colour(emg::
     const int qline = line0 + (wave >> 1) * 16 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
     constexpr bool SPLIT = VMODE == 3;
-    if (half == 0) quad_forward<T, 0, QD, SPLIT>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
-    else quad_forward<T, 1, QD, SPLIT>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
+    if (half == 0) quad_forward<T, 0, QD, SPLIT, FT>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
+    else quad_forward<T, 1, QD, SPLIT, FT>(A.n0(), n0p, nlines, qline, qend, j, fac, lfac, V, dum, dum4);
     __syncthreads();
     // the backward pass stores into the FIELD; its dummy slots must be global memory too, or
     // the address select mixes address spaces and the stores become flat instructions
-    if (half == 0) quad_backward<T, DIR, 0, QD, BATCH, SPLIT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
-    else quad_backward<T, DIR, 1, QD, BATCH, SPLIT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
+    if (half == 0) quad_backward<T, DIR, 0, QD, BATCH, SPLIT, FT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
+    else quad_backward<T, DIR, 1, QD, BATCH, SPLIT, FT>(L, colour, cntp, cntq, n0p, qline, qend, j, fac, lfac, V, dummy, boff);
 }
 
 // ---- the colour pass of SMALL levels with short dependent chains: k_line_wide ----------------------------
@@ -2054,7 +2058,14 @@ template <class T> bool line_compact_used(const emg::Level<T> &L, int dir)
         // decided on the plan of ONE source (a level that streams for one source streams for groups as well: more
         // right-hand sides never mean fewer lines per workgroup), so that a source sees the same records -- and gives
         // the same bits -- alone and in a batch
-        if (line_plan<T>(lc, 1).kind != LK_STREAM || line_plan<T>(lc, L.batch).kind != LK_STREAM) return false;
+        // Also the three-phase kernel on lines of more than LINE_SHORT blocks (its T records only: its w records live
+        // in LDS): the levels with 64- ... 128-block lines are bound by the same factor stream. Both plans must run the
+        // same kind of kernel -- the streamed one rounds its w records, the three-phase one does not.
+        const LinePlan P1 = line_plan<T>(lc, 1), PB = line_plan<T>(lc, L.batch);
+        auto ok = [](const LinePlan &P) {
+            return P.kind == LK_STREAM || (P.kind == LK_COLOUR && !P.shortl && P.vmode >= 0 && P.vmode <= 2 && g_line_compact_colour);
+        };
+        if (!ok(P1) || !ok(PB) || P1.kind != PB.kind) return false;
         any = true;
     }
     return any;
@@ -2108,10 +2119,10 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
 }
 
 template <class T, int DIR>
-void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac, T *vec, hipStream_t st)
+int launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac, T *vec, hipStream_t st)
 {
     const emg::LineClass lc = emg::line_class(DIR, L.nx, L.ny, L.nz, c);
-    if (lc.lines <= 0) return;
+    if (lc.lines <= 0) return 0;
     const dim3 bb = d3(emg::lineblk_block());
     const dim3 bgp = d3(emg::lineblk_grid(lc, true));
     const T *f = fac + lc.fac_off;
@@ -2139,7 +2150,7 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
             hipLaunchKernelGGL((k_line_wide<T, DIR, true>), grid, dim3(nbthr + 64), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf, nbthr);
         else
             hipLaunchKernelGGL((k_line_wide<T, DIR, false>), grid, dim3(nbthr + 64), smem, st, L, c, lc.cntp, lc.cntq, lpw, f, lf, nf, nbthr);
-        return;
+        return 0;
     }
     const LinePlan P = line_plan<T>(lc, L.batch);
     if (P.kind == LK_STREAM) {
@@ -2154,7 +2165,7 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
             else launch_stream_group<T, DIR, 1>(L, c, lc, fv, lf, vec, vstride, b0, P.lpw, st, compact);
             b0 += gs;
         }
-        return;
+        return 0;
     }
     if (P.kind == LK_COLOUR) {
         const int lpw = P.lpw;
@@ -2176,6 +2187,28 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off,                               \
                                (VM == 0 && (g_line_debug & 1)) ? ~(size_t)0 : vstride);                                  \
     } while (0)
+        // compact T records (line_compact_used): the same kernel reading single-precision factor rows
+#define LC_LAUNCH_C(VM)                                                                                                  \
+    do {                                                                                                                 \
+        const FT *fc = reinterpret_cast<const FT *>(fv);                                                                 \
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, VM, false, P4, FT>), lds_cu);              \
+        (void)allow_lds(reinterpret_cast<const void *>(&k_line_colour<T, DIR, VM, true, P4, FT>), lds_cu);               \
+        if (L.batch > 1)                                                                                                 \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, true, P4, FT>), dim3(nwg, L.batch), dim3(LC_THREADS), P.smem, st, \
+                               L, c, lc.cntp, lc.cntq, lc.n0p, lpw, fc, lf, vec, vec + dummy_off, vstride);              \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_line_colour<T, DIR, VM, false, P4, FT>), dim3(nwg), dim3(LC_THREADS), P.smem, st, L, c, \
+                               lc.cntp, lc.cntq, lc.n0p, lpw, fc, lf, vec, vec + dummy_off, vstride);                    \
+    } while (0)
+        if (compact) {
+            if (P.shortl || P.vmode > 2 || g_line_occ2 || (g_line_debug & 1)) {
+                return fail(EMG3D_ERR_BADARG, "gauss_seidel: compact line factors under options that cannot read them");
+            }
+            if (P.vmode == 1) LC_LAUNCH_C(1);
+            else if (P.vmode == 2) LC_LAUNCH_C(2);
+            else LC_LAUNCH_C(0);
+            return 0;
+        }
         if (P.shortl) {
             if (P.vmode == 1) LC_LAUNCH(1, P2);
             else LC_LAUNCH(0, P2);
@@ -2186,9 +2219,13 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                lc.cntp, lc.cntq, lc.n0p, lpw, f, lf, vec, vec + dummy_off, vstride);
         else LC_LAUNCH(0, P4);
 #undef LC_LAUNCH
-        return;
+#undef LC_LAUNCH_C
+        return 0;
     }
     // separate launches (option line_fuse = 0): the right-hand sides one after the other
+    if (compact) {
+        return fail(EMG3D_ERR_BADARG, "gauss_seidel: compact line factors need the fused line kernels (line_fuse)");
+    }
     for (int b = 0; b < L.batch; ++b) {
         const emg::Level<T> Lb = emg::source_level(L, b);
         T *const vb = vec + (size_t)b * vstride;
@@ -2209,6 +2246,7 @@ void launch_line_colour(const emg::Level<T> &L, int c, const T *fac, const doubl
                                lf, (const T *)vb, vb + dummy_off);
         }
     }
+    return 0;
 }
 
 template <class T>
@@ -2320,9 +2358,11 @@ int launch_gs(const emg3d_level *lv, int lr, int nu, const void *fac, const doub
             // one class do not see each other: solving the class again right away reproduces the same
             // values bit by bit. (The reference's sequential sweeps have the same redundant first line.)
             if (g_skip_repeat && cc == 0 && emg::line_pass_repeats(g_line_order, it)) continue;
-            if (lr == 1) launch_line_colour<T, 0>(L, c, (const T *)fac, lfac, (T *)scratch, st);
-            else if (lr == 2) launch_line_colour<T, 1>(L, c, (const T *)fac, lfac, (T *)scratch, st);
-            else launch_line_colour<T, 2>(L, c, (const T *)fac, lfac, (T *)scratch, st);
+            int rc;
+            if (lr == 1) rc = launch_line_colour<T, 0>(L, c, (const T *)fac, lfac, (T *)scratch, st);
+            else if (lr == 2) rc = launch_line_colour<T, 1>(L, c, (const T *)fac, lfac, (T *)scratch, st);
+            else rc = launch_line_colour<T, 2>(L, c, (const T *)fac, lfac, (T *)scratch, st);
+            if (rc != 0) return rc;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -2524,6 +2564,7 @@ static const OptionEntry g_options[] = {
     {"line_wide", &g_line_wide},         {"line_wide_bt", &g_line_wide_bt},     {"line_compact", &g_line_compact},
     {"line_compact_rd", &g_line_compact_rd}, {"line_compact_occ", &g_line_compact_occ},
     {"line_compact_np", &g_line_compact_np}, {"point_compact", &g_point_compact},
+    {"line_compact_colour", &g_line_compact_colour},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value

@@ -33,7 +33,7 @@ int g_point_tile_min = 1 << 20;
 int g_line_order = 1;
 int g_line_wide = 0;
 int g_point_compact = 0;      // 1: the tile-major eta sums stored in single precision (kernels.hip: option point_compact)
-int g_line_compact = 0;       // 1: T and w records of the line passes stored in single precision (kernels.hip: compact k_line_stream)          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
+int g_line_compact = 0;       // 1: T and w records of the line passes stored in single precision (kernels.hip: compact k_line_stream); 2: T only (k_line_colour)          // 1: the line passes in the wide form (stencil.h: line_wide_ref), where the level allows it
 
 // one sweep of the tiled point-smoother schedule: the eight tile-colour launches of
 // kernels.hip (k_gs_point_tile), each workgroup's phases separated like its barriers
@@ -131,7 +131,9 @@ void line_colour(const emg::Level<T> &L, int c, const T *fac, const double *lfac
 // precision by the set-up, the w records rounded when the forward pass stores them -- and with them the raw right-hand
 // sides of the rows the middle block reads, which the producer waves put into the same records --, all arithmetic
 // and the solution in T
-template <class T, int DIR>
+// WT: storage of the w records -- compact_of<T> (the streamed kernel: g_line_compact = 1) or T (the three-phase kernel
+// k_line_colour, whose records live in LDS: g_line_compact = 2)
+template <class T, int DIR, class WT>
 void line_colour_compact(const emg::Level<T> &L, int c, const typename emg::compact_of<T>::type *fac, const double *lfac,
                          T *rhs, T *xout)
 {
@@ -143,14 +145,14 @@ void line_colour_compact(const emg::Level<T> &L, int c, const typename emg::comp
     for_threads(emg::lineblk_grid(lc, true), emg::lineblk_block(), [&](int gx, int gy, int gz) {
         emg::line_rhs_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, rhs);
     });
-    std::vector<FT> w((size_t)5 * lc.n0p * lc.lines);
+    std::vector<WT> w((size_t)5 * lc.n0p * lc.lines);
     const int mk = emg::line_mid(lc.n0);
     for (int lid = 0; lid < lc.lines; ++lid) {
-        for (int r = 0; r < 5; ++r) w[((size_t)mk * lc.lines + lid) * 5 + r] = emg::narrow<FT>(rhs[((size_t)mk * lc.lines + lid) * 5 + r]);
-        w[((size_t)(mk + 1) * lc.lines + lid) * 5] = emg::narrow<FT>(rhs[((size_t)(mk + 1) * lc.lines + lid) * 5]);
+        for (int r = 0; r < 5; ++r) w[((size_t)mk * lc.lines + lid) * 5 + r] = emg::narrow<WT>(rhs[((size_t)mk * lc.lines + lid) * 5 + r]);
+        w[((size_t)(mk + 1) * lc.lines + lid) * 5] = emg::narrow<WT>(rhs[((size_t)(mk + 1) * lc.lines + lid) * 5]);
     }
-    for (int lid = 0; lid < lc.lines; ++lid) emg::line_forward_ref<T, FT, FT>(lc.n0, lc.n0p, lc.lines, lid, f, lf, w.data(), (const T *)rhs);
-    for (int lid = 0; lid < lc.lines; ++lid) emg::line_backward_ref<T, FT, FT>(lc.n0, lc.n0p, lc.lines, lid, f, lf, w.data(), xout);
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_forward_ref<T, FT, WT>(lc.n0, lc.n0p, lc.lines, lid, f, lf, w.data(), (const T *)rhs);
+    for (int lid = 0; lid < lc.lines; ++lid) emg::line_backward_ref<T, FT, WT>(lc.n0, lc.n0p, lc.lines, lid, f, lf, w.data(), xout);
     for_threads(emg::lineblk_grid(lc, false), emg::lineblk_block(), [&](int gx, int gy, int gz) {
         emg::line_scatter_thread<T, DIR>(L, c, lc.cntp, lc.cntq, gx, gy, gz, (const T *)xout);
     });
@@ -269,10 +271,16 @@ template <class T> void gs(const LevelArgs *lv, int lr, int nu, const void *xfac
         }
         for (int cc = 0; cc < 4; ++cc) {
             const int c = emg::line_sweep_colour(g_line_order, it, cc);
+            if (compact && g_line_compact == 2) {
+                if (lr == 1) line_colour_compact<T, 0, T>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                else if (lr == 2) line_colour_compact<T, 1, T>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                else line_colour_compact<T, 2, T>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                continue;
+            }
             if (compact) {
-                if (lr == 1) line_colour_compact<T, 0>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
-                else if (lr == 2) line_colour_compact<T, 1>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
-                else line_colour_compact<T, 2>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                if (lr == 1) line_colour_compact<T, 0, FT>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                else if (lr == 2) line_colour_compact<T, 1, FT>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
+                else line_colour_compact<T, 2, FT>(L, c, facc.data(), lfac.data(), vec.data(), xvec.data());
                 continue;
             }
             if (wide) {

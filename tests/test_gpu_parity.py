@@ -715,6 +715,48 @@ def test_compact_streamed_line_kernel_vs_cpu_walk(shape, lr, lpw, dtype):
     assert dc < 0.1 * d, (dc, d)
 
 
+@pytest.mark.parametrize('shape,lr,opts', [((64, 40, 40), 1, {}), ((40, 63, 40), 2, {}), ((36, 36, 66), 3, {}), ((100, 70, 70), 1, {}),
+                                           ((20, 128, 30), 2, {'line_lpw': 16, 'line_stream': 1}), ((12, 10, 300), 3, {})])
+@pytest.mark.parametrize('dtype', [complex, float])
+def test_compact_three_phase_line_kernel_vs_cpu_walk(shape, lr, opts, dtype):
+    """COMPACT T records on the levels that run k_line_colour (lines of 7 ... ~128 blocks whose right-hand-side /
+    solution records live in LDS -- those stay fp64): per sweep against the CPU walk with single-precision T records and
+    fp64 w records on the kernel's own T records (tests/emu, g_line_compact = 2). Records in LDS (mode 1), slots 0..3 in
+    LDS (mode 2, option line_stream = 1), 4- and 8- and 16-line workgroups."""
+    from emu import emu
+    from contextlib import ExitStack
+    lib = _lib.lib()
+    grid, vm, s, e0 = _random_long_line_level(shape, lr, dtype)
+    dev = torch.device('cuda')
+    out = {}
+    with ExitStack() as stack:
+        for k, v in opts.items():
+            stack.enter_context(_option(k, v))
+        if lib.emg3d_line_kernel_name(lr, *shape, int(dtype is complex), 1) != b'k_line_colour':
+            pytest.skip('not a k_line_colour level for this dtype')
+        for compact in (0, 1):
+            lv = DeviceLevel.from_host(vm, dev)
+            if compact:
+                lv.set_line_compact(True)
+            assert lib.emg3d_line_compact_used(lv._cref, lr) == compact
+            lv.s.copy_(torch.from_numpy(s.field))
+            lv.e.copy_(torch.from_numpy(e0.field))
+            lv.smooth(lr, 3)
+            out[compact] = lv.e.cpu().numpy()
+            fac, lfac = (t.cpu().numpy() for t in lv.line_factors(lr))
+    emu.lib().emu_set_line_compact(2)
+    try:
+        ref = e0.copy()
+        emu.gauss_seidel_fac(ref, s, vm, lr, 3, fac, lfac.view(np.float64))
+    finally:
+        emu.lib().emu_set_line_compact(0)
+    d = relerr(out[1], out[0])
+    dc = relerr(out[1], ref.field)
+    print(f"compact three-phase {shape} lr={lr} {dtype.__name__}: vs fp64 records {d:.2e}, vs CPU walk (same T) {dc:.2e}")
+    assert 1e-10 < d < 3e-2, d
+    assert dc < 5e-12, dc       # (no rounding of w here: nothing can flip; measured 3e-13 complex, 2e-12 real)
+
+
 class _option:
     """Set a run-time option of the library for the duration of a with-block."""
 

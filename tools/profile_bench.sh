@@ -4,7 +4,10 @@
 #   two PMC passes of the same command (separate runs, no trace options combined with --pmc), and
 #   the same three passes over the 256^3 smoother measurement (tools/microbench.py: the north-star
 #   kernel k_gs_point_tile); summaries under gpurun_out/ -- copy what is to be judged to profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
+export PMC_ROUND=$TAG
+# options of the 256^3 smoother measurement (default: the coefficient storage the solver uses on such a model)
+MB_OPTS=${MB_OPTS:---opt line_compact=1 --opt point_compact=1}
 WL=${2:-triaxial256}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -36,10 +39,10 @@ python tools/pmc_summary.py $W > $R/gpurun_out/${TAG}_pmc_write_$WL.txt
 # the 256^3 smoothers (point + lines), nu = 2
 cd /tmp
 M="python $R/tools/microbench.py all --n 256 --slabs \"\""
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/mtrace -o run -- python $R/tools/microbench.py all --n 256 --slabs "" --fused-only > $O/mtrace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/mtrace -o run -- python $R/tools/microbench.py all --n 256 --slabs "" --fused-only $MB_OPTS > $O/mtrace.log 2>&1
 python $R/tools/rocpd_summary.py $O/mtrace/run_results.db > $R/gpurun_out/${TAG}_smoothers256_kernel_stats.txt
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/mf -o run -- python $R/tools/microbench.py all --n 256 --slabs "" --fused-only > $O/mf.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/mw -o run -- python $R/tools/microbench.py all --n 256 --slabs "" --fused-only > $O/mw.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/mf -o run -- python $R/tools/microbench.py all --n 256 --slabs "" --fused-only $MB_OPTS > $O/mf.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/mw -o run -- python $R/tools/microbench.py all --n 256 --slabs "" --fused-only $MB_OPTS > $O/mw.log 2>&1
 MF=$(ls $O/mf/*counter_collection.csv | head -1); MW=$(ls $O/mw/*counter_collection.csv | head -1)
 cd $R && python tools/pmc_traffic.py smoothers_256 $MF $MW > $R/gpurun_out/${TAG}_pmc_traffic_smoothers256.log 2>&1
 python tools/pmc_summary.py $MF 16581375 > $R/gpurun_out/${TAG}_pmc_fetch_smoothers256.txt
