@@ -2096,6 +2096,13 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
         const bool rd8 = g_line_compact_rd == 8 || (g_line_compact_rd == 0 && DIR == 0);
         if (compact) kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, NPROD, false, true, true>
                                 : (const void *)&k_line_stream<T, DIR, 1, RD, NPROD, false, true, true>;
+        // rows per ring chunk of the compact kernel: 16 for x-lines (their producers read 16 consecutive blocks of a line as
+        // one contiguous segment), 8 for y / z lines (same-box A/B at 256^3: x 0.709 -> 0.775, y 0.785 -> 0.764, z 0.780 ->
+        // 0.766 ms per launch with 8) unless option line_stream_r names a value
+        if (compact && DIR != 0 && g_line_stream_r == 0 && R > 8) {
+            R = 8;
+            smem_c = (size_t)2 * 2 * R * lpw * 5 * sizeof(T) + (size_t)2 * 2 * R * lpw * 8 * sizeof(double);
+        }
         if (compact && g_line_compact_np == 384) {
             kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, 384, false, true, true>
                        : (const void *)&k_line_stream<T, DIR, 1, RD, 384, false, true, true>;
