@@ -103,7 +103,7 @@ typedef struct emg3d_level {
  * and widened when they are loaded, every operation, every right-hand side and the solution stay fp64. The line
  * solve becomes (A_line (1 + O(eps32 cond(S_k))))^-1 -- a perturbation of the smoother, not of the equation: the
  * iteration converges to the same field at the same rate as long as eps32 x cond of the 5 x 5 blocks (~ 1 / (omega mu
- * sigma h^2)) stays well below the smoothing factor, which is the caller's to check (emg3d_amd.solver: cond <= 1e5).
+ * sigma h^2)) stays well below the smoothing factor, which is the caller's to check (emg3d_amd.solver: cond <= 3e4).
  * What it buys: 120 + 2 x 40 instead of 240 + 2 x 80 B per block and colour pass of the ~1 210 B such a pass moves,
  * and 184 instead of 304 B per cell and direction of factor memory. Set it BEFORE emg3d_dev_line_setup and keep it:
  * set-up, emg3d_line_fac_bytes_lv and the smoother read it from the level. Unset (0): everything fp64. */

@@ -375,7 +375,7 @@ def test_residual_form_auto_rule():
 
 def test_line_compact_auto_rule():
     """solver.block_condition / COMPACT_COND_MAX: 'auto' keeps the streamed line records in single precision where the
-    block condition estimate 1 / (|s| mu0 sigma_min h_min^2) is at most 1e5 -- the bench workloads are (configs 2, 3,
+    block condition estimate 1 / (|s| mu0 sigma_min h_min^2) is at most 3e4 -- the bench workloads are (configs 2, 3,
     5: 4e2, 1.6e4, 2e4), an air layer of 1e8 Ohm m is not (2e10), nor is a model with a zero conductivity -- from a
     Model (property arrays + mapping) and from a bare eta / zeta holder alike."""
     from emg3d_amd import solver, models

@@ -75,7 +75,7 @@ for seed in seeds:
         # that two iterates with the same residual history differ by 1e-8 in the near-null space of the operator)
         ok = same and (err < (1e-7 if (ssl or info['residual_form'] is not False) else 1e-9) or info['exit'] != 0)
         print('SEED', seed, shape, 'case', case, 'f', freq, kw, '| exit', info['exit'], io['exit'], 'cycles', info['it_mg'], io['it_mg'], 'krylov it', info.get('it_ssl'),
-              'rel.err %.3e %.3e' % (info['rel_error'], io['rel_error']), 'fields %.1e' % err, 'residual form', info['residual_form'], 'ok' if ok else 'DIFFERENT', flush=True)
+              'rel.err %.3e %.3e' % (info['rel_error'], io['rel_error']), 'fields %.1e' % err, 'residual form', info['residual_form'], 'compact', info.get('line_compact'), 'ok' if ok else 'DIFFERENT', flush=True)
         bad += 0 if ok else 1
         if os.environ.get('HIST') and not ok:
             print('   gpu   ', ' '.join('%.2e' % x for x in info['error_at_cycle']))
