@@ -152,12 +152,6 @@ int g_line_compact_rd = 0;
 int g_line_compact_occ = 1;
 // ... also on the levels that run k_line_colour with lines of more than LINE_SHORT blocks (1, default; 0: streamed levels only)
 int g_line_compact_colour = 1;
-// ... the w records of the blocks nearest the middle block stay in LDS where the ring leaves room (y / z lines with 8 rows
-// per chunk: ~170 of 256 rows). 0, default: all w records through the scratch -- same bits either way, and FASTER: with
-// the stash the same-box A/B at 256^3 reads 0.679 / 0.734 / 0.746 -> 0.712 / 0.767 / 0.779 ms per launch (x / y / z),
-// at 256 x 128 x 128 +10 % -- the second store per chain step and the producers' two-sided loads cost more than the
-// 35 B per block save (profiles/r06_compact_line_kernel_ab.txt). 1: on (kept for the record and its test).
-int g_line_compact_stash = 0;
 // producer threads of the compact kernel: 384 (default; six waves) or 256 -- same-box A/B at 256^3, ms per launch
 // x / y / z: 0.732 / 0.780 / 0.770 with four producer waves, 0.697 / 0.766 / 0.764 with six
 int g_line_compact_np = 384;
@@ -1515,29 +1509,21 @@ constexpr int LS_PROD = 384;                 // producer threads of k_line_strea
 // LFR: the coupling entries come from the coupling ring (lfring), not from the lfac records
 // FT / WT: storage types of the T records / the w records (T, or emg::compact_of<T>); vec: the w records of the
 // group's first source as WT, source b's b * vstride elements (of WT) behind them
-// SPLITW (one source): the w records of the rows klo <= row < khi -- the blocks nearest the middle block, written last
-// by the forward pass and read first by the backward pass -- stay in LDS (`stash`: slots 0..3 of a row, [row - klo][lpw]
-// [4]; slot 4 and all other rows in the global scratch, the layout of VecRef's split form): they never travel to HBM.
-// One store into either space per step, the idle one to a dummy slot -- no branch around a memory operation.
-template <class T, int HALF, int RD, int B, bool LFR, class FT = T, class WT = T, bool SPLITW = false>
+template <class T, int HALF, int RD, int B, bool LFR, class FT = T, class WT = T>
 __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines, int qline, int qend, int line0, int j,
                                                       const FT *fac, const double *lfac, WT *vec, size_t vstride,
                                                       size_t dummy_off, const T *ringbase, int lpw, int R, int nchunks,
-                                                      const double *lfring, WT *stash = nullptr, int klo = 0, int khi = 0,
-                                                      WT *ldummy = nullptr)
+                                                      const double *lfring)
 {
-    static_assert(!SPLITW || B == 1, "records in LDS: one source");
     const HalfWalk<HALF> W(n0, n0p);
     const bool active = qline < qend;
     const int line = min(qline, qend - 1);
     const int ll = line - line0;
-    const VecRef<WT> V = SPLITW ? VecRef<WT>{stash - (size_t)klo * lpw * 4, lpw, line0, 4, vec, nlines, 0, vec, nlines, klo, khi}
-                                : VecRef<WT>::global(vec, nlines);
+    const VecRef<WT> V = VecRef<WT>::global(vec, nlines);
     WT *const dummy = vec + dummy_off;                           // (every source's scratch has its dummy slots)
     WT *const dslot = dummy + ((threadIdx.x & 63) >> 2) * 5;
-    WT *const ldslot = ldummy + ((threadIdx.x & 63) >> 2) * 5;   // (SPLITW: the dummy slots of the LDS side)
     QuadRow<T, FT> ring[RD];
-    using LAddr = LaneAddr<T, HALF, SPLITW, FT, WT>;
+    using LAddr = LaneAddr<T, HALF, false, FT, WT>;
     const LAddr LA(fac, lfac, nlines, line, j, V);
     auto fetch = [&](QuadRow<T, FT> &q, int i) { q.template load<LAddr, false, !LFR>(LA, W.fwd(W.clampi(i))); };
 #pragma unroll
@@ -1562,27 +1548,14 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
                     q.take_b(lfring + (size_t)(c & 1) * ((size_t)2 * R * lpw * 8) +
                              ((size_t)(HALF * R + (i0 + d - c * R)) * lpw + ll) * 8, j);
                 WT *const o4 = active ? LA.pv4(k) : dslot + 4;
-                if constexpr (SPLITW) {
-                    const bool in = LA.in_lds(k);
-                    WT *const ol = (active && in) ? LA.pvj(k) : ldslot + j;
-                    WT *const og = (active && !in) ? LA.gpvj(k) : dslot + j;
-                    const T v = it[j], v4 = it[4];
-                    T wn, w4;
-                    quad_forward_step(q, v, v4, nz, is0, wsel[0], w4p[0], wn, w4);
-                    const WT wr = emg::narrow<WT>(wn);
-                    *ol = wr;
-                    *og = wr;
-                    *o4 = emg::narrow<WT>(w4);
-                } else {
-                    WT *const oj = active ? LA.pvj(k) : dslot + j;
+                WT *const oj = active ? LA.pvj(k) : dslot + j;
 #pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const T v = it[b * srcelems + j], v4 = it[b * srcelems + 4];
-                        T wn, w4;
-                        quad_forward_step(q, v, v4, nz, is0, wsel[b], w4p[b], wn, w4);
-                        oj[b * vstride] = emg::narrow<WT>(wn);
-                        o4[b * vstride] = emg::narrow<WT>(w4);
-                    }
+                for (int b = 0; b < B; ++b) {
+                    const T v = it[b * srcelems + j], v4 = it[b * srcelems + 4];
+                    T wn, w4;
+                    quad_forward_step(q, v, v4, nz, is0, wsel[b], w4p[b], wn, w4);
+                    oj[b * vstride] = emg::narrow<WT>(wn);
+                    o4[b * vstride] = emg::narrow<WT>(w4);
                 }
                 fetch(ring[d], i0 + d + RD);
             }
@@ -1596,12 +1569,11 @@ __device__ __forceinline__ void quad_forward_stream(int n0, int n0p, int nlines,
 // row k - 1 for a mirrored block) -- sixteen lines x 80 B are contiguous in the scratch, so the idle
 // producer waves fetch them as wide coalesced loads and the chain quads need neither a register ring
 // nor four scattered 16-byte loads per step for them.
-template <class T, int DIR, class WT = T, bool SPLITW = false>
+template <class T, int DIR, class WT = T>
 __device__ __forceinline__ void stream_produce_w(const WT *vec, int nlines, int n0, int n0p, int line0, int nl, int lpw,
                                                  T *buf, int R, int chunk, int pt, int np,
                                                  const emg::Axes<T, DIR> *A = nullptr, int colour = 0, int cntp = 0,
-                                                 int cntq = 0, double *lfo = nullptr, const WT *stash = nullptr, int klo = 0,
-                                                 int khi = 0)
+                                                 int cntq = 0, double *lfo = nullptr)
 {
     const int mk = emg::line_mid(n0);
     const int items = 2 * R * lpw;
@@ -1613,24 +1585,7 @@ __device__ __forceinline__ void stream_produce_w(const WT *vec, int nlines, int 
         const int lid = line0 + min(ll, nl - 1);
         const WT *const r0 = vec + ((size_t)k * nlines + lid) * 5;
         const WT *const rt = vec + ((size_t)(half ? k - 1 : k) * nlines + lid) * 5;
-        WT a0, a1, a2, a3;
-        const WT a4 = rt[4];
-        if constexpr (SPLITW) {
-            // slots 0..3 of the rows klo .. khi - 1 come from the LDS stash (both sides are read, the one that does not
-            // apply at a fixed address of its space: no branch)
-            const int kt = half ? k - 1 : k;
-            const bool in0 = k >= klo && k < khi, in1 = kt >= klo && kt < khi;
-            const int ls = min(ll, nl - 1);
-            const WT *const l0 = stash + ((size_t)((in0 ? k : klo) - klo) * lpw + ls) * 4;
-            const WT *const l1 = stash + ((size_t)((in1 ? kt : klo) - klo) * lpw + ls) * 4;
-            const WT *const g0 = in0 ? vec + (size_t)lid * 5 : r0;          // (row 0 of the scratch when the stash has it)
-            const WT *const g1 = in1 ? vec + (size_t)lid * 5 : rt;
-            const WT b0 = l0[0], b1 = l1[1], b2 = l1[2], b3 = l1[3];
-            const WT c0 = g0[0], c1 = g1[1], c2 = g1[2], c3 = g1[3];
-            a0 = in0 ? b0 : c0; a1 = in1 ? b1 : c1; a2 = in1 ? b2 : c2; a3 = in1 ? b3 : c3;
-        } else {
-            a0 = r0[0]; a1 = rt[1]; a2 = rt[2]; a3 = rt[3];
-        }
+        const WT a0 = r0[0], a1 = rt[1], a2 = rt[2], a3 = rt[3], a4 = rt[4];
         T *o = buf + ((size_t)(half * R + row) * lpw + ll) * 5;
         o[0] = emg::widen(a0); o[1] = emg::widen(a1); o[2] = emg::widen(a2); o[3] = emg::widen(a3); o[4] = emg::widen(a4);
         if (lfo) {
@@ -1650,11 +1605,11 @@ __device__ __forceinline__ void stream_produce_w(const WT *vec, int nlines, int 
 // the w records come from the LDS ring (stream_produce_w)
 // vec / vstride as in quad_forward_stream (WT); fdummy: dummy store targets of FIELD type for surplus quads and
 // padding blocks (global memory, like the field)
-template <class T, int DIR, int HALF, int RD, int B, bool PAIR, bool LFR, class FT = T, class WT = T, bool SPLITW = false>
+template <class T, int DIR, int HALF, int RD, int B, bool PAIR, bool LFR, class FT = T, class WT = T>
 __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int colour, int cntp, int cntq, int n0p, int qline,
                                                 int qend, int line0, int j, const FT *fac, const double *lfac, WT *vec,
                                                 size_t vstride, T *fdummy, size_t boff0, const T *ringbase, int lpw, int R,
-                                                int nchunks, const double *lfring, WT *stash = nullptr, int klo = 0, int khi = 0)
+                                                int nchunks, const double *lfring)
 {
     const emg::Axes<T, DIR> A(L, boff0);
     const int n0 = A.n0();
@@ -1692,10 +1647,7 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
     const double own0 = j == 0 ? 1.0 : 0.0;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        // (SPLITW: the rows around the middle block -- the raw right-hand sides of rows m, m + 1 and w of rows m - 1,
-        //  m + 1, m + 2 -- are in the stash, slot 4 in the scratch)
-        const VecRef<WT> Vb = SPLITW ? VecRef<WT>{stash - (size_t)klo * lpw * 4, lpw, line0, 4, vec, nlines, 0, vec, nlines, klo, khi}
-                                     : VecRef<WT>::global(vec + b * vstride, nlines);
+        const VecRef<WT> Vb = VecRef<WT>::global(vec + b * vstride, nlines);
         T xa, xb;
         quad_middle<T, FT, WT>(n0, n0p, nlines, line, j, fac, lfac, Vb, xa, xb);
         const T xq0 = quad_bcast<0>(xa), xq4 = quad_bcast<0>(xb), xq5 = quad_bcast<1>(xb);
@@ -1784,11 +1736,10 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
 // precision, rounded once when the set-up / the forward pass stores them and widened when they are loaded; the
 // right-hand sides, the rings, every operation and the solution stay in T. 120 + 2 x 40 instead of 240 + 2 x 80
 // of the ~1 210 B a block costs per colour pass on the levels that live in HBM.
-// SPLITW: srows > 0 rows of w records around the middle block stay in LDS (quad_forward_stream)
-template <class T, int DIR, int B, int RD, int NPROD, bool PAIR, bool LFR, bool COMPACT = false, bool SPLITW = false>
+template <class T, int DIR, int B, int RD, int NPROD, bool PAIR, bool LFR, bool COMPACT = false>
 __global__ __launch_bounds__(128 + NPROD, NPROD == 128 ? 2 : 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                                     int lpw, int R, const void *facv, const double *lfac,
-                                                                    T *vecT, size_t vstrideT, size_t boff0, int srows = 0)
+                                                                    T *vecT, size_t vstrideT, size_t boff0)
 {
     // vecT: the scratch of the group's first right-hand side (source b's: b * vstrideT elements of T behind it);
     // boff0: element offset of the group's first source in the field / source buffers
@@ -1812,19 +1763,13 @@ __global__ __launch_bounds__(128 + NPROD, NPROD == 128 ? 2 : 1) void k_line_stre
     const int smax = max(mk, n0p - 2 - mk);
     const int nchunks = (smax + R - 1) / R;
     const int wave = threadIdx.x >> 6;
-    // the stash of w records (SPLITW): behind the rings; rows klo .. khi - 1 around the middle block, then dummy slots
-    WT *const stash = reinterpret_cast<WT *>(reinterpret_cast<double *>(ringbase + 2 * bufelems) + (LFR ? 2 * lfelems : 0));
-    const int shalf = (srows - 4) / 2;
-    const int klo = SPLITW ? max(mk - 1 - shalf, 0) : 0, khi = SPLITW ? min(mk + 3 + shalf, n0p) : 0;
-    WT *const ldummy = stash + (size_t)max(srows, 0) * lpw * 4;
     if (wave >= 2) {
         // ---- producers: right-hand sides for the forward pass, w records for the backward pass
         const int pt = threadIdx.x - 128;
 #pragma unroll 1
         for (int b = 0; b < B; ++b) {
             const emg::Axes<T, DIR> A(L, boff0 + b * L.bstride);
-            const VecRef<WT> V = SPLITW ? VecRef<WT>{stash - (size_t)klo * lpw * 4, lpw, line0, 4, vec, nlines, 0, vec, nlines, klo, khi}
-                                        : VecRef<WT>::global(vec + b * vstride, nlines);
+            const VecRef<WT> V = VecRef<WT>::global(vec + b * vstride, nlines);
             for (int ll = pt; ll < nl; ll += NPROD) {
                 const int lid = line0 + ll;
                 int i1, i2, l2;
@@ -1856,18 +1801,17 @@ __global__ __launch_bounds__(128 + NPROD, NPROD == 128 ? 2 : 1) void k_line_stre
         const emg::Axes<T, DIR> A0(L, boff0);
 #pragma unroll 1
         for (int b = 0; b < B; ++b)
-            stream_produce_w<T, DIR, WT, SPLITW>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD,
-                                                 &A0, colour, cntp, cntq, (LFR && b == 0) ? lfring : nullptr, stash, klo, khi);
+            stream_produce_w<T, DIR, WT>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw, ringbase + b * srcelems, R, 0, pt, NPROD,
+                                         &A0, colour, cntp, cntq, (LFR && b == 0) ? lfring : nullptr);
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
             if (c + 1 < nchunks) {
 #pragma unroll 1
                 for (int b = 0; b < B; ++b)
-                    stream_produce_w<T, DIR, WT, SPLITW>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
-                                                         ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD,
-                                                         &A0, colour, cntp, cntq,
-                                                         (LFR && b == 0) ? lfring + (size_t)((c + 1) & 1) * lfelems : nullptr,
-                                                         stash, klo, khi);
+                    stream_produce_w<T, DIR, WT>(vec + b * vstride, nlines, n0, n0p, line0, nl, lpw,
+                                                 ringbase + (size_t)((c + 1) & 1) * bufelems + b * srcelems, R, c + 1, pt, NPROD,
+                                                 &A0, colour, cntp, cntq,
+                                                 (LFR && b == 0) ? lfring + (size_t)((c + 1) & 1) * lfelems : nullptr);
             }
             lds_barrier();
         }
@@ -1876,11 +1820,11 @@ __global__ __launch_bounds__(128 + NPROD, NPROD == 128 ? 2 : 1) void k_line_stre
     const int half = wave & 1;
     const int qline = line0 + ((threadIdx.x & 63) >> 2), j = threadIdx.x & 3;
     const int qend = line0 + nl;
-    if (half == 0) quad_forward_stream<T, 0, RD, B, LFR, FT, WT, SPLITW>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, dummy_off, ringbase, lpw, R, nchunks, lfring, stash, klo, khi, ldummy);
-    else quad_forward_stream<T, 1, RD, B, LFR, FT, WT, SPLITW>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, dummy_off, ringbase, lpw, R, nchunks, lfring, stash, klo, khi, ldummy);
+    if (half == 0) quad_forward_stream<T, 0, RD, B, LFR, FT, WT>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, dummy_off, ringbase, lpw, R, nchunks, lfring);
+    else quad_forward_stream<T, 1, RD, B, LFR, FT, WT>(n0, n0p, nlines, qline, qend, line0, j, fac, lfac, vec, vstride, dummy_off, ringbase, lpw, R, nchunks, lfring);
     __syncthreads();
-    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR, LFR, FT, WT, SPLITW>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, fdummy, boff0, ringbase, lpw, R, nchunks, lfring, stash, klo, khi);
-    else quad_backward_stream<T, DIR, 1, RD, B, PAIR, LFR, FT, WT, SPLITW>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, fdummy, boff0, ringbase, lpw, R, nchunks, lfring, stash, klo, khi);
+    if (half == 0) quad_backward_stream<T, DIR, 0, RD, B, PAIR, LFR, FT, WT>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, fdummy, boff0, ringbase, lpw, R, nchunks, lfring);
+    else quad_backward_stream<T, DIR, 1, RD, B, PAIR, LFR, FT, WT>(L, colour, cntp, cntq, n0p, qline, qend, line0, j, fac, lfac, vec, vstride, fdummy, boff0, ringbase, lpw, R, nchunks, lfring);
 }
 
 // End of the spelled-out section: back to the mode the translation unit is compiled with -- -ffp-contract=fast-honor-
@@ -2172,26 +2116,12 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
             smem_c = (size_t)2 * 2 * R * lpw * 5 * sizeof(T) + (size_t)2 * 2 * R * lpw * 8 * sizeof(double);
         }
     }
-    int srows = 0;
-    if constexpr (B == 1) {
-        // the LDS the rings leave free holds the w records (slots 0..3) of the rows around the middle block
-        using WT = typename emg::compact_of<T>::type;
-        const size_t row = (size_t)lpw * 4 * sizeof(WT), dummy = (size_t)16 * 5 * sizeof(WT);
-        const size_t room = (size_t)160 * 1024 > smem_c + dummy ? (size_t)160 * 1024 - smem_c - dummy : 0;
-        if (compact && g_line_compact_stash && g_line_compact_occ != 2 && nprod == 384 && room / row >= 12) {
-            srows = (int)std::min<size_t>(room / row, (size_t)lc.n0p);
-            const bool rd8s = g_line_compact_rd == 8 || (g_line_compact_rd == 0 && DIR == 0);
-            kern = rd8s ? (const void *)&k_line_stream<T, DIR, 1, 8, 384, false, true, true, true>
-                        : (const void *)&k_line_stream<T, DIR, 1, RD, 384, false, true, true, true>;
-            smem_c += (size_t)srows * row + dummy;
-        }
-    }
     (void)allow_lds(kern, 160 * 1024);
     T *v0 = vec + (size_t)b0 * vstride;
     size_t boff0 = (size_t)b0 * L.bstride;
     const unsigned nwg = cdiv(lc.lines, lpw);
     void *args[] = {(void *)&L, (void *)&c, (void *)&lc.cntp, (void *)&lc.cntq, (void *)&lc.n0p, (void *)&lpw, (void *)&R,
-                    (void *)&f, (void *)&lf, (void *)&v0, (void *)&vstride, (void *)&boff0, (void *)&srows};
+                    (void *)&f, (void *)&lf, (void *)&v0, (void *)&vstride, (void *)&boff0};
     (void)hipLaunchKernel(kern, dim3(nwg), dim3(128 + nprod), args, smem_c, st);
 }
 
@@ -2641,7 +2571,7 @@ static const OptionEntry g_options[] = {
     {"line_wide", &g_line_wide},         {"line_wide_bt", &g_line_wide_bt},     {"line_compact", &g_line_compact},
     {"line_compact_rd", &g_line_compact_rd}, {"line_compact_occ", &g_line_compact_occ},
     {"line_compact_np", &g_line_compact_np}, {"point_compact", &g_point_compact},
-    {"line_compact_colour", &g_line_compact_colour}, {"line_compact_stash", &g_line_compact_stash},
+    {"line_compact_colour", &g_line_compact_colour},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);
 static int g_options_generation = 0;      // bumped whenever an option changes its value
