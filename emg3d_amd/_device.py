@@ -244,7 +244,7 @@ class DeviceLevel:
         slots = self.__dict__.get('_slots')
         if slots is None:
             nx, ny, nz = self.grid.shape_cells
-            nf = max(lib.emg3d_line_fac_bytes(d, nx, ny, nz, self.is_complex) for d in (1, 2, 3))
+            nf = max(lib.emg3d_line_fac_bytes_lv(self._cref, d) for d in (1, 2, 3))      # (compact records: smaller)
             nl = max(lib.emg3d_line_lfac_bytes(d, nx, ny, nz) for d in (1, 2, 3))
             slots = self._slots = [{'dir': None, 'used': 0,
                                     'fac': torch.empty(nf, dtype=torch.uint8, device=self.device),

@@ -2061,11 +2061,14 @@ template <class T> bool line_compact_used(const emg::Level<T> &L, int dir)
         // Also the three-phase kernel on lines of more than LINE_SHORT blocks (its T records only: its w records live
         // in LDS): the levels with 64- ... 128-block lines are bound by the same factor stream. Both plans must run the
         // same kind of kernel -- the streamed one rounds its w records, the three-phase one does not.
-        const LinePlan P1 = line_plan<T>(lc, 1), PB = line_plan<T>(lc, L.batch);
+        // ... for ANY number of right-hand sides: a class with few lines runs the three-phase kernel with 4 or 8 lines per
+        // workgroup for one source and the streamed kernel (16 lines per workgroup, records too large for LDS) for a
+        // batch -- such a level keeps fp64 records for everybody (PI: the plan of a very large batch).
+        const LinePlan P1 = line_plan<T>(lc, 1), PB = line_plan<T>(lc, L.batch), PI = line_plan<T>(lc, 1 << 10);
         auto ok = [](const LinePlan &P) {
             return P.kind == LK_STREAM || (P.kind == LK_COLOUR && !P.shortl && P.vmode >= 0 && P.vmode <= 2 && g_line_compact_colour);
         };
-        if (!ok(P1) || !ok(PB) || P1.kind != PB.kind) return false;
+        if (!ok(P1) || !ok(PB) || !ok(PI) || P1.kind != PB.kind || P1.kind != PI.kind) return false;
         any = true;
     }
     return any;

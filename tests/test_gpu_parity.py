@@ -738,6 +738,12 @@ def test_compact_three_phase_line_kernel_vs_cpu_walk(shape, lr, opts, dtype):
             lv = DeviceLevel.from_host(vm, dev)
             if compact:
                 lv.set_line_compact(True)
+                if not lib.emg3d_line_compact_used(lv._cref, lr):
+                    # a class with few lines (4- or 8-line workgroups, or slots 0..3 in LDS) runs the STREAMED kernel as soon
+                    # as it carries a batch: such a level keeps fp64 records for everybody, so that a source gives the same
+                    # bits alone and in a batch (kernels.hip: line_compact_used)
+                    assert shape in ((20, 128, 30), (12, 10, 300))
+                    pytest.skip('the level streams for batches: fp64 records for single sources too')
             assert lib.emg3d_line_compact_used(lv._cref, lr) == compact
             lv.s.copy_(torch.from_numpy(s.field))
             lv.e.copy_(torch.from_numpy(e0.field))
@@ -2074,7 +2080,9 @@ def test_line_factor_policy_rebuild_equals_resident(kw):
     if kw['linerelaxation'] in (True, 7):
         # (two / one buffer per level, each sized for the level's largest direction: on the slab-shaped levels of
         # a semicoarsened hierarchy the padded records of short lines cost more than a third)
-        assert nbytes['single'] < nbytes['rebuild'] <= 0.9 * nbytes['resident'] and nbytes['single'] <= 0.5 * nbytes['resident']
+        # (the buffers of 'rebuild' / 'single' are sized for a level's largest direction -- with compact records on some
+        #  directions and fp64 + N records on others the saving against 'resident' is smaller than 1/3 / 2/3)
+        assert nbytes['single'] < nbytes['rebuild'] < nbytes['resident'] and nbytes['single'] <= 0.6 * nbytes['resident'], nbytes
     with pytest.raises(ValueError, match='line_factors'):
         solver.Hierarchy(vmodel, line_factors='sometimes')
 
