@@ -146,15 +146,12 @@ int g_line_compact = 0;
 // 0.794 / 0.789 (the producers of y / z lines, whose gathers use half of every cache line, are what the chains wait
 // for: more chain loads in flight delay them; x-line producers read whole lines)
 int g_line_compact_rd = 0;
-// ... workgroups per CU of the compact kernel: 1 (four producer waves, 16 rows per ring chunk: 147 KB of LDS) or 2 (two
-// producer waves, 8 rows per chunk: 74 KB -- two workgroups of four waves share a CU and fill each other's start-up,
-// middle-block and drain phases)
-int g_line_compact_occ = 1;
+// (Measured and not kept as options -- profiles/r06_compact_line_kernel_ab.txt: two workgroups of four waves per CU with 8
+// rows per chunk, 0.915 / 0.761 / 0.773 ms per launch against 0.817 / 0.757 / 0.748; four producer waves instead of six,
+// 0.732 / 0.780 / 0.770 against 0.697 / 0.766 / 0.764; the w records of the rows nearest the middle block in LDS, +4-10 %.)
 // ... also on the levels that run k_line_colour with lines of more than LINE_SHORT blocks (1, default; 0: streamed levels only)
 int g_line_compact_colour = 1;
-// producer threads of the compact kernel: 384 (default; six waves) or 256 -- same-box A/B at 256^3, ms per launch
-// x / y / z: 0.732 / 0.780 / 0.770 with four producer waves, 0.697 / 0.766 / 0.764 with six
-int g_line_compact_np = 384;
+constexpr int LS_PROD_COMPACT = 384;      // producer threads of the compact single-source kernel: six waves
 
 // eta edge sums of the tiled point smoother: 8-byte storage (launch.h: tile_pst_*) for real
 // fields and for complex fields whose eta are purely imaginary (emg3d_level::flags)
@@ -1737,7 +1734,7 @@ __device__ __forceinline__ void quad_backward_stream(const emg::Level<T> &L, int
 // right-hand sides, the rings, every operation and the solution stay in T. 120 + 2 x 40 instead of 240 + 2 x 80
 // of the ~1 210 B a block costs per colour pass on the levels that live in HBM.
 template <class T, int DIR, int B, int RD, int NPROD, bool PAIR, bool LFR, bool COMPACT = false>
-__global__ __launch_bounds__(128 + NPROD, NPROD == 128 ? 2 : 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
+__global__ __launch_bounds__(128 + NPROD, 1) void k_line_stream(emg::Level<T> L, int colour, int cntp, int cntq, int n0p,
                                                                     int lpw, int R, const void *facv, const double *lfac,
                                                                     T *vecT, size_t vstrideT, size_t boff0)
 {
@@ -2097,25 +2094,16 @@ void launch_stream_group(const emg::Level<T> &L, int c, const emg::LineClass &lc
     }
     if constexpr (B == 1) {
         const bool rd8 = g_line_compact_rd == 8 || (g_line_compact_rd == 0 && DIR == 0);
-        if (compact) kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, NPROD, false, true, true>
-                                : (const void *)&k_line_stream<T, DIR, 1, RD, NPROD, false, true, true>;
+        if (compact) {
+            kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, LS_PROD_COMPACT, false, true, true>
+                       : (const void *)&k_line_stream<T, DIR, 1, RD, LS_PROD_COMPACT, false, true, true>;
+            nprod = LS_PROD_COMPACT;
+        }
         // rows per ring chunk of the compact kernel: 16 for x-lines (their producers read 16 consecutive blocks of a line as
         // one contiguous segment), 8 for y / z lines (same-box A/B at 256^3: x 0.709 -> 0.775, y 0.785 -> 0.764, z 0.780 ->
         // 0.766 ms per launch with 8) unless option line_stream_r names a value
         if (compact && DIR != 0 && g_line_stream_r == 0 && R > 8) {
             R = 8;
-            smem_c = (size_t)2 * 2 * R * lpw * 5 * sizeof(T) + (size_t)2 * 2 * R * lpw * 8 * sizeof(double);
-        }
-        if (compact && g_line_compact_np == 384) {
-            kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, 384, false, true, true>
-                       : (const void *)&k_line_stream<T, DIR, 1, RD, 384, false, true, true>;
-            nprod = 384;
-        }
-        if (compact && g_line_compact_occ == 2) {
-            kern = rd8 ? (const void *)&k_line_stream<T, DIR, 1, 8, 128, false, true, true>
-                       : (const void *)&k_line_stream<T, DIR, 1, RD, 128, false, true, true>;
-            nprod = 128;
-            R = R > 8 ? 8 : R;
             smem_c = (size_t)2 * 2 * R * lpw * 5 * sizeof(T) + (size_t)2 * 2 * R * lpw * 8 * sizeof(double);
         }
     }
@@ -2572,8 +2560,7 @@ static const OptionEntry g_options[] = {
     {"line_order", &g_line_order},       {"point_order", &emg::point_order_ref()},
     {"line_stream_bmin", &g_line_stream_bmin}, {"line_stream_lf", &g_line_stream_lf}, {"residual_roll", &g_residual_roll},
     {"line_wide", &g_line_wide},         {"line_wide_bt", &g_line_wide_bt},     {"line_compact", &g_line_compact},
-    {"line_compact_rd", &g_line_compact_rd}, {"line_compact_occ", &g_line_compact_occ},
-    {"line_compact_np", &g_line_compact_np}, {"point_compact", &g_point_compact},
+    {"line_compact_rd", &g_line_compact_rd}, {"point_compact", &g_point_compact},
     {"line_compact_colour", &g_line_compact_colour},
 };
 constexpr int N_OPTIONS = sizeof(g_options) / sizeof(g_options[0]);

@@ -160,9 +160,8 @@ int emg3d_device_count(void);
  * every level whose direction streams (tests, timing), -1 never (the flag is ignored). CHANGES the rounding of the
  * streamed line solves (see EMG3D_LEVEL_LINE_COMPACT).
  * "point_compact": the same three values for the eta sums of the tiled point smoother (EMG3D_LEVEL_POINT_COMPACT).
- * "line_compact_rd" (0 = 8 for x-lines, 4 else), "line_compact_np" (384 | 256), "line_compact_occ" (1 | 2): launch
- * shape of the compact streamed kernel (prefetch depth of the chain waves, producer threads, workgroups per CU); no
- * influence on results.
+ * "line_compact_rd" (0 = 8 for x-lines, 4 else; 4 | 8): prefetch depth of the chain waves of the compact streamed
+ * kernel; no influence on results.
  * "line_debug" is for timing experiments only (bit 0 aliases the records of a line: WRONG
  * results); a non-zero value is refused unless the environment variable EMG3D_AMD_ALLOW_DEBUG is set.
  * Out-of-range values of "line_order" (0..2) and "point_order" (0..1) are refused (EMG3D_ERR_BADARG). */
