@@ -190,14 +190,19 @@ class DeviceLevel:
                                  for lr in (1, 2, 3)))
         return top
 
-    def set_line_compact(self, on=True):
+    def set_line_compact(self, on=True, point_here=True):
         """Mark this level (and the coarse levels made from it afterwards) as solving correction equations only:
         the streamed line passes keep their T and w records, the tiled point smoother its eta sums in single precision
-        (include/emg3d_amd.h: EMG3D_LEVEL_LINE_COMPACT, _POINT_COMPACT). Before the first factorisation of the level."""
+        (include/emg3d_amd.h: EMG3D_LEVEL_LINE_COMPACT, _POINT_COMPACT). Before the first factorisation of the level.
+        point_here = False: the point smoother of THIS level keeps fp64 sums (the coarse levels below it do not): a
+        finest level that would run in residual form for their sake alone -- a plain multigrid solve at a loose tolerance
+        -- loses more to the residual form than the narrower sums save (solver.Hierarchy(point_compact_top=))."""
         if self._factors or self.__dict__.get('_slots') or self.children:
             raise RuntimeError("set_line_compact: the level already has factors or coarse levels")
         bits = _lib.LEVEL_LINE_COMPACT | _lib.LEVEL_POINT_COMPACT
-        self.flags = (self.flags | bits) if on else (self.flags & ~bits)
+        base = self.flags & ~bits
+        self._child_flags = (base | bits) if on else base
+        self.flags = (base | _lib.LEVEL_LINE_COMPACT | (_lib.LEVEL_POINT_COMPACT if point_here else 0)) if on else base
         self._c.flags = self.flags
         self.work.line_compact = bool(on)
 
@@ -495,7 +500,7 @@ class DeviceLevel:
                   if self.case in ('VTI', 'triaxial') else ceta_x)
         czeta = restrict_param(self.zeta, 0, torch.float64)
         clevel = DeviceLevel(cgrid, self.case, ceta_x, ceta_y, ceta_z, czeta, self.dtype,
-                             self.work, self.device, self.batch, self.flags)
+                             self.work, self.device, self.batch, self.__dict__.get('_child_flags', self.flags))
 
         # restriction weights (only for coarsened directions; others are never read) and
         # prolongation tables: all 1-D arrays of the link go up in ONE float64 and ONE int32

@@ -348,7 +348,8 @@ def solve_batch(model, sfields, semicoarsening=True, linerelaxation=True, verb=0
         hierarchy.check(vmodel)
         hier = hierarchy
     else:
-        hier = Hierarchy(vmodel, batch=nb, line_compact=line_compact)
+        hier = Hierarchy(vmodel, batch=nb, line_compact=line_compact,
+                         point_compact_top=bool(var.sslsolver) or bool(getattr(svar, 'residual_form', False)))
     top = hier.top
     for v in vars_:
         v.hierarchy_compact = hier.line_compact
@@ -589,7 +590,7 @@ def block_condition(vmodel):
 class Hierarchy:
     """Level 0 on the device for one (model, frequency): upload once, cycle many times."""
 
-    def __init__(self, vmodel, device=None, batch=1, line_factors=None, line_compact=None):
+    def __init__(self, vmodel, device=None, batch=1, line_factors=None, line_compact=None, point_compact_top=False):
         """line_compact: True / False / 'auto' (default; or the environment's EMG3D_AMD_LINE_COMPACT) -- COMPACT line
         records: on the levels whose line passes stream their records through HBM (lines of ~128 blocks and more) the
         inverse blocks of the stored line factorisation and the forward pass's w records are kept in single precision
@@ -621,8 +622,13 @@ class Hierarchy:
         if line_compact == 'auto':
             line_compact = block_condition(vmodel) <= COMPACT_COND_MAX
         self.line_compact = bool(line_compact)
+        # point_compact_top: also the FINEST level's tiled point smoother keeps its eta sums in single precision. That
+        # level must then cycle in residual form; `solve` asks for it where it does anyway (tolerance below 1e-7, models
+        # with air, multigrid as a Krylov preconditioner), not for a plain multigrid solve at a loose tolerance, where the
+        # residual form would cost more (~0.9 ms per 256^3 cycle) than the narrower sums save (~0.35 ms).
+        self.point_compact_top = bool(point_compact_top) and self.line_compact
         if self.line_compact:
-            self.top.set_line_compact(True)
+            self.top.set_line_compact(True, point_here=self.point_compact_top)
 
     def check(self, vmodel):
         """A hierarchy handed to ``solve`` must belong to the same grid shape and frequency
@@ -676,7 +682,8 @@ def multigrid(model, sfield, efield, var, **kwargs):
     count in ``var.it``, final error in ``var.l2``. The level hierarchy lives in HBM for the
     duration of the call; pass ``hierarchy=`` (a ``Hierarchy``) to reuse one.
     """
-    hier = kwargs.get('hierarchy') or Hierarchy(model, line_compact=getattr(var, 'line_compact', None))
+    hier = kwargs.get('hierarchy') or Hierarchy(model, line_compact=getattr(var, 'line_compact', None),
+                                                point_compact_top=bool(getattr(var, 'residual_form', False)))
     var.hierarchy_compact = hier.line_compact
     hier.upload(sfield, efield, getattr(var, 'sparse_source', False))
     try:
@@ -715,7 +722,8 @@ def krylov(model, sfield, efield, var, hierarchy=None):
     routines.
     """
     from emg3d_amd import _krylov
-    hier = hierarchy or Hierarchy(model, line_compact=getattr(var, 'line_compact', None))
+    # (as a preconditioner every level, the finest included, solves a correction equation)
+    hier = hierarchy or Hierarchy(model, line_compact=getattr(var, 'line_compact', None), point_compact_top=True)
     var.hierarchy_compact = hier.line_compact
     device_solver = {'bicgstab': _krylov.bicgstab, 'cgs': _krylov.cgs, 'gcrotmk': _krylov.gcrotmk}[var.sslsolver]
     try:
