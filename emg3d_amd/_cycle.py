@@ -340,7 +340,8 @@ def run_cycles(top, var):
     # cond of a block, relative to the right-hand side they are given -- then scale with the
     # residual, not with the field, and the iteration converges to round-off.
     resform = bool(getattr(var, 'residual_form', False)) and not var.sslsolver and top.batch == 1
-    if not resform and not var.sslsolver and top.batch == 1 and getattr(top, 'uses_line_compact', lambda: False)():
+    if (not resform and not var.sslsolver and top.batch == 1 and
+            getattr(top, 'uses_line_compact', lambda lines=True: False)(lines=bool(var.lr_cycle) or var.lr_dir != 0)):
         # compact line records (solver.Hierarchy(line_compact=...)): the streamed line solves are perturbed by
         # eps32 x cond, the finest level must see residuals, not the field
         resform = var.residual_form = True

@@ -206,13 +206,14 @@ class DeviceLevel:
         self._c.flags = self.flags
         self.work.line_compact = bool(on)
 
-    def uses_line_compact(self):
-        """Does a line direction of THIS level keep compact records (the flag is set and the direction streams)? The
-        finest level of such a hierarchy runs in residual form (_cycle.run_cycles)."""
+    def uses_line_compact(self, lines=True):
+        """Does a smoother of THIS level keep compact records -- a line direction (the flag is set and the direction
+        streams or runs the three-phase kernel on long lines; only asked if the solve relaxes lines at all: `lines`), or
+        the tiled point smoother? The finest level of such a solve runs in residual form (_cycle.run_cycles)."""
         if not self.flags & (_lib.LEVEL_LINE_COMPACT | _lib.LEVEL_POINT_COMPACT):
             return False
         lib = _lib.lib()
-        return (any(lib.emg3d_line_compact_used(self._cref, lr) for lr in (1, 2, 3)) or
+        return ((lines and any(lib.emg3d_line_compact_used(self._cref, lr) for lr in (1, 2, 3))) or
                 bool(lib.emg3d_point_compact_used(self._cref)))
 
     @property

@@ -400,7 +400,7 @@ def _multigrid_batch(lv, svar, vars_, active=None):
     # (finest level in residual form, as _cycle.run_cycles does it for one source)
     resform = bool(getattr(svar, 'residual_form', False)) and not svar.sslsolver
     may_switch = bool(getattr(svar, 'residual_form_auto', False)) and not svar.sslsolver
-    if not resform and not svar.sslsolver and lv.uses_line_compact():
+    if not resform and not svar.sslsolver and lv.uses_line_compact(lines=bool(svar.lr_cycle) or svar.lr_dir != 0):
         # (compact line records on this level: it must see residuals, as in _cycle.run_cycles)
         resform = svar.residual_form = True
         for v in vars_:
