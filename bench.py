@@ -143,7 +143,7 @@ def workload(name, source_index=0, with_model=True):
 
 # -------------------------------------------------------------------------- GPU side ---
 class Bench:
-    def __init__(self, wl, model, device):
+    def __init__(self, wl, model, device, line_compact=None):
         import torch
         import emg3d_amd as emg3d
         from emg3d_amd import solver
@@ -153,7 +153,7 @@ class Bench:
         self.sfield = emg3d.get_source_field(grid, wl['source'], wl['frequency'])
         vmodel = emg3d.models.VolumeModel(model, self.sfield)
         self.grid, self.case = grid, model.case
-        self.hier = solver.Hierarchy(vmodel, device)
+        self.hier = solver.Hierarchy(vmodel, device, line_compact=line_compact)
         self.efield = emg3d.Field(grid, frequency=wl['frequency'])
         self.hier.upload(self.sfield, self.efield)
         self.var = solver.MGParameters(verb=0, sslsolver=False, shape_cells=grid.shape_cells,
@@ -198,6 +198,32 @@ class Bench:
             st['launches'] += 4 * nu - ((nu - 1) if self.skip_repeat else 0)
             st['ms'] += ms
         return stats
+
+
+def cycle_fp64_storage(wl, model, device, steps):
+    """The same timed cycles with every coefficient record in fp64 (Hierarchy(line_compact=False): round 5's storage, the
+    finest level in direct form) next to the headline, which runs the solver's defaults -- single-precision STORAGE of the
+    streamed line passes' T / w records and of the coarse levels' eta sums where the model's block condition allows it,
+    all arithmetic fp64, converged fields and cycle counts those of the fp64 oracle (tests, profiles/r06_full_size_converged.txt)."""
+    import torch
+    b = Bench(wl, model, device, line_compact=False)
+    b.cycles((b.solver._GRAPH_AFTER + 1) * b.var.maxcycle)
+    w0 = b.var.smoother_cell_sweeps
+    b.recording = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b.cycles(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    b.recording = False
+    stats = b.kernel_stats()
+    dom = max(stats, key=lambda k: stats[k]['ms'])
+    ms_launch = stats[dom]['ms'] / stats[dom]['launches']
+    bpl = BYTES_PER_CELL_SWEEP[b.case] * b.grid.n_cells / 4.0
+    return {'line_factor_storage': 'fp64', 'residual_form': bool(getattr(b.var, 'residual_form', False)), 'steps': steps,
+            'ms_per_step': dt / steps * 1e3, 'value': (b.var.smoother_cell_sweeps - w0) / dt / 1e6,
+            'dominant_level0_kernel': {1: 'k_gs_line<x>', 2: 'k_gs_line<y>', 3: 'k_gs_line<z>', 0: 'k_gs_point'}[dom],
+            'ms_per_launch': ms_launch, 'frac': bpl / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def line_kernel_name(lr, shape, batch=1, is_complex=True):
@@ -659,6 +685,13 @@ def run_gpu(args):
             out['time_to_tol'] = time_to_tol(args.workload, wl, b)
         except Exception as exc:        # informational block: never takes the bench line down
             out['time_to_tol'] = {'error': repr(exc)}
+    if rank == 0 and world == 1 and not args.no_ttt and b.hier.line_compact:
+        try:       # both storages in one line (the review of round 5): the cycle with fp64 records, same process, same box
+            out['fp64_storage'] = fs = cycle_fp64_storage(wl, model, device, max(2, min(args.steps, 10)))
+            out['roofline']['frac_fp64_storage'] = fs['frac']
+            out['ms_per_step_fp64_storage'] = fs['ms_per_step']
+        except Exception as exc:        # informational block: never takes the bench line down
+            out['fp64_storage'] = {'error': repr(exc)}
     if rank == 0 and world == 1 and not args.no_256:
         del b            # (its buffers stay with the caching allocator: handing tens of GB back to the driver makes a later
                          #  hipMalloc take 1.7 - 2 s on this stack, profiles/r05_config5_stall.txt)
